@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running CPU test (enable with VSG_SLOW=1)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("VSG_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow test; set VSG_SLOW=1")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)

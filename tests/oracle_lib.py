@@ -1,0 +1,295 @@
+"""ctypes binding of the CPU oracle (oracle/libvs_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB_PATH = os.path.join(ORACLE_DIR, "libvs_oracle.so")
+
+
+class VsoOptions(C.Structure):
+    _fields_ = [
+        ("presmoothing", C.c_int),
+        ("frac_min_region_size", C.c_float),
+        ("chunk_size", C.c_int),
+        ("chunk_overlap_ratio", C.c_float),
+        ("num_constraint_frames", C.c_int),
+        ("enforce_n4_connectivity", C.c_int),
+        ("enforce_spatial_connectedness", C.c_int),
+        ("color_distance", C.c_int),
+    ]
+
+
+def build_oracle(force=False):
+    src = os.path.join(ORACLE_DIR, "vs_oracle.cpp")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build_oracle()
+    L = C.CDLL(_LIB_PATH)
+    vp = C.c_void_p
+    L.vso_default_options.argtypes = [C.POINTER(VsoOptions)]
+    L.vso_stream_create.restype = vp
+    L.vso_stream_create.argtypes = [C.POINTER(VsoOptions), C.c_int, C.c_int]
+    L.vso_stream_destroy.argtypes = [vp]
+    L.vso_stream_process_frame.restype = C.c_int
+    L.vso_stream_process_frame.argtypes = [vp, C.c_int, vp, C.c_size_t, vp, C.c_int]
+    L.vso_stream_num_results.restype = C.c_int
+    L.vso_stream_num_results.argtypes = [vp]
+    L.vso_stream_result_bytes.restype = C.c_int
+    L.vso_stream_result_bytes.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.vso_stream_result_id_image.restype = C.c_int
+    L.vso_stream_result_id_image.argtypes = [vp, C.c_int, vp]
+    L.vso_stream_result_num_regions.restype = C.c_int
+    L.vso_stream_result_num_regions.argtypes = [vp, C.c_int]
+    L.vso_stream_result_hierarchy_regions.restype = C.c_int
+    L.vso_stream_result_hierarchy_regions.argtypes = [vp, C.c_int]
+    L.vso_stream_result_first_region.restype = C.c_int
+    L.vso_stream_result_first_region.argtypes = [vp, C.c_int, C.POINTER(C.c_int), vp]
+    L.vso_stream_last_merge_stats.argtypes = [vp, vp]
+    L.vso_stream_last_smoothed.restype = C.c_int
+    L.vso_stream_last_smoothed.argtypes = [vp, vp]
+    L.vso_preprocess.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp]
+    L.vso_bilateral_tables.restype = C.c_float
+    L.vso_bilateral_tables.argtypes = [C.c_float, C.c_float, vp, vp]
+    L.vso_spatial_buckets.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+    L.vso_temporal_buckets.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.vso_graph_create.restype = vp
+    L.vso_graph_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.vso_graph_destroy.argtypes = [vp]
+    L.vso_graph_add_frame.argtypes = [vp, vp, vp]
+    L.vso_graph_add_virtual_frame.argtypes = [vp, vp]
+    L.vso_graph_add_temporal.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.vso_graph_segment.argtypes = [vp, C.c_int, C.c_int]
+    L.vso_graph_obtain_results.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.vso_graph_num_regions.restype = C.c_int
+    L.vso_graph_num_regions.argtypes = [vp]
+    L.vso_graph_num_neighbor_links.restype = C.c_int64
+    L.vso_graph_num_neighbor_links.argtypes = [vp]
+    L.vso_graph_node_roots.argtypes = [vp, vp]
+    L.vso_graph_index_image.argtypes = [vp, C.c_int, vp]
+    L.vso_graph_region_sizes.argtypes = [vp, vp, vp]
+    L.vso_graph_merge_stats.argtypes = [vp, vp]
+    L.vso_graph_bucket_census.argtypes = [vp, vp]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_options(**kw):
+    o = VsoOptions()
+    lib().vso_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class OracleStream:
+    """DenseSegmentation::ProcessFrame restatement."""
+
+    def __init__(self, width, height, options=None, has_flow=False):
+        self.W, self.H = width, height
+        self.has_flow = has_flow
+        self.opts = options if options is not None else default_options()
+        self.h = lib().vso_stream_create(C.byref(self.opts), width, height)
+
+    def close(self):
+        if self.h:
+            lib().vso_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def process_frame(self, bgr, flow=None, flush=False):
+        """bgr: HxWx3 uint8 (any row stride) or None.  Returns number of results."""
+        if bgr is not None:
+            assert bgr.dtype == np.uint8 and bgr.shape == (self.H, self.W, 3)
+            assert bgr.strides[2] == 1 and bgr.strides[1] == 3
+            stride = bgr.strides[0]
+        else:
+            stride = 0
+        if flow is not None:
+            flow = np.ascontiguousarray(flow, dtype=np.float32)
+            assert flow.shape == (self.H, self.W, 2)
+        return lib().vso_stream_process_frame(self.h, int(flush), _ptr(bgr), stride, _ptr(flow),
+                                              int(self.has_flow))
+
+    def num_results(self):
+        return lib().vso_stream_num_results(self.h)
+
+    def result_bytes(self, i):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        rc = lib().vso_stream_result_bytes(self.h, i, C.byref(p), C.byref(n))
+        assert rc == 0
+        return C.string_at(p, n.value)
+
+    def result_id_image(self, i):
+        out = np.empty((self.H, self.W), np.int32)
+        assert lib().vso_stream_result_id_image(self.h, i, _ptr(out)) == 0
+        return out
+
+    def result_num_regions(self, i):
+        return lib().vso_stream_result_num_regions(self.h, i)
+
+    def result_hierarchy_regions(self, i):
+        return lib().vso_stream_result_hierarchy_regions(self.h, i)
+
+    def result_first_region(self, i):
+        rid = C.c_int()
+        m = np.zeros(6, np.float32)
+        assert lib().vso_stream_result_first_region(self.h, i, C.byref(rid), _ptr(m)) == 0
+        return rid.value, m
+
+    def last_merge_stats(self):
+        s = np.zeros(3, np.int64)
+        lib().vso_stream_last_merge_stats(self.h, _ptr(s))
+        return s
+
+    def last_smoothed(self):
+        out = np.empty((self.H, self.W, 3), np.float32)
+        assert lib().vso_stream_last_smoothed(self.h, _ptr(out)) == 0
+        return out
+
+
+def preprocess(bgr, presmoothing=2):
+    H, W, _ = bgr.shape
+    out = np.empty((H, W, 3), np.float32)
+    lib().vso_preprocess(_ptr(bgr), bgr.strides[0], W, H, presmoothing, _ptr(out))
+    return out
+
+
+def bilateral_tables(min_val, max_val):
+    lut = np.empty(12288, np.float32)
+    sw = np.empty(81, np.float32)
+    scale = lib().vso_bilateral_tables(float(min_val), float(max_val), _ptr(lut), _ptr(sw))
+    return scale, lut, sw[:49].copy()
+
+
+def spatial_buckets(feat, l1=False):
+    H, W, _ = feat.shape
+    feat = np.ascontiguousarray(feat, np.float32)
+    out = np.empty((4, H, W), np.uint16)
+    lib().vso_spatial_buckets(_ptr(feat), W, H, int(l1), _ptr(out))
+    return out
+
+
+def temporal_buckets(cur, prev, flow=None, l1=False):
+    H, W, _ = cur.shape
+    cur = np.ascontiguousarray(cur, np.float32)
+    prev = np.ascontiguousarray(prev, np.float32)
+    if flow is not None:
+        flow = np.ascontiguousarray(flow, np.float32)
+    out = np.empty((9, H, W), np.uint16)
+    pidx = np.empty((H, W), np.int32)
+    lib().vso_temporal_buckets(_ptr(cur), _ptr(prev), _ptr(flow), W, H, int(l1), _ptr(out),
+                               _ptr(pidx))
+    return out, pidx
+
+
+class OracleGraph:
+    """DenseSegGraphInterface restatement (seam 3)."""
+
+    def __init__(self, width, height, max_frames, l1=False):
+        self.W, self.H, self.max_frames = width, height, max_frames
+        self.h = lib().vso_graph_create(width, height, max_frames, int(l1))
+        self._keep = []
+        self.num_frames = 0
+
+    def close(self):
+        if self.h:
+            lib().vso_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def add_frame(self, feat, constraint_ids=None):
+        feat = np.ascontiguousarray(feat, np.float32)
+        self._keep.append(feat)
+        if constraint_ids is not None:
+            constraint_ids = np.ascontiguousarray(constraint_ids, np.int32)
+        lib().vso_graph_add_frame(self.h, _ptr(feat), _ptr(constraint_ids))
+        self.num_frames += 1
+
+    def add_virtual_frame(self, constraint_ids):
+        constraint_ids = np.ascontiguousarray(constraint_ids, np.int32)
+        lib().vso_graph_add_virtual_frame(self.h, _ptr(constraint_ids))
+        self.num_frames += 1
+
+    def add_temporal(self, cur, prev, flow=None, is_virtual=False):
+        if flow is not None:
+            flow = np.ascontiguousarray(flow, np.float32)
+            self._keep.append(flow)
+        lib().vso_graph_add_temporal(self.h, _ptr(cur), _ptr(prev), _ptr(flow), int(is_virtual))
+
+    def segment(self, min_region_size, force_constraints):
+        lib().vso_graph_segment(self.h, min_region_size, int(force_constraints))
+
+    def node_roots(self):
+        out = np.empty(self.W * self.H * self.num_frames, np.int32)
+        lib().vso_graph_node_roots(self.h, _ptr(out))
+        return out
+
+    def obtain_results(self, flows=None, enforce_n4=True, enforce_spatial_connectedness=True):
+        arr = None
+        if flows is not None:
+            arr = (C.c_void_p * len(flows))()
+            for i, f in enumerate(flows):
+                if f is not None:
+                    f = np.ascontiguousarray(f, np.float32)
+                    self._keep.append(f)
+                    arr[i] = f.ctypes.data
+                else:
+                    arr[i] = None
+        lib().vso_graph_obtain_results(self.h, arr, int(enforce_n4),
+                                       int(enforce_spatial_connectedness))
+
+    def num_regions(self):
+        return lib().vso_graph_num_regions(self.h)
+
+    def num_neighbor_links(self):
+        return lib().vso_graph_num_neighbor_links(self.h)
+
+    def index_image(self, t):
+        out = np.empty((self.H, self.W), np.int32)
+        lib().vso_graph_index_image(self.h, t, _ptr(out))
+        return out
+
+    def region_sizes(self):
+        n = self.num_regions()
+        s = np.empty(n, np.int32)
+        c = np.empty(n, np.int32)
+        lib().vso_graph_region_sizes(self.h, _ptr(s), _ptr(c))
+        return s, c
+
+    def merge_stats(self):
+        s = np.zeros(3, np.int64)
+        lib().vso_graph_merge_stats(self.h, _ptr(s))
+        return s
+
+    def bucket_census(self):
+        out = np.zeros((2048, 7), np.int64)
+        lib().vso_graph_bucket_census(self.h, _ptr(out))
+        return out
