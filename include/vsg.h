@@ -1,0 +1,168 @@
+/*
+ * vsg.h -- C ABI of the MI355X-native dense over-segmentation hot path (libvsg_hip.so).
+ *
+ * This is the drop-in boundary: plain pointers, sizes and status ints, no C++ or torch types.
+ * Two seams of the reference are mirrored (reference paths relative to the reference root):
+ *
+ *   vsg_stream_*  <->  segmentation::DenseSegmentation            (seam 2)
+ *       segmentation/dense_segmentation.h:112-186  (ProcessFrame, ChunkSize)
+ *       called by DenseSegmentationUnit::ProcessFrame/PostProcess, segmentation_unit.cpp:118-161
+ *
+ *   vsg_graph_*   <->  segmentation::DenseSegGraphInterface       (seam 3)
+ *       segmentation/dense_seg_graph_interface.h:107-159 (13 pure virtuals)
+ *       obtained through DenseSegmentation::CreateDenseSegGraph, dense_segmentation.cpp:253-266
+ *
+ * Results cross the boundary as serialized segmentation.proto `SegmentationDesc` messages
+ * (segment_util/segmentation.proto:55-172), i.e. exactly what the reference's units exchange as
+ * PointerFrame<SegmentationDesc>; INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions: every function returns VSG_OK (0) or a negative status; vsg_last_error() returns
+ * a thread-local message for the last failure.  A handle is thread-compatible (one caller thread
+ * per handle, like the reference's units) and owns one HIP stream.  Pointers returned by the
+ * library stay valid until the next call on the same handle.  There is NO CPU fallback: if no
+ * HIP device is usable, creation fails with VSG_ERR_DEVICE.
+ */
+#ifndef VSG_H_
+#define VSG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSG_OK 0
+#define VSG_ERR_INVALID -1   /* bad argument / contract violation (reference: glog CHECK)   */
+#define VSG_ERR_DEVICE -2    /* HIP runtime error / no device                              */
+#define VSG_ERR_STATE -3     /* call not valid in the handle's current state               */
+#define VSG_ERR_INTERNAL -4  /* invariant violated inside the library                      */
+
+/* Where the memory behind a frame / flow / label pointer lives. */
+#define VSG_MEM_HOST 0
+#define VSG_MEM_DEVICE 1
+
+typedef struct vsg_stream vsg_stream;
+typedef struct vsg_graph vsg_graph;
+
+/* Mirrors segmentation::DenseSegmentationOptions (dense_segmentation.h:42-95). */
+typedef struct vsg_options {
+  int presmoothing;                   /* 0 PRESMOOTH_NONE, 2 PRESMOOTH_BILATERAL (default)  */
+  float frac_min_region_size;         /* 0.01f                                              */
+  int chunk_size;                     /* 20, must be >= 3                                   */
+  float chunk_overlap_ratio;          /* 0.2f                                               */
+  int num_constraint_frames;          /* 1                                                  */
+  int enforce_n4_connectivity;        /* 1                                                  */
+  int enforce_spatial_connectedness;  /* 1                                                  */
+  int color_distance;                 /* 0 COLOR_DISTANCE_L1, 1 COLOR_DISTANCE_L2 (default) */
+  int device;                         /* HIP device ordinal, -1 = current device            */
+} vsg_options;
+
+/* Per-stage device time of the last segmented chunk, milliseconds (HIP events on the handle's
+ * stream) and work counters; used by bench.py for the roofline line. */
+typedef struct vsg_timings {
+  float preprocess_ms;     /* min/max + bilateral, summed over the chunk's frames           */
+  float edges_ms;          /* spatial + temporal edge weight / bucket kernels               */
+  float sort_ms;           /* bucket counting sort                                          */
+  float merge_ms;          /* ordered union-find merge (all buckets)                        */
+  float readout_ms;        /* flatten, N4, run-length, neighbours (device part)             */
+  float host_post_ms;      /* host: tube splitting, ids, SegmentationDesc assembly          */
+  int64_t edges_total;     /* edges in the chunk graph                                      */
+  int64_t edges_active;    /* edges that reached an exact merge worker                      */
+  int64_t merges;          /* forced + regular + small merges                               */
+  int64_t preprocess_launches;
+  int64_t edge_launches;
+} vsg_timings;
+
+const char* vsg_last_error(void);
+int vsg_version(void);
+void vsg_default_options(vsg_options* o);
+/* Number of visible HIP devices (0 => every create call fails loudly). */
+int vsg_device_count(void);
+
+/* ---- seam 2: DenseSegmentation ------------------------------------------------------------ */
+/* DenseSegmentation::DenseSegmentation(options, frame_width, frame_height), cpp:50-106. */
+int vsg_stream_create(const vsg_options* o, int width, int height, vsg_stream** out);
+void vsg_stream_destroy(vsg_stream* s);
+/* int DenseSegmentation::ProcessFrame(flush, features, flow, results), cpp:108-162.
+ *   bgr    : H rows of W BGR24 pixels, `stride` bytes apart (VideoFrame::MatView); NULL with
+ *            flush != 0 for a pure flush (DenseSegmentationUnit::PostProcess).
+ *   flow   : backward flow, W*H interleaved (x,y) f32 (DenseFlowFrame::MatViewInterleaved), or
+ *            NULL.  has_flow_stream says whether the unit has a flow stream at all; the flow of
+ *            the first frame is ignored (segmentation_unit.cpp:124-130).
+ *   mem    : VSG_MEM_HOST or VSG_MEM_DEVICE for both pointers.
+ * *num_results = number of SegmentationDesc now available (0: frame buffered). */
+int vsg_stream_process_frame(vsg_stream* s, int flush, const uint8_t* bgr, size_t stride,
+                             const float* flow, int has_flow_stream, int mem, int* num_results);
+/* DenseSegmentation::ChunkSize(), h:130. */
+int vsg_stream_chunk_size(const vsg_stream* s);
+/* Result i of the last process_frame call as serialized SegmentationDesc. */
+int vsg_stream_result_bytes(vsg_stream* s, int i, const uint8_t** data, size_t* len);
+/* Convenience: SegmentationDescToIdImage(level 0) of result i (segmentation_util.cpp:741-770);
+ * out is W*H int32 in host memory. */
+int vsg_stream_result_id_image(vsg_stream* s, int i, int32_t* out);
+int vsg_stream_last_merge_stats(const vsg_stream* s, int64_t* forced_regular_small);
+int vsg_stream_last_timings(const vsg_stream* s, vsg_timings* t);
+/* Parity hook: smoothed feature planes of the most recently added frame, W*H*3 f32 BGR
+ * interleaved, host memory (PreprocessFeatures output, cpp:164-198). */
+int vsg_stream_last_smoothed(vsg_stream* s, float* out);
+
+/* Multi-GPU hand-off: everything chunk c+1 needs from chunk c.
+ * The two label planes are the region-id images of the two overlap frames
+ * (overlap_segmentations_[0..1], dense_segmentation.cpp:300-308, 400-403) in DEVICE memory of the
+ * exporting handle; scalars = {max_region_id_, chunk_id_, num_output_frames_, input_frames_}.
+ * Valid right after a process_frame call that returned results without flush. */
+int vsg_stream_export_halo(vsg_stream* s, const int32_t** dev_labels_virtual,
+                           const int32_t** dev_labels_constrained, int64_t scalars[4]);
+/* Starts a fresh stream in the middle of a video: the next chunk is constrained by the given
+ * label planes (mem says where they live).  The caller then feeds the constrained overlap frame
+ * first (with its flow), i.e. the frame `last_output_frame + 1` of the previous chunk. */
+int vsg_stream_import_halo(vsg_stream* s, const int32_t* labels_virtual,
+                           const int32_t* labels_constrained, int mem, const int64_t scalars[4]);
+
+/* ---- seam 3: DenseSegGraphInterface ------------------------------------------------------- */
+/* CreateDenseSegGraph(frame_width, frame_height, max_frames) + InitializeGraph(),
+ * dense_seg_graph_interface.h:46-48,112; l1 selects DistanceColorL1 (dense_segmentation.cpp:247-251). */
+int vsg_graph_create(int width, int height, int max_frames, int l1, int device, vsg_graph** out);
+void vsg_graph_destroy(vsg_graph* g);
+/* PreprocessFeatures + AddNodesAndSpatialEdges[Constrained] on a BGR24 frame
+ * (dense_segmentation.cpp:164-220; interface h:115-117).  constraint_ids: NULL or W*H int32. */
+int vsg_graph_add_frame_bgr(vsg_graph* g, const uint8_t* bgr, size_t stride, int presmoothing,
+                            const int32_t* constraint_ids, int mem);
+/* AddNodesAndSpatialEdges[Constrained] on already smoothed features (W*H*3 f32 interleaved),
+ * i.e. SpatialCvMatDistance3L2(feat). */
+int vsg_graph_add_frame_features(vsg_graph* g, const float* feat, const int32_t* constraint_ids,
+                                 int mem);
+/* AddVirtualNodesConstrained(desc) with desc rendered to a W*H int32 id image, h:121. */
+int vsg_graph_add_virtual_frame(vsg_graph* g, const int32_t* constraint_ids, int mem);
+/* AddTemporalEdges / AddTemporalFlowEdges / AddTemporalVirtualEdges / AddTemporalFlowVirtualEdges
+ * (h:124-132): connects the last two added slices.  flow NULL = no flow. */
+int vsg_graph_add_temporal(vsg_graph* g, const float* flow, int is_virtual, int mem);
+/* FinishBuildingGraph (h:135): waits for the asynchronous build kernels. */
+int vsg_graph_finish_building(vsg_graph* g);
+/* SegmentFullGraph(min_region_size, force_constraints), h:141. */
+int vsg_graph_segment(vsg_graph* g, int min_region_size, int force_constraints);
+/* ObtainResults(..., flows, false, enforce_n4, enforce_spatial_connectedness) followed by
+ * DetermineNeighborIds (h:147-158).  use_flows: pass the flows given to add_temporal. */
+int vsg_graph_obtain_results(vsg_graph* g, int use_flows, int enforce_n4,
+                             int enforce_spatial_connectedness);
+int vsg_graph_num_frames(const vsg_graph* g);
+int vsg_graph_num_regions(const vsg_graph* g);
+int64_t vsg_graph_num_neighbor_links(const vsg_graph* g);
+/* Region table after obtain_results: size and constrained id per RegionInformation index. */
+int vsg_graph_region_sizes(const vsg_graph* g, int32_t* sizes, int32_t* constrained_ids);
+/* Per-pixel RegionInformation index of slice t from the rasterizations (host, W*H int32). */
+int vsg_graph_index_image(const vsg_graph* g, int t, int32_t* out);
+/* Parity hooks (host memory outputs). */
+int vsg_graph_smoothed(vsg_graph* g, int t, float* out /* W*H*3 interleaved */);
+int vsg_graph_spatial_buckets(vsg_graph* g, int t, uint16_t* out /* 4*W*H, plane k */);
+int vsg_graph_temporal_buckets(vsg_graph* g, int t, uint16_t* out /* 9*W*H */, int32_t* prev_idx);
+/* Union-find representative (node id) of every node after segment(); n = W*H*frames. */
+int vsg_graph_node_roots(vsg_graph* g, int32_t* out);
+int vsg_graph_merge_stats(const vsg_graph* g, int64_t* forced_regular_small);
+int vsg_graph_timings(const vsg_graph* g, vsg_timings* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSG_H_ */

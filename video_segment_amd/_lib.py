@@ -1,0 +1,137 @@
+"""ctypes loader of the product library libvsg_hip.so (C ABI: include/vsg.h).
+
+The library is the HIP path; there is no Python or CPU fallback.  Loading fails loudly if the
+shared object has not been built (run ``python -c 'import __graft_entry__ as g; g.build()'`` or
+``make -C video_segment_amd/csrc``).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "lib", "libvsg_hip.so")
+
+VSG_OK = 0
+VSG_MEM_HOST = 0
+VSG_MEM_DEVICE = 1
+
+
+class VsgOptions(C.Structure):
+    _fields_ = [
+        ("presmoothing", C.c_int),
+        ("frac_min_region_size", C.c_float),
+        ("chunk_size", C.c_int),
+        ("chunk_overlap_ratio", C.c_float),
+        ("num_constraint_frames", C.c_int),
+        ("enforce_n4_connectivity", C.c_int),
+        ("enforce_spatial_connectedness", C.c_int),
+        ("color_distance", C.c_int),
+        ("device", C.c_int),
+    ]
+
+
+class VsgTimings(C.Structure):
+    _fields_ = [
+        ("preprocess_ms", C.c_float),
+        ("edges_ms", C.c_float),
+        ("sort_ms", C.c_float),
+        ("merge_ms", C.c_float),
+        ("readout_ms", C.c_float),
+        ("host_post_ms", C.c_float),
+        ("edges_total", C.c_int64),
+        ("edges_active", C.c_int64),
+        ("merges", C.c_int64),
+        ("preprocess_launches", C.c_int64),
+        ("edge_launches", C.c_int64),
+    ]
+
+
+# Every symbol include/vsg.h declares (checked by tests/test_capi_symbols.py).
+EXPORTED_SYMBOLS = [
+    "vsg_last_error", "vsg_version", "vsg_default_options", "vsg_device_count",
+    "vsg_stream_create", "vsg_stream_destroy", "vsg_stream_process_frame", "vsg_stream_chunk_size",
+    "vsg_stream_result_bytes", "vsg_stream_result_id_image", "vsg_stream_last_merge_stats",
+    "vsg_stream_last_timings", "vsg_stream_last_smoothed", "vsg_stream_export_halo",
+    "vsg_stream_import_halo",
+    "vsg_graph_create", "vsg_graph_destroy", "vsg_graph_add_frame_bgr",
+    "vsg_graph_add_frame_features", "vsg_graph_add_virtual_frame", "vsg_graph_add_temporal",
+    "vsg_graph_finish_building", "vsg_graph_segment", "vsg_graph_obtain_results",
+    "vsg_graph_num_frames", "vsg_graph_num_regions", "vsg_graph_num_neighbor_links",
+    "vsg_graph_region_sizes", "vsg_graph_index_image", "vsg_graph_smoothed",
+    "vsg_graph_spatial_buckets", "vsg_graph_temporal_buckets", "vsg_graph_node_roots",
+    "vsg_graph_merge_stats", "vsg_graph_timings",
+]
+
+
+def build(force=False):
+    """Compiles the HIP library in-tree (hipcc --offload-arch=gfx950)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", CSRC_DIR, "-j8", "-s"])
+    else:
+        # make decides what is stale
+        subprocess.check_call(["make", "-C", CSRC_DIR, "-j8", "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libvsg_hip.so is missing (%s): build the HIP extension first; there is no fallback "
+            "path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.vsg_last_error.restype = C.c_char_p
+    L.vsg_version.restype = C.c_int
+    L.vsg_default_options.argtypes = [C.POINTER(VsgOptions)]
+    L.vsg_device_count.restype = C.c_int
+    L.vsg_stream_create.argtypes = [C.POINTER(VsgOptions), C.c_int, C.c_int, C.POINTER(vp)]
+    L.vsg_stream_destroy.argtypes = [vp]
+    L.vsg_stream_process_frame.argtypes = [vp, C.c_int, vp, C.c_size_t, vp, C.c_int, C.c_int,
+                                           C.POINTER(C.c_int)]
+    L.vsg_stream_chunk_size.argtypes = [vp]
+    L.vsg_stream_result_bytes.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.vsg_stream_result_id_image.argtypes = [vp, C.c_int, vp]
+    L.vsg_stream_last_merge_stats.argtypes = [vp, vp]
+    L.vsg_stream_last_timings.argtypes = [vp, C.POINTER(VsgTimings)]
+    L.vsg_stream_last_smoothed.argtypes = [vp, vp]
+    L.vsg_stream_export_halo.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), vp]
+    L.vsg_stream_import_halo.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.vsg_graph_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.vsg_graph_destroy.argtypes = [vp]
+    L.vsg_graph_add_frame_bgr.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_int]
+    L.vsg_graph_add_frame_features.argtypes = [vp, vp, vp, C.c_int]
+    L.vsg_graph_add_virtual_frame.argtypes = [vp, vp, C.c_int]
+    L.vsg_graph_add_temporal.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.vsg_graph_finish_building.argtypes = [vp]
+    L.vsg_graph_segment.argtypes = [vp, C.c_int, C.c_int]
+    L.vsg_graph_obtain_results.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.vsg_graph_num_frames.argtypes = [vp]
+    L.vsg_graph_num_regions.argtypes = [vp]
+    L.vsg_graph_num_neighbor_links.argtypes = [vp]
+    L.vsg_graph_num_neighbor_links.restype = C.c_int64
+    L.vsg_graph_region_sizes.argtypes = [vp, vp, vp]
+    L.vsg_graph_index_image.argtypes = [vp, C.c_int, vp]
+    L.vsg_graph_smoothed.argtypes = [vp, C.c_int, vp]
+    L.vsg_graph_spatial_buckets.argtypes = [vp, C.c_int, vp]
+    L.vsg_graph_temporal_buckets.argtypes = [vp, C.c_int, vp, vp]
+    L.vsg_graph_node_roots.argtypes = [vp, vp]
+    L.vsg_graph_merge_stats.argtypes = [vp, vp]
+    L.vsg_graph_timings.argtypes = [vp, C.POINTER(VsgTimings)]
+    _lib = L
+    return L
+
+
+class VsgError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != VSG_OK:
+        raise VsgError("vsg error %d: %s" % (rc, lib().vsg_last_error().decode()))

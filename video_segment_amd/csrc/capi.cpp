@@ -1,0 +1,417 @@
+// capi.cpp -- extern "C" entry points declared in include/vsg.h.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/vsg.h"
+#include "stream.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+template <class F>
+int Guard(F&& f) {
+  try {
+    f();
+    return VSG_OK;
+  } catch (const vsg::Error& e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return VSG_ERR_INTERNAL;
+  }
+}
+
+void RequireDevice(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    vsg::Throw(VSG_ERR_DEVICE,
+               "no usable HIP device (libvsg_hip has no CPU fallback): " +
+                   std::string(e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+  }
+  if (device >= n) vsg::Throw(VSG_ERR_DEVICE, "device ordinal out of range");
+}
+
+}  // namespace
+
+struct vsg_stream {
+  std::unique_ptr<vsg::DenseSegmentationHip> impl;
+  std::vector<int32_t> id_image;
+};
+
+struct vsg_graph {
+  int W = 0, H = 0;
+  size_t wh = 0;
+  hipStream_t stream = nullptr;
+  std::unique_ptr<vsg::DenseGraphHip> g;
+  std::unique_ptr<vsg::Preprocessor> pre;
+  std::vector<std::shared_ptr<vsg::DevBuf<float>>> feats;     // per slice (null for virtual)
+  std::vector<std::shared_ptr<std::vector<float>>> flows_host;   // per slice
+  vsg::DevBuf<uint8_t> staging_bgr;
+  vsg::DevBuf<float> staging_f32;
+  vsg::DevBuf<int32_t> staging_ids;
+  vsg::DevBuf<float> flow_dev;
+  vsg_timings timings;
+  ~vsg_graph() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    g.reset();
+    pre.reset();
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+extern "C" {
+
+const char* vsg_last_error(void) { return g_last_error.c_str(); }
+int vsg_version(void) { return 100; }
+
+void vsg_default_options(vsg_options* o) {
+  o->presmoothing = 2;
+  o->frac_min_region_size = 0.01f;
+  o->chunk_size = 20;
+  o->chunk_overlap_ratio = 0.2f;
+  o->num_constraint_frames = 1;
+  o->enforce_n4_connectivity = 1;
+  o->enforce_spatial_connectedness = 1;
+  o->color_distance = 1;
+  o->device = -1;
+}
+
+int vsg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ---- stream ------------------------------------------------------------------------------
+int vsg_stream_create(const vsg_options* o, int width, int height, vsg_stream** out) {
+  return Guard([&] {
+    VSG_REQUIRE(o && out, VSG_ERR_INVALID, "null argument");
+    RequireDevice(o->device);
+    std::unique_ptr<vsg_stream> s(new vsg_stream);
+    s->impl.reset(new vsg::DenseSegmentationHip(*o, width, height));
+    *out = s.release();
+  });
+}
+
+void vsg_stream_destroy(vsg_stream* s) { delete s; }
+
+int vsg_stream_process_frame(vsg_stream* s, int flush, const uint8_t* bgr, size_t stride,
+                             const float* flow, int has_flow_stream, int mem, int* num_results) {
+  return Guard([&] {
+    VSG_REQUIRE(s && num_results, VSG_ERR_INVALID, "null argument");
+    *num_results = s->impl->ProcessFrame(flush != 0, bgr, stride, flow, has_flow_stream != 0, mem);
+  });
+}
+
+int vsg_stream_chunk_size(const vsg_stream* s) { return s ? s->impl->ChunkSize() : VSG_ERR_INVALID; }
+
+int vsg_stream_result_bytes(vsg_stream* s, int i, const uint8_t** data, size_t* len) {
+  return Guard([&] {
+    VSG_REQUIRE(s && data && len, VSG_ERR_INVALID, "null argument");
+    VSG_REQUIRE(i >= 0 && i < s->impl->num_results(), VSG_ERR_INVALID, "result index");
+    const std::string& b = s->impl->result_bytes(i);
+    *data = reinterpret_cast<const uint8_t*>(b.data());
+    *len = b.size();
+  });
+}
+
+int vsg_stream_result_id_image(vsg_stream* s, int i, int32_t* out) {
+  return Guard([&] {
+    VSG_REQUIRE(s && out, VSG_ERR_INVALID, "null argument");
+    VSG_REQUIRE(i >= 0 && i < s->impl->num_results(), VSG_ERR_INVALID, "result index");
+    const size_t n = (size_t)s->impl->W() * s->impl->H();
+    for (size_t k = 0; k < n; ++k) out[k] = -1;
+    vsg::RenderIdImage(s->impl->result(i), s->impl->W(), out);
+  });
+}
+
+int vsg_stream_last_merge_stats(const vsg_stream* s, int64_t* st) {
+  return Guard([&] {
+    VSG_REQUIRE(s && st, VSG_ERR_INVALID, "null argument");
+    s->impl->last_merge_stats(st);
+  });
+}
+
+int vsg_stream_last_timings(const vsg_stream* s, vsg_timings* t) {
+  return Guard([&] {
+    VSG_REQUIRE(s && t, VSG_ERR_INVALID, "null argument");
+    *t = s->impl->last_timings();
+  });
+}
+
+int vsg_stream_last_smoothed(vsg_stream* s, float* out) {
+  return Guard([&] {
+    VSG_REQUIRE(s && out, VSG_ERR_INVALID, "null argument");
+    s->impl->CopyLastSmoothed(out);
+  });
+}
+
+int vsg_stream_export_halo(vsg_stream* s, const int32_t** virt, const int32_t** cons,
+                           int64_t scalars[4]) {
+  return Guard([&] {
+    VSG_REQUIRE(s && virt && cons && scalars, VSG_ERR_INVALID, "null argument");
+    s->impl->ExportHalo(virt, cons, scalars);
+  });
+}
+
+int vsg_stream_import_halo(vsg_stream* s, const int32_t* virt, const int32_t* cons, int mem,
+                           const int64_t scalars[4]) {
+  return Guard([&] {
+    VSG_REQUIRE(s && virt && cons && scalars, VSG_ERR_INVALID, "null argument");
+    s->impl->ImportHalo(virt, cons, mem, scalars);
+  });
+}
+
+// ---- graph -------------------------------------------------------------------------------
+int vsg_graph_create(int width, int height, int max_frames, int l1, int device, vsg_graph** out) {
+  return Guard([&] {
+    VSG_REQUIRE(out, VSG_ERR_INVALID, "null argument");
+    RequireDevice(device);
+    if (device >= 0) VSG_HIP(hipSetDevice(device));
+    std::unique_ptr<vsg_graph> g(new vsg_graph);
+    g->W = width;
+    g->H = height;
+    g->wh = (size_t)width * height;
+    VSG_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    g->g.reset(new vsg::DenseGraphHip(width, height, max_frames, l1 != 0, g->stream));
+    g->pre.reset(new vsg::Preprocessor(width, height, g->stream));
+    std::memset(&g->timings, 0, sizeof(g->timings));
+    *out = g.release();
+  });
+}
+
+void vsg_graph_destroy(vsg_graph* g) { delete g; }
+
+static const int32_t* StageIds(vsg_graph* g, const int32_t* ids, int mem) {
+  if (!ids) return nullptr;
+  if (mem == VSG_MEM_DEVICE) return ids;
+  g->staging_ids.ensure(g->wh);
+  VSG_HIP(hipMemcpyAsync(g->staging_ids.get(), ids, g->wh * sizeof(int32_t), hipMemcpyHostToDevice,
+                         g->stream));
+  return g->staging_ids.get();
+}
+
+int vsg_graph_add_frame_bgr(vsg_graph* g, const uint8_t* bgr, size_t stride, int presmoothing,
+                            const int32_t* constraint_ids, int mem) {
+  return Guard([&] {
+    VSG_REQUIRE(g && bgr, VSG_ERR_INVALID, "null argument");
+    VSG_REQUIRE(stride >= (size_t)g->W * 3, VSG_ERR_INVALID, "stride smaller than a row");
+    const uint8_t* dev = bgr;
+    if (mem == VSG_MEM_HOST) {
+      g->staging_bgr.ensure(stride * (size_t)g->H);
+      VSG_HIP(hipMemcpyAsync(g->staging_bgr.get(), bgr,
+                             stride * (size_t)(g->H - 1) + (size_t)g->W * 3, hipMemcpyHostToDevice,
+                             g->stream));
+      dev = g->staging_bgr.get();
+    }
+    auto feat = std::make_shared<vsg::DevBuf<float>>(3 * g->wh);
+    g->pre->Run(dev, stride, presmoothing, feat->get());
+    g->timings.preprocess_ms += g->pre->last_ms();
+    g->timings.preprocess_launches += 1;
+    const int32_t* ids = StageIds(g, constraint_ids, mem);
+    g->g->AddFrame(feat->get(), ids);
+    VSG_HIP(hipStreamSynchronize(g->stream));
+    g->feats.push_back(feat);
+    g->flows_host.push_back(nullptr);
+  });
+}
+
+int vsg_graph_add_frame_features(vsg_graph* g, const float* feat_in, const int32_t* constraint_ids,
+                                 int mem) {
+  return Guard([&] {
+    VSG_REQUIRE(g && feat_in, VSG_ERR_INVALID, "null argument");
+    const float* src = feat_in;
+    if (mem == VSG_MEM_HOST) {
+      g->staging_f32.ensure(3 * g->wh);
+      VSG_HIP(hipMemcpyAsync(g->staging_f32.get(), feat_in, 3 * g->wh * sizeof(float),
+                             hipMemcpyHostToDevice, g->stream));
+      src = g->staging_f32.get();
+    }
+    auto feat = std::make_shared<vsg::DevBuf<float>>(3 * g->wh);
+    vsg::LaunchInterleavedToPlanar(src, g->wh, feat->get(), g->stream);
+    const int32_t* ids = StageIds(g, constraint_ids, mem);
+    g->g->AddFrame(feat->get(), ids);
+    VSG_HIP(hipStreamSynchronize(g->stream));
+    g->feats.push_back(feat);
+    g->flows_host.push_back(nullptr);
+  });
+}
+
+int vsg_graph_add_virtual_frame(vsg_graph* g, const int32_t* constraint_ids, int mem) {
+  return Guard([&] {
+    VSG_REQUIRE(g && constraint_ids, VSG_ERR_INVALID, "null argument");
+    // max label: scan on the host (ids come from a SegmentationDesc, i.e. host data, or are small)
+    std::vector<int32_t> host(g->wh);
+    if (mem == VSG_MEM_HOST) {
+      std::memcpy(host.data(), constraint_ids, g->wh * sizeof(int32_t));
+    } else {
+      VSG_HIP(hipMemcpy(host.data(), constraint_ids, g->wh * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    int max_label = 0;
+    for (int32_t v : host) max_label = std::max(max_label, v + 1);
+    const int32_t* ids = StageIds(g, constraint_ids, mem);
+    g->g->AddVirtualFrame(ids, std::max(max_label, 1));
+    VSG_HIP(hipStreamSynchronize(g->stream));
+    g->feats.push_back(nullptr);
+    g->flows_host.push_back(nullptr);
+  });
+}
+
+int vsg_graph_add_temporal(vsg_graph* g, const float* flow, int is_virtual, int mem) {
+  return Guard([&] {
+    VSG_REQUIRE(g, VSG_ERR_INVALID, "null argument");
+    const int nf = g->g->num_frames();
+    VSG_REQUIRE(nf >= 2, VSG_ERR_STATE, "temporal edges need two slices");
+    const float* fdev = nullptr;
+    if (flow) {
+      auto fh = std::make_shared<std::vector<float>>(2 * g->wh);
+      g->flow_dev.ensure(2 * g->wh);
+      if (mem == VSG_MEM_HOST) {
+        std::memcpy(fh->data(), flow, 2 * g->wh * sizeof(float));
+        VSG_HIP(hipMemcpyAsync(g->flow_dev.get(), flow, 2 * g->wh * sizeof(float),
+                               hipMemcpyHostToDevice, g->stream));
+      } else {
+        VSG_HIP(hipMemcpyAsync(g->flow_dev.get(), flow, 2 * g->wh * sizeof(float),
+                               hipMemcpyDeviceToDevice, g->stream));
+        VSG_HIP(hipMemcpyAsync(fh->data(), flow, 2 * g->wh * sizeof(float), hipMemcpyDeviceToHost,
+                               g->stream));
+      }
+      g->flows_host[nf - 1] = fh;
+      fdev = g->flow_dev.get();
+    }
+    const float* cur = g->feats[nf - 1] ? g->feats[nf - 1]->get() : nullptr;
+    const float* prev = g->feats[nf - 2] ? g->feats[nf - 2]->get() : nullptr;
+    VSG_REQUIRE(is_virtual || (cur && prev), VSG_ERR_STATE, "real temporal edges need two real slices");
+    g->g->AddTemporal(cur, prev, fdev, is_virtual != 0);
+    VSG_HIP(hipStreamSynchronize(g->stream));
+  });
+}
+
+int vsg_graph_finish_building(vsg_graph* g) {
+  return Guard([&] {
+    VSG_REQUIRE(g, VSG_ERR_INVALID, "null argument");
+    g->g->FinishBuilding();
+  });
+}
+
+int vsg_graph_segment(vsg_graph* g, int min_region_size, int force_constraints) {
+  return Guard([&] {
+    VSG_REQUIRE(g, VSG_ERR_INVALID, "null argument");
+    g->g->Segment(min_region_size, force_constraints != 0);
+  });
+}
+
+int vsg_graph_obtain_results(vsg_graph* g, int use_flows, int enforce_n4,
+                             int enforce_spatial_connectedness) {
+  return Guard([&] {
+    VSG_REQUIRE(g, VSG_ERR_INVALID, "null argument");
+    std::vector<const float*> flows;
+    if (use_flows) {
+      for (auto& f : g->flows_host) flows.push_back(f ? f->data() : nullptr);
+    }
+    g->g->ObtainResults(use_flows ? &flows : nullptr, enforce_n4 != 0,
+                        enforce_spatial_connectedness != 0);
+  });
+}
+
+int vsg_graph_num_frames(const vsg_graph* g) { return g ? g->g->num_frames() : VSG_ERR_INVALID; }
+int vsg_graph_num_regions(const vsg_graph* g) {
+  return g ? (int)g->g->regions().size() : VSG_ERR_INVALID;
+}
+int64_t vsg_graph_num_neighbor_links(const vsg_graph* g) {
+  if (!g) return VSG_ERR_INVALID;
+  int64_t n = 0;
+  for (const auto& r : g->g->regions()) n += (int64_t)r.neighbors.size();
+  return n;
+}
+
+int vsg_graph_region_sizes(const vsg_graph* g, int32_t* sizes, int32_t* constrained_ids) {
+  return Guard([&] {
+    VSG_REQUIRE(g && sizes && constrained_ids, VSG_ERR_INVALID, "null argument");
+    const auto& regs = g->g->regions();
+    for (size_t i = 0; i < regs.size(); ++i) {
+      sizes[i] = regs[i].size;
+      constrained_ids[i] = regs[i].constrained_id;
+    }
+  });
+}
+
+int vsg_graph_index_image(const vsg_graph* g, int t, int32_t* out) {
+  return Guard([&] {
+    VSG_REQUIRE(g && out, VSG_ERR_INVALID, "null argument");
+    for (size_t k = 0; k < g->wh; ++k) out[k] = -1;
+    for (const auto& r : g->g->regions()) {
+      if (!r.has_raster) continue;
+      for (const auto& sl : r.raster) {
+        if (sl.frame != t) continue;
+        for (const auto& iv : sl.raster) {
+          for (int x = iv.lx; x <= iv.rx; ++x) out[(size_t)iv.y * g->W + x] = r.index;
+        }
+      }
+    }
+  });
+}
+
+int vsg_graph_smoothed(vsg_graph* g, int t, float* out) {
+  return Guard([&] {
+    VSG_REQUIRE(g && out, VSG_ERR_INVALID, "null argument");
+    VSG_REQUIRE(t >= 0 && t < (int)g->feats.size() && g->feats[t], VSG_ERR_INVALID, "slice index");
+    vsg::DevBuf<float> tmp(3 * g->wh);
+    vsg::LaunchPlanarToInterleaved(g->feats[t]->get(), g->wh, tmp.get(), g->stream);
+    VSG_HIP(hipMemcpyAsync(out, tmp.get(), 3 * g->wh * sizeof(float), hipMemcpyDeviceToHost,
+                           g->stream));
+    VSG_HIP(hipStreamSynchronize(g->stream));
+  });
+}
+
+int vsg_graph_spatial_buckets(vsg_graph* g, int t, uint16_t* out) {
+  return Guard([&] {
+    VSG_REQUIRE(g && out, VSG_ERR_INVALID, "null argument");
+    g->g->CopySpatialBuckets(t, out);
+  });
+}
+
+int vsg_graph_temporal_buckets(vsg_graph* g, int t, uint16_t* out, int32_t* prev_idx) {
+  return Guard([&] {
+    VSG_REQUIRE(g && out && prev_idx, VSG_ERR_INVALID, "null argument");
+    g->g->CopyTemporalBuckets(t, out, prev_idx);
+  });
+}
+
+int vsg_graph_node_roots(vsg_graph* g, int32_t* out) {
+  return Guard([&] {
+    VSG_REQUIRE(g && out, VSG_ERR_INVALID, "null argument");
+    g->g->CopyNodeRoots(out);
+  });
+}
+
+int vsg_graph_merge_stats(const vsg_graph* g, int64_t* s3) {
+  return Guard([&] {
+    VSG_REQUIRE(g && s3, VSG_ERR_INVALID, "null argument");
+    const auto& t = g->g->timings();
+    s3[0] = t.merges[0];
+    s3[1] = t.merges[1];
+    s3[2] = t.merges[2];
+  });
+}
+
+int vsg_graph_timings(const vsg_graph* g, vsg_timings* t) {
+  return Guard([&] {
+    VSG_REQUIRE(g && t, VSG_ERR_INVALID, "null argument");
+    *t = g->timings;
+    const auto& gt = g->g->timings();
+    t->merge_ms = gt.merge_ms;
+    t->readout_ms = gt.readout_ms;
+    t->host_post_ms = gt.host_post_ms;
+    t->edges_total = gt.edges_total;
+    t->edges_active = gt.edges_active;
+    t->merges = gt.merges[0] + gt.merges[1] + gt.merges[2];
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,851 @@
+// dense_graph.cpp -- host orchestration of the device graph (see dense_graph.h).
+//
+// Reference call sites mirrored: DenseSegmentationGraph::AddNodesAndSpatialEdges*,
+// AddVirtualNodesConstrained, AddTemporal*Edges*, SegmentFullGraph, ObtainResults,
+// DetermineNeighborIds (segmentation/dense_segmentation_graph.h:83-160, 327-579) and
+// FastSegmentationGraph::SegmentGraph / MergeConstrainedRegions / DetermineNeighborIdsImpl
+// (segmentation/segmentation_graph.h:339-496, 703-786).
+#include "dense_graph.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace vsg {
+
+namespace {
+double NowMs() {
+  using clk = std::chrono::steady_clock;
+  return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
+}
+template <class T>
+void D2H(T* dst, const T* src, size_t n, hipStream_t s) {
+  if (n == 0) return;
+  VSG_HIP(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, s));
+}
+template <class T>
+void H2D(T* dst, const T* src, size_t n, hipStream_t s) {
+  if (n == 0) return;
+  VSG_HIP(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+}
+}  // namespace
+
+DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t stream)
+    : W_(W), H_(H), capacity_frames_(max_frames), max_frames_(max_frames), l1_(l1),
+      stream_(stream), wh_((size_t)W * H) {
+  VSG_REQUIRE(W >= 2 && H >= 1 && W <= 65535 && H <= 65535, -1, "unsupported frame size");
+  VSG_REQUIRE(max_frames >= 1 && max_frames < 4096, -1, "unsupported number of frames");
+  const size_t N = wh_ * (size_t)max_frames;
+  VSG_REQUIRE(N * 9 < (size_t)0xFFFFFFFFu, -1, "graph too large for 32-bit edge positions");
+  parent_.alloc(N);
+  desc_sz_.alloc(N);
+  cons_.alloc(N);
+  flags_.alloc(N);
+  cc_.alloc(N);
+  label_uf_.alloc(N);
+  label_img_.alloc(N);
+  adjust_.alloc(N);
+  lists_.resize(2 * max_frames - 1);
+  list_desc_dev_.alloc(lists_.size());
+  list_slot_base_dev_.alloc(lists_.size() + 1);
+  const size_t total_slots = (size_t)(4 * max_frames + 9 * (max_frames - 1)) * wh_;
+  kept_all_.alloc(total_slots);
+  bucket_base_dev_.alloc((size_t)(kNumBuckets + 1) * (lists_.size() + 1));
+  keys_tmp_.alloc(9 * wh_);
+  keys_sorted_tmp_.alloc(9 * wh_);
+  vals_tmp_.alloc(9 * wh_);
+  scalars_.alloc(16);
+  stats_.alloc(4);
+  size_t temp = SortPairsU16TempBytes((int)(9 * wh_));
+  temp = std::max(temp, ScanTempBytes((int)N));
+  cub_temp_.alloc(temp);
+  Reset(max_frames);
+}
+
+DenseGraphHip::~DenseGraphHip() {}
+
+void DenseGraphHip::Reset(int max_frames) {
+  VSG_REQUIRE(max_frames >= 1 && max_frames <= capacity_frames_, -1, "max_frames above capacity");
+  max_frames_ = max_frames;
+  num_frames_ = 0;
+  has_constraints_ = false;
+  virtual_slices_.clear();
+  flattened_ = false;
+  for (auto& lb : lists_) lb.used = false;
+  regions_.clear();
+  key_to_region_.clear();
+  key_size_override_.clear();
+  next_region_index_ = 0;
+  timings_ = GraphTimings();
+}
+
+void DenseGraphHip::SortList(ListBuf& lb, int n) {
+  lb.slots.ensure((size_t)n);
+  lb.offsets.ensure(kBucketSlots);
+  SortPairsU16(cub_temp_.get(), cub_temp_.size(), keys_tmp_.get(), keys_sorted_tmp_.get(),
+               vals_tmp_.get(), lb.slots.get(), n, stream_);
+  LaunchBucketOffsets(keys_sorted_tmp_.get(), n, lb.offsets.get(), stream_);
+  lb.n = n;
+  lb.used = true;
+}
+
+void DenseGraphHip::AddFrame(const float* feat, const int32_t* cons_dev) {
+  VSG_REQUIRE(num_frames_ < max_frames_, -1, "more frames than max_frames (CHECK_LE)");
+  const int t = num_frames_;
+  const int base = (int)(wh_ * t);
+  LaunchInitNodes(feat, wh_, base, cons_dev, nodes(), stream_);
+  ListBuf& lb = lists_[2 * t];
+  lb.type = 0;
+  lb.base_a = base;
+  lb.base_b = base;
+  LaunchSpatialEdges(feat, W_, H_, l1_ ? 1 : 0, keys_tmp_.get(), vals_tmp_.get(), stream_);
+  SortList(lb, (int)(4 * wh_));
+  if (cons_dev) has_constraints_ = true;
+  ++num_frames_;
+}
+
+void DenseGraphHip::AddVirtualFrame(const int32_t* ids_dev, int max_label) {
+  VSG_REQUIRE(num_frames_ < max_frames_, -1, "more frames than max_frames (CHECK_LE)");
+  VSG_REQUIRE(max_label >= 1, -1, "max_label must be positive");
+  const int t = num_frames_;
+  first_label_scratch_.ensure((size_t)max_label);
+  LaunchInitVirtualNodes(ids_dev, wh_, (int)(wh_ * t), max_label, first_label_scratch_.get(),
+                         nodes(), stream_);
+  virtual_slices_.push_back(t);
+  has_constraints_ = true;
+  ++num_frames_;
+}
+
+void DenseGraphHip::AddTemporal(const float* cur, const float* prev, const float* flow,
+                                bool is_virtual) {
+  VSG_REQUIRE(num_frames_ >= 2, -3, "temporal edges need two slices");
+  const int t = num_frames_ - 1;
+  ListBuf& lb = lists_[2 * t - 1];
+  lb.type = 1;
+  lb.base_a = (int)(wh_ * t);
+  lb.base_b = (int)(wh_ * (t - 1));
+  lb.prev_idx.ensure(wh_);
+  LaunchTemporalEdges(cur, prev, flow, W_, H_, l1_ ? 1 : 0, is_virtual ? 1 : 0, keys_tmp_.get(),
+                      vals_tmp_.get(), lb.prev_idx.get(), stream_);
+  SortList(lb, (int)(9 * wh_));
+}
+
+void DenseGraphHip::FinishBuilding() { VSG_HIP(hipStreamSynchronize(stream_)); }
+
+void DenseGraphHip::EnsureScratch(size_t n) {
+  if (n <= scratch_edges_) return;
+  n = n + n / 8 + 1024;
+  e_ra_.alloc(n);
+  e_rb_.alloc(n);
+  e_gpos_.alloc(n);
+  e_active_.alloc(n);
+  e_apos_.alloc(n);
+  a_ra_.alloc(n);
+  a_rb_.alloc(n);
+  a_gpos_.alloc(n);
+  a_comp_.alloc(n);
+  a_idx_.alloc(n);
+  s_comp_.alloc(n);
+  s_idx_.alloc(n);
+  seg_key_.alloc(n);
+  seg_cnt_.alloc(n);
+  seg_off_.alloc(n);
+  size_t temp = cub_temp_.size();
+  temp = std::max(temp, SortPairsU32TempBytes((int)n));
+  temp = std::max(temp, ScanTempBytes((int)n));
+  temp = std::max(temp, RleTempBytes((int)n));
+  if (temp > cub_temp_.size()) cub_temp_.alloc(temp);
+  scratch_edges_ = n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SegmentFullGraph
+// ---------------------------------------------------------------------------------------------
+void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
+  VSG_REQUIRE(num_frames_ >= 1, -3, "no frames");
+  min_region_size_ = min_region_size;
+  const int L = (int)lists_.size();
+  const size_t N = wh_ * (size_t)num_frames_;
+
+  // List table.
+  std::vector<ListDesc> desc(L);
+  list_slot_base_.assign(L + 1, 0);
+  uint32_t acc = 0;
+  int64_t edges_total = 0;
+  for (int l = 0; l < L; ++l) {
+    ListBuf& lb = lists_[l];
+    list_slot_base_[l] = acc;
+    ListDesc d = {};
+    if (lb.used) {
+      d.slots = lb.slots.get();
+      d.kept = kept_all_.get() + acc;
+      d.prev_idx = lb.type == 1 ? lb.prev_idx.get() : nullptr;
+      d.offsets = lb.offsets.get();
+      d.type = lb.type;
+      d.base_a = lb.base_a;
+      d.base_b = lb.base_b;
+      d.n = lb.n;
+      acc += (uint32_t)lb.n;
+    }
+    desc[l] = d;
+  }
+  list_slot_base_[L] = acc;
+  H2D(list_desc_dev_.get(), desc.data(), (size_t)L, stream_);
+  H2D(list_slot_base_dev_.get(), list_slot_base_.data(), (size_t)L + 1, stream_);
+  VSG_HIP(hipMemsetAsync(kept_all_.get(), 0, acc, stream_));
+  LaunchBuildBucketTable(list_desc_dev_.get(), L, bucket_base_dev_.get(), stream_);
+  bucket_base_host_.resize((size_t)(kNumBuckets + 1) * (L + 1));
+  D2H(bucket_base_host_.data(), bucket_base_dev_.get(), bucket_base_host_.size(), stream_);
+  VSG_HIP(hipMemsetAsync(stats_.get(), 0, 4 * sizeof(unsigned long long), stream_));
+  LaunchInitIdentity(cc_.get(), N, stream_);
+  VSG_HIP(hipStreamSynchronize(stream_));
+
+  int n_max = 0;
+  for (int b = 0; b <= kNumBuckets; ++b) {
+    const int tot = bucket_base_host_[(size_t)b * (L + 1) + L];
+    edges_total += tot;
+    if (b < kNumBuckets) n_max = std::max(n_max, tot);
+  }
+  EnsureScratch((size_t)std::max(n_max, 1));
+
+  MergeScratch S = {};
+  S.e_ra = e_ra_.get();
+  S.e_rb = e_rb_.get();
+  S.e_gpos = e_gpos_.get();
+  S.e_active = e_active_.get();
+  S.e_apos = e_apos_.get();
+  S.a_ra = a_ra_.get();
+  S.a_rb = a_rb_.get();
+  S.a_gpos = a_gpos_.get();
+  S.a_comp = a_comp_.get();
+  S.a_idx = a_idx_.get();
+  S.s_comp = s_comp_.get();
+  S.s_idx = s_idx_.get();
+  S.seg_key = seg_key_.get();
+  S.seg_cnt = seg_cnt_.get();
+  S.seg_off = seg_off_.get();
+  S.num_active = scalars_.get();
+  S.num_segs = scalars_.get() + 1;
+  S.cc = cc_.get();
+  S.stats = stats_.get();
+  S.cub_temp = cub_temp_.get();
+  S.cub_temp_bytes = cub_temp_.size();
+
+  MergeParams P;
+  P.W = W_;
+  P.H = H_;
+  P.num_lists = L;
+  P.min_region_size = min_region_size;
+  P.force_merge_weight = l1_ ? 0.002f : 0.001f;
+  const float scale = 2048.0f / (1.0f + 1e-6f);
+  P.inv_scale = (float)(1.0 / (double)scale);
+
+  const double t0 = NowMs();
+  const bool inert_enabled = !has_constraints_;
+  for (int b = 0; b < kNumBuckets; ++b) {
+    const int n_b = bucket_base_host_[(size_t)b * (L + 1) + L];
+    if (n_b == 0) continue;
+    RunBucketStage(b, n_b, list_desc_dev_.get(), bucket_base_dev_.get(),
+                   list_slot_base_dev_.get(), kept_all_.get(), nodes(), P, inert_enabled, S,
+                   stream_);
+  }
+  LaunchKeepVirtualBucket(list_desc_dev_.get(), L, stream_);
+  if (force_constraints && has_constraints_) MergeConstrainedHostAssisted();
+  unsigned long long st[4] = {0, 0, 0, 0};
+  D2H(st, stats_.get(), 4, stream_);
+  VSG_HIP(hipStreamSynchronize(stream_));
+  timings_.merge_ms = (float)(NowMs() - t0);
+  timings_.edges_total = edges_total;
+  timings_.merges[0] += (int64_t)st[0];
+  timings_.merges[1] += (int64_t)st[1];
+  timings_.merges[2] += (int64_t)st[2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// MergeConstrainedRegions (segmentation_graph.h:703-786), host assisted.
+//
+// The reference walks all non-virtual nodes in id order, then all virtual nodes.  A node only
+// matters through (its own constraint field >= 0, its current representative), and consecutive
+// nodes with the same representative repeat the same step until it becomes a no-op, so the device
+// reduces the node walk to runs of equal representatives and the host replays the runs on the few
+// thousand region states involved.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct SimRegion {
+  int parent;
+  float d[3];
+  int sz, cons, flags;
+  bool dirty;
+};
+}  // namespace
+
+void DenseGraphHip::MergeConstrainedHostAssisted() {
+  const int N = (int)(wh_ * (size_t)num_frames_);
+  // Ranges: non-virtual nodes first (in id order), then virtual nodes (in id order).
+  std::vector<std::pair<int, int>> vranges;
+  for (int t : virtual_slices_) vranges.emplace_back((int)(wh_ * t), (int)(wh_ * (t + 1)));
+  std::sort(vranges.begin(), vranges.end());
+  std::vector<std::pair<int, int>> nvranges;
+  int cursor = 0;
+  for (auto& vr : vranges) {
+    if (vr.first > cursor) nvranges.emplace_back(cursor, vr.first);
+    cursor = vr.second;
+  }
+  if (cursor < N) nvranges.emplace_back(cursor, N);
+
+  // scratch: label_uf_ = flags, label_img_ = roots, adjust_ = offsets / compacted (all N ints)
+  int32_t* d_flags = label_uf_.get();
+  int32_t* d_roots = label_img_.get();
+  int32_t* d_offs = adjust_.get();
+  // The run lists are small; collect them per range.
+  auto collect_runs = [&](int begin, int end, std::vector<int32_t>* run_roots,
+                          std::vector<int32_t>* run_counts) {
+    const int n = end - begin;
+    if (n <= 0) return;
+    LaunchConstrainedRoots(nodes(), begin, end, d_flags, d_roots, stream_);
+    ExclusiveSumI32(cub_temp_.get(), cub_temp_.size(), d_flags, d_offs, n, stream_);
+    int last_off = 0, last_flag = 0;
+    D2H(&last_off, d_offs + (n - 1), 1, stream_);
+    D2H(&last_flag, d_flags + (n - 1), 1, stream_);
+    VSG_HIP(hipStreamSynchronize(stream_));
+    const int k = last_off + last_flag;
+    if (k == 0) return;
+    EnsureScratch((size_t)k);
+    // compact roots into a_ra_ (as int32), then RLE into seg_key_/seg_cnt_
+    LaunchCompactI32(d_flags, d_offs, d_roots, n, a_ra_.get(), stream_);
+    RunLengthEncodeU32(cub_temp_.get(), cub_temp_.size(),
+                       reinterpret_cast<const uint32_t*>(a_ra_.get()), seg_key_.get(),
+                       seg_cnt_.get(), scalars_.get() + 2, k, stream_);
+    int runs = 0;
+    D2H(&runs, scalars_.get() + 2, 1, stream_);
+    VSG_HIP(hipStreamSynchronize(stream_));
+    const size_t old = run_roots->size();
+    run_roots->resize(old + runs);
+    run_counts->resize(old + runs);
+    D2H(run_roots->data() + old, reinterpret_cast<const int32_t*>(seg_key_.get()), (size_t)runs,
+        stream_);
+    D2H(run_counts->data() + old, seg_cnt_.get(), (size_t)runs, stream_);
+    VSG_HIP(hipStreamSynchronize(stream_));
+  };
+
+  std::vector<int32_t> nv_roots, nv_counts, v_roots, v_counts;
+  for (auto& r : nvranges) collect_runs(r.first, r.second, &nv_roots, &nv_counts);
+  for (auto& r : vranges) collect_runs(r.first, r.second, &v_roots, &v_counts);
+
+  // Distinct representatives and their states.
+  std::vector<int32_t> ids;
+  {
+    ids = nv_roots;
+    ids.insert(ids.end(), v_roots.begin(), v_roots.end());
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+  }
+  const int m = (int)ids.size();
+  if (m == 0) return;
+  small_i32_a_.ensure((size_t)m);
+  small_i32_b_.ensure((size_t)m);
+  small_i32_c_.ensure((size_t)m);
+  small_f4_.ensure((size_t)m);
+  H2D(small_i32_a_.get(), ids.data(), (size_t)m, stream_);
+  LaunchGatherStates(nodes(), small_i32_a_.get(), m, small_f4_.get(), small_i32_b_.get(),
+                     small_i32_c_.get(), stream_);
+  std::vector<float4> h_ds(m);
+  std::vector<int32_t> h_cons(m), h_flags(m);
+  D2H(h_ds.data(), small_f4_.get(), (size_t)m, stream_);
+  D2H(h_cons.data(), small_i32_b_.get(), (size_t)m, stream_);
+  D2H(h_flags.data(), small_i32_c_.get(), (size_t)m, stream_);
+  VSG_HIP(hipStreamSynchronize(stream_));
+
+  std::unordered_map<int, SimRegion> sim;
+  sim.reserve((size_t)m * 2);
+  for (int i = 0; i < m; ++i) {
+    SimRegion r;
+    r.parent = ids[i];
+    r.d[0] = h_ds[i].x;
+    r.d[1] = h_ds[i].y;
+    r.d[2] = h_ds[i].z;
+    std::memcpy(&r.sz, &h_ds[i].w, 4);
+    r.cons = h_cons[i];
+    r.flags = h_flags[i];
+    r.dirty = false;
+    sim.emplace(ids[i], r);
+  }
+  auto find = [&sim](int r) {
+    for (;;) {
+      const SimRegion& s = sim.at(r);
+      if (s.parent == r) return r;
+      r = s.parent;
+    }
+  };
+  const float force_w = l1_ ? 0.002f : 0.001f;
+  auto distance = [&](const SimRegion& a, const SimRegion& b, float w) {
+    const float x = a.d[0] - b.d[0], y = a.d[1] - b.d[1], z = a.d[2] - b.d[2];
+    const float dist = (float)std::sqrt((double)((x * x + y * y + z * z) * (1.0f / 3.0f)));
+    if (w < force_w && (double)dist < 0.2) return 0.0f;
+    return dist;
+  };
+  // MergeRegions(rep_1, rep_2); returns nothing, updates sim.
+  auto merge = [&](int r1, int r2) {
+    SimRegion& a = sim.at(r1);
+    SimRegion& b = sim.at(r2);
+    const bool first = a.sz > b.sz;
+    SimRegion& mrg = first ? a : b;
+    SimRegion& oth = first ? b : a;
+    const int mid = first ? r1 : r2;
+    if (!((mrg.flags | oth.flags) & kFlagNoDesc)) {
+      const float denom = 1.0f / (float)(oth.sz + mrg.sz);
+      const float ca = (float)oth.sz * denom;
+      const float cb = (float)mrg.sz * denom;
+      for (int c = 0; c < 3; ++c) mrg.d[c] = ca * oth.d[c] + cb * mrg.d[c];
+    }
+    mrg.sz += oth.sz;
+    mrg.cons = std::max(a.cons, b.cons);
+    oth.parent = mid;
+    mrg.dirty = true;
+    oth.dirty = true;
+  };
+
+  std::unordered_map<int, int> c2r;
+  // non-virtual pass
+  for (size_t k = 0; k < nv_roots.size(); ++k) {
+    for (int rep = 0; rep < nv_counts[k]; ++rep) {
+      const int my = find(nv_roots[k]);
+      SimRegion& me = sim.at(my);
+      auto pos = c2r.find(me.cons);
+      if (pos == c2r.end()) {
+        c2r.emplace(me.cons, my);
+        continue;   // map changed
+      }
+      const int crep = find(pos->second);
+      if (crep == my) break;   // no-op from here on
+      SimRegion& cr = sim.at(crep);
+      const float dist = distance(me, cr, 1.0f);
+      bool changed = false;
+      if (dist > 0.15f) {
+        if ((double)me.sz < (double)cr.sz * 0.3) {
+          changed = me.cons != -1;
+          me.cons = -1;
+          me.dirty = true;
+        } else if ((double)cr.sz < (double)me.sz * 0.3) {
+          changed = (cr.cons != -1) || (pos->second != my);
+          cr.cons = -1;
+          cr.dirty = true;
+          pos->second = my;
+        } else {
+          me.cons = -1;
+          cr.cons = -1;
+          me.dirty = cr.dirty = true;
+          c2r.erase(pos);
+          changed = true;
+        }
+      } else {
+        merge(my, crep);
+        changed = true;
+      }
+      if (!changed) break;
+    }
+  }
+  // virtual pass
+  for (size_t k = 0; k < v_roots.size(); ++k) {
+    for (int rep = 0; rep < v_counts[k]; ++rep) {
+      const int my = find(v_roots[k]);
+      SimRegion& me = sim.at(my);
+      auto pos = c2r.find(me.cons);
+      if (pos == c2r.end()) {
+        c2r.emplace(me.cons, my);
+        continue;
+      }
+      const int crep = find(pos->second);
+      if (crep == my) break;
+      merge(my, crep);
+    }
+  }
+
+  // Write back.
+  std::vector<int32_t> u_ids, u_parent, u_cons, u_flags;
+  std::vector<float4> u_ds;
+  for (auto& kv : sim) {
+    if (!kv.second.dirty) continue;
+    u_ids.push_back(kv.first);
+    u_parent.push_back(kv.second.parent);
+    float w;
+    std::memcpy(&w, &kv.second.sz, 4);
+    u_ds.push_back(make_float4(kv.second.d[0], kv.second.d[1], kv.second.d[2], w));
+    u_cons.push_back(kv.second.cons);
+    u_flags.push_back(kv.second.flags);
+  }
+  const int u = (int)u_ids.size();
+  if (u == 0) return;
+  DevBuf<int32_t> d_ids(u), d_par(u), d_cons(u), d_fl(u);
+  DevBuf<float4> d_ds(u);
+  H2D(d_ids.get(), u_ids.data(), (size_t)u, stream_);
+  H2D(d_par.get(), u_parent.data(), (size_t)u, stream_);
+  H2D(d_cons.get(), u_cons.data(), (size_t)u, stream_);
+  H2D(d_fl.get(), u_flags.data(), (size_t)u, stream_);
+  H2D(d_ds.get(), u_ds.data(), (size_t)u, stream_);
+  LaunchScatterStates(nodes(), d_ids.get(), u, d_par.get(), d_ds.get(), d_cons.get(), d_fl.get(),
+                      stream_);
+  VSG_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---------------------------------------------------------------------------------------------
+// ObtainResults + DetermineNeighborIds
+// ---------------------------------------------------------------------------------------------
+void DenseGraphHip::ObtainResults(const std::vector<const float*>* host_flows, bool enforce_n4,
+                                  bool enforce_spatial_connectedness) {
+  const double t_start = NowMs();
+  const size_t N = wh_ * (size_t)num_frames_;
+  if (host_flows) VSG_REQUIRE((int)host_flows->size() == num_frames_, -1, "one flow per frame");
+
+  // 1. representative key per node (FlattenUnionFind).
+  LaunchFlatten(nodes(), N, label_uf_.get(), stream_);
+  label_uf_host_.resize(N);
+  D2H(label_uf_host_.data(), label_uf_.get(), N, stream_);
+  VSG_HIP(hipMemcpyAsync(label_img_.get(), label_uf_.get(), N * sizeof(int32_t),
+                         hipMemcpyDeviceToDevice, stream_));
+  VSG_HIP(hipMemsetAsync(adjust_.get(), 0, N * sizeof(int32_t), stream_));
+
+  // 2. N4 connectivity on every rasterised slice (constrained_slices_ is never filled in the
+  //    reference's live path, SURVEY A.7-1, so constrained slices are swept as well).
+  std::vector<int32_t> frames;
+  for (int t = 0; t < num_frames_; ++t) {
+    if (!std::binary_search(virtual_slices_.begin(), virtual_slices_.end(), t)) frames.push_back(t);
+  }
+  const int nf = (int)frames.size();
+  small_i32_a_.ensure((size_t)std::max(nf, 1));
+  H2D(small_i32_a_.get(), frames.data(), (size_t)nf, stream_);
+  if (enforce_n4) {
+    LaunchEnforceN4(label_img_.get(), W_, H_, small_i32_a_.get(), nf, adjust_.get(), stream_);
+  }
+
+  // 3. run-length intervals in (slice, y, x) order.
+  const int rows = nf * H_;
+  row_counts_.ensure((size_t)rows + 1);
+  row_offsets_.ensure((size_t)rows + 1);
+  for (int i = 0; i < nf; ++i) {
+    LaunchRowRunCounts(label_img_.get(), W_, H_, frames[i], row_counts_.get() + (size_t)i * H_,
+                       stream_);
+  }
+  VSG_HIP(hipMemsetAsync(row_counts_.get() + rows, 0, sizeof(int32_t), stream_));
+  ExclusiveSumI32(cub_temp_.get(), cub_temp_.size(), row_counts_.get(), row_offsets_.get(),
+                  rows + 1, stream_);
+  int num_iv = 0;
+  D2H(&num_iv, row_offsets_.get() + rows, 1, stream_);
+  VSG_HIP(hipStreamSynchronize(stream_));
+  iv_label_.ensure((size_t)num_iv);
+  iv_ty_.ensure((size_t)num_iv);
+  iv_lx_.ensure((size_t)num_iv);
+  iv_rx_.ensure((size_t)num_iv);
+  IntervalArrays iva{iv_label_.get(), iv_ty_.get(), iv_lx_.get(), iv_rx_.get()};
+  for (int i = 0; i < nf; ++i) {
+    LaunchWriteIntervals(label_img_.get(), W_, H_, frames[i],
+                         row_offsets_.get() + (size_t)i * H_, iva, stream_);
+  }
+  std::vector<int32_t> h_label(num_iv), h_lx(num_iv), h_rx(num_iv);
+  std::vector<uint32_t> h_ty(num_iv);
+  D2H(h_label.data(), iv_label_.get(), (size_t)num_iv, stream_);
+  D2H(h_ty.data(), iv_ty_.get(), (size_t)num_iv, stream_);
+  D2H(h_lx.data(), iv_lx_.get(), (size_t)num_iv, stream_);
+  D2H(h_rx.data(), iv_rx_.get(), (size_t)num_iv, stream_);
+
+  // 4. size adjustments of the N4 pass (sparse).
+  std::vector<int32_t> adj_keys, adj_vals;
+  if (enforce_n4) {
+    // cc_ is free after the merge and label_img_ after the interval kernels (stream order).
+    int32_t* d_flags = cc_.get();
+    int32_t* d_offs = label_img_.get();
+    LaunchNonzeroFlags(adjust_.get(), (int)N, d_flags, stream_);
+    ExclusiveSumI32(cub_temp_.get(), cub_temp_.size(), d_flags, d_offs, (int)N, stream_);
+    int lo = 0, lf = 0;
+    D2H(&lo, d_offs + (N - 1), 1, stream_);
+    D2H(&lf, d_flags + (N - 1), 1, stream_);
+    VSG_HIP(hipStreamSynchronize(stream_));
+    const int cnt = lo + lf;
+    if (cnt > 0) {
+      small_i32_b_.ensure((size_t)cnt);
+      small_i32_c_.ensure((size_t)cnt);
+      LaunchCompactIndexValue(d_flags, d_offs, adjust_.get(), (int)N, small_i32_b_.get(),
+                              small_i32_c_.get(), stream_);
+      adj_keys.resize(cnt);
+      adj_vals.resize(cnt);
+      D2H(adj_keys.data(), small_i32_b_.get(), (size_t)cnt, stream_);
+      D2H(adj_vals.data(), small_i32_c_.get(), (size_t)cnt, stream_);
+      VSG_HIP(hipStreamSynchronize(stream_));
+    }
+  }
+  VSG_HIP(hipStreamSynchronize(stream_));
+  const double t_dev1 = NowMs();
+
+  // 5. regions in first-appearance order of their intervals (GetCreateRegionInformation via
+  //    AddIntervalToRasterization, dense_segmentation_graph.h:432-466).
+  regions_.clear();
+  key_to_region_.clear();
+  next_region_index_ = 0;
+  std::vector<int32_t> region_keys;
+  for (int i = 0; i < num_iv; ++i) {
+    const int key = h_label[i];
+    auto it = key_to_region_.find(key);
+    int idx;
+    if (it == key_to_region_.end()) {
+      idx = next_region_index_++;
+      key_to_region_.emplace(key, idx);
+      regions_.emplace_back();
+      regions_.back().index = idx;
+      regions_.back().has_raster = true;
+      region_keys.push_back(key);
+    } else {
+      idx = it->second;
+    }
+    RegionInfo& ri = regions_[idx];
+    const int t = (int)(h_ty[i] >> 16), y = (int)(h_ty[i] & 0xFFFFu);
+    if (ri.raster.empty() || ri.raster.back().frame < t) ri.raster.push_back(RasterSlice{t, Raster()});
+    ri.raster.back().raster.push_back(Interval{y, h_lx[i], h_rx[i]});
+  }
+  // sizes / constraints of the representatives
+  auto fetch_states = [&](const std::vector<int32_t>& keys, std::vector<int32_t>* sz,
+                          std::vector<int32_t>* cons) {
+    const int m = (int)keys.size();
+    sz->resize(m);
+    cons->resize(m);
+    if (m == 0) return;
+    small_i32_a_.ensure((size_t)m);
+    small_i32_b_.ensure((size_t)m);
+    small_i32_c_.ensure((size_t)m);
+    small_f4_.ensure((size_t)m);
+    H2D(small_i32_a_.get(), keys.data(), (size_t)m, stream_);
+    LaunchGatherStates(nodes(), small_i32_a_.get(), m, small_f4_.get(), small_i32_b_.get(),
+                       small_i32_c_.get(), stream_);
+    std::vector<float4> ds(m);
+    D2H(ds.data(), small_f4_.get(), (size_t)m, stream_);
+    D2H(cons->data(), small_i32_b_.get(), (size_t)m, stream_);
+    VSG_HIP(hipStreamSynchronize(stream_));
+    for (int i = 0; i < m; ++i) std::memcpy(&(*sz)[i], &ds[i].w, 4);
+  };
+  {
+    std::vector<int32_t> sz, cons;
+    fetch_states(region_keys, &sz, &cons);
+    for (size_t i = 0; i < region_keys.size(); ++i) {
+      regions_[i].size = sz[i];
+      regions_[i].constrained_id = cons[i];
+    }
+  }
+
+  std::unordered_map<int, int> size_adjust;
+  for (size_t i = 0; i < adj_keys.size(); ++i) size_adjust[adj_keys[i]] = adj_vals[i];
+
+  // 6. EnforceSpatialConnectedness (dense_segmentation_graph.h:666-904).
+  std::vector<uint32_t> rl_ty;
+  std::vector<int32_t> rl_lx, rl_rx, rl_new;
+  int next_new_key = (int)N;
+  if (enforce_spatial_connectedness) {
+    std::vector<const float*> flows;
+    const bool have_flows = host_flows != nullptr;
+    if (have_flows) flows = *host_flows;
+    const int num_regions = (int)regions_.size();
+    TubeResult tr;
+    for (int r = 0; r < num_regions; ++r) {
+      if (!regions_[r].has_raster) continue;
+      SplitRegionIntoTubes(regions_[r].raster, W_, H_, flows, have_flows, &tr);
+      if (tr.tubes.size() <= 1) continue;
+      for (int k = 0; k < (int)tr.tubes.size(); ++k) {
+        const RasterSlice& s0 = tr.tubes[k][0];
+        const size_t first_idx = (size_t)s0.frame * wh_ + (size_t)s0.raster[0].y * W_ + s0.raster[0].lx;
+        int rep_key = label_uf_host_[first_idx];
+        if (k != tr.tube_to_keep) {
+          int& adj = size_adjust[rep_key];
+          adj = (int)((float)adj - tr.areas[k]);   // int -= float
+          rep_key = next_new_key++;
+          const int idx = next_region_index_++;
+          key_to_region_.emplace(rep_key, idx);
+          regions_.emplace_back();
+          regions_.back().index = idx;
+          regions_.back().size = (int)tr.areas[k];
+          regions_.back().constrained_id = -1;
+          for (const RasterSlice& sl : tr.tubes[k]) {
+            for (const Interval& iv : sl.raster) {
+              rl_ty.push_back(((uint32_t)sl.frame << 16) | (uint32_t)iv.y);
+              rl_lx.push_back(iv.lx);
+              rl_rx.push_back(iv.rx);
+              rl_new.push_back(rep_key);
+            }
+          }
+        }
+        auto it = key_to_region_.find(rep_key);
+        int idx;
+        if (it == key_to_region_.end()) {
+          // representative without rasterization (possible only after N4 swaps)
+          std::vector<int32_t> sz, cons;
+          fetch_states(std::vector<int32_t>{rep_key}, &sz, &cons);
+          idx = next_region_index_++;
+          key_to_region_.emplace(rep_key, idx);
+          regions_.emplace_back();
+          regions_.back().index = idx;
+          regions_.back().size = sz[0];
+          regions_.back().constrained_id = cons[0];
+        } else {
+          idx = it->second;
+        }
+        regions_[idx].has_raster = true;
+        regions_[idx].raster.swap(tr.tubes[k]);
+      }
+    }
+  }
+
+  // 7. size adjustments (dense_segmentation_graph.h:566-578).
+  for (const auto& kv : size_adjust) {
+    auto it = key_to_region_.find(kv.first);
+    if (it == key_to_region_.end()) {
+      key_size_override_[kv.first] = 0;
+      continue;
+    }
+    regions_[it->second].size += kv.second;
+  }
+  const double t_host1 = NowMs();
+
+  // 8. DetermineNeighborIds: relabel split tubes on the device, then collect region pairs.
+  const int n_rl = (int)rl_ty.size();
+  if (n_rl > 0) {
+    DevBuf<uint32_t> d_ty((size_t)n_rl);
+    DevBuf<int32_t> d_lx((size_t)n_rl), d_rx((size_t)n_rl), d_nl((size_t)n_rl);
+    H2D(d_ty.get(), rl_ty.data(), (size_t)n_rl, stream_);
+    H2D(d_lx.get(), rl_lx.data(), (size_t)n_rl, stream_);
+    H2D(d_rx.get(), rl_rx.data(), (size_t)n_rl, stream_);
+    H2D(d_nl.get(), rl_new.data(), (size_t)n_rl, stream_);
+    LaunchRelabelIntervals(d_ty.get(), d_lx.get(), d_rx.get(), d_nl.get(), n_rl, W_, H_,
+                           label_uf_.get(), stream_);
+    VSG_HIP(hipStreamSynchronize(stream_));
+  }
+  const int L = (int)lists_.size();
+  int capacity = (int)std::max<size_t>(pairs_.size(), (size_t)1 << 20);
+  int count = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    pairs_.ensure((size_t)capacity);
+    order_keys_.ensure((size_t)capacity);
+    LaunchNeighborPairs(list_desc_dev_.get(), L, label_uf_.get(), W_, pairs_.get(),
+                        order_keys_.get(), scalars_.get() + 3, capacity, stream_);
+    D2H(&count, scalars_.get() + 3, 1, stream_);
+    VSG_HIP(hipStreamSynchronize(stream_));
+    if (count <= capacity) break;
+    VSG_REQUIRE(attempt == 0, -4, "neighbour pair buffer overflow");
+    capacity = count + 1024;
+  }
+  std::vector<unsigned long long> uniq;
+  if (count > 0) {
+    pairs_sorted_.ensure((size_t)count);
+    pairs_unique_.ensure((size_t)count);
+    size_t temp = std::max(SortKeysU64TempBytes(count), UniqueU64TempBytes(count));
+    if (temp > cub_temp_.size()) cub_temp_.alloc(temp);
+    SortKeysU64(cub_temp_.get(), cub_temp_.size(), pairs_.get(), pairs_sorted_.get(), count, stream_);
+    UniqueU64(cub_temp_.get(), cub_temp_.size(), pairs_sorted_.get(), pairs_unique_.get(),
+              scalars_.get() + 4, count, stream_);
+    int nu = 0;
+    D2H(&nu, scalars_.get() + 4, 1, stream_);
+    VSG_HIP(hipStreamSynchronize(stream_));
+    uniq.resize(nu);
+    D2H(uniq.data(), pairs_unique_.get(), (size_t)nu, stream_);
+    VSG_HIP(hipStreamSynchronize(stream_));
+  }
+  const double t_dev2 = NowMs();
+
+  // Representatives that own no interval get a RegionInformation in order of first appearance
+  // (bucket, list, position, first-then-second end point).
+  std::vector<int32_t> unseen;
+  for (unsigned long long pr : uniq) {
+    const int ka = (int)(uint32_t)(pr >> 32), kb = (int)(uint32_t)(pr & 0xFFFFFFFFull);
+    if (!key_to_region_.count(ka)) unseen.push_back(ka);
+    if (!key_to_region_.count(kb)) unseen.push_back(kb);
+  }
+  std::sort(unseen.begin(), unseen.end());
+  unseen.erase(std::unique(unseen.begin(), unseen.end()), unseen.end());
+  if (!unseen.empty()) {
+    const int U = (int)unseen.size();
+    DevBuf<int32_t> d_keys((size_t)U);
+    DevBuf<unsigned long long> d_min((size_t)U);
+    H2D(d_keys.get(), unseen.data(), (size_t)U, stream_);
+    VSG_HIP(hipMemsetAsync(d_min.get(), 0xFF, (size_t)U * sizeof(unsigned long long), stream_));
+    LaunchFirstOrderOfKeys(pairs_.get(), order_keys_.get(), count, d_keys.get(), U, d_min.get(),
+                           stream_);
+    std::vector<unsigned long long> h_min(U);
+    D2H(h_min.data(), d_min.get(), (size_t)U, stream_);
+    VSG_HIP(hipStreamSynchronize(stream_));
+    std::vector<int> order(U);
+    for (int i = 0; i < U; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return h_min[a] < h_min[b]; });
+    std::vector<int32_t> sz, cons;
+    fetch_states(unseen, &sz, &cons);
+    for (int oi : order) {
+      const int key = unseen[oi];
+      const int idx = next_region_index_++;
+      key_to_region_.emplace(key, idx);
+      regions_.emplace_back();
+      RegionInfo& ri = regions_.back();
+      ri.index = idx;
+      auto ov = key_size_override_.find(key);
+      ri.size = (ov != key_size_override_.end()) ? ov->second : sz[oi];
+      ri.constrained_id = cons[oi];
+      ri.has_raster = false;
+    }
+  }
+  for (unsigned long long pr : uniq) {
+    const int ka = (int)(uint32_t)(pr >> 32), kb = (int)(uint32_t)(pr & 0xFFFFFFFFull);
+    const int ia = key_to_region_.at(ka), ib = key_to_region_.at(kb);
+    regions_[ia].neighbors.push_back(ib);
+    regions_[ib].neighbors.push_back(ia);
+  }
+  for (RegionInfo& ri : regions_) {
+    std::sort(ri.neighbors.begin(), ri.neighbors.end());
+    ri.neighbors.erase(std::unique(ri.neighbors.begin(), ri.neighbors.end()), ri.neighbors.end());
+  }
+  const double t_end = NowMs();
+  timings_.readout_ms = (float)((t_dev1 - t_start) + (t_dev2 - t_host1));
+  timings_.host_post_ms = (float)((t_host1 - t_dev1) + (t_end - t_dev2));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Parity hooks.
+// ---------------------------------------------------------------------------------------------
+void DenseGraphHip::CopySpatialBuckets(int t, uint16_t* out) {
+  VSG_REQUIRE(t >= 0 && t < num_frames_ && lists_[2 * t].used, -1, "no spatial list for slice");
+  ListBuf& lb = lists_[2 * t];
+  std::vector<uint32_t> slots(lb.n);
+  std::vector<int32_t> offs(kBucketSlots);
+  D2H(slots.data(), lb.slots.get(), (size_t)lb.n, stream_);
+  D2H(offs.data(), lb.offsets.get(), (size_t)kBucketSlots, stream_);
+  VSG_HIP(hipStreamSynchronize(stream_));
+  for (size_t i = 0; i < 4 * wh_; ++i) out[i] = 0xFFFF;
+  for (int b = 0; b <= kNumBuckets; ++b) {
+    for (int p = offs[b]; p < offs[b + 1]; ++p) {
+      const uint32_t s = slots[p];
+      out[(size_t)(s & 3u) * wh_ + (s >> 2)] = (uint16_t)b;
+    }
+  }
+}
+
+void DenseGraphHip::CopyTemporalBuckets(int t, uint16_t* out, int32_t* prev_idx) {
+  VSG_REQUIRE(t >= 1 && t < num_frames_ && lists_[2 * t - 1].used, -1, "no temporal list");
+  ListBuf& lb = lists_[2 * t - 1];
+  std::vector<uint32_t> slots(lb.n);
+  std::vector<int32_t> offs(kBucketSlots);
+  D2H(slots.data(), lb.slots.get(), (size_t)lb.n, stream_);
+  D2H(offs.data(), lb.offsets.get(), (size_t)kBucketSlots, stream_);
+  D2H(prev_idx, lb.prev_idx.get(), wh_, stream_);
+  VSG_HIP(hipStreamSynchronize(stream_));
+  for (size_t i = 0; i < 9 * wh_; ++i) out[i] = 0xFFFF;
+  for (int b = 0; b <= kNumBuckets; ++b) {
+    for (int p = offs[b]; p < offs[b + 1]; ++p) {
+      const uint32_t s = slots[p];
+      const uint32_t pix = s / 9u, k = s - pix * 9u;
+      out[(size_t)k * wh_ + pix] = (uint16_t)b;
+    }
+  }
+}
+
+void DenseGraphHip::CopyNodeRoots(int32_t* out) {
+  const size_t N = wh_ * (size_t)num_frames_;
+  LaunchFlatten(nodes(), N, label_uf_.get(), stream_);
+  D2H(out, label_uf_.get(), N, stream_);
+  VSG_HIP(hipStreamSynchronize(stream_));
+}
+
+}  // namespace vsg

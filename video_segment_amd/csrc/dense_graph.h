@@ -1,0 +1,134 @@
+// dense_graph.h -- DenseGraphHip: the MI355X implementation of the reference's
+// DenseSegGraphInterface (segmentation/dense_seg_graph_interface.h:107-159) for
+// DenseSegmentationGraph<DistanceColorL2|L1, ColorMeanDescriptorTraits>.
+#ifndef VSG_DENSE_GRAPH_H_
+#define VSG_DENSE_GRAPH_H_
+
+#include <memory>
+#include <unordered_map>
+#include <vector>
+
+#include "device_graph.h"
+#include "host_model.h"
+
+namespace vsg {
+
+struct GraphTimings {
+  float edges_ms = 0, sort_ms = 0, merge_ms = 0, readout_ms = 0, host_post_ms = 0;
+  int64_t edges_total = 0, edges_active = 0;
+  int64_t merges[3] = {0, 0, 0};   // forced, regular, small
+};
+
+class DenseGraphHip {
+ public:
+  DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t stream);
+  ~DenseGraphHip();
+
+  int W() const { return W_; }
+  int H() const { return H_; }
+  int max_frames() const { return max_frames_; }
+  int num_frames() const { return num_frames_; }
+  hipStream_t stream() const { return stream_; }
+
+  // Starts a new (empty) graph reusing all device buffers.  max_frames may shrink/grow up to the
+  // capacity given at construction.
+  void Reset(int max_frames);
+
+  // AddNodesAndSpatialEdges[Constrained].  feat: 3 planes of W*H f32 (B,G,R) in device memory,
+  // must stay valid until the stream has executed the call.  cons: W*H int32 device or nullptr.
+  void AddFrame(const float* feat_planar_dev, const int32_t* cons_dev);
+  // AddVirtualNodesConstrained.  max_label: upper bound (exclusive) of the ids in the image.
+  void AddVirtualFrame(const int32_t* ids_dev, int max_label);
+  // AddTemporal[Flow][Virtual]Edges: connects the last two slices.
+  void AddTemporal(const float* cur_dev, const float* prev_dev, const float* flow_dev,
+                   bool is_virtual);
+  void FinishBuilding();
+  void Segment(int min_region_size, bool force_constraints);
+  // ObtainResults + DetermineNeighborIds.  host_flows: per slice W*H*2 f32 host pointers (may
+  // contain nullptr) or null.
+  void ObtainResults(const std::vector<const float*>* host_flows, bool enforce_n4,
+                     bool enforce_spatial_connectedness);
+
+  std::vector<RegionInfo>& regions() { return regions_; }
+  const std::vector<RegionInfo>& regions() const { return regions_; }
+  const GraphTimings& timings() const { return timings_; }
+
+  // parity hooks
+  void CopySpatialBuckets(int t, uint16_t* out_host);                     // [4][H][W]
+  void CopyTemporalBuckets(int t, uint16_t* out_host, int32_t* prev_idx_host);   // [9][H][W]
+  void CopyNodeRoots(int32_t* out_host);
+
+ private:
+  struct ListBuf {
+    DevBuf<uint32_t> slots;      // sorted slot ids
+    DevBuf<int32_t> offsets;     // [kBucketSlots]
+    DevBuf<int32_t> prev_idx;    // temporal only
+    DevBuf<uint16_t> keys_dbg;   // unsorted keys kept for the parity hooks
+    int type = 0;
+    int n = 0;
+    int base_a = 0, base_b = 0;
+    bool used = false;
+  };
+
+  void EnsureScratch(size_t n_edges_max);
+  void SortList(ListBuf& lb, int n);
+  void MergeConstrainedHostAssisted();
+  NodeArrays nodes() {
+    return NodeArrays{parent_.get(), desc_sz_.get(), cons_.get(), flags_.get()};
+  }
+
+  int W_, H_, capacity_frames_, max_frames_;
+  bool l1_;
+  hipStream_t stream_;
+  int num_frames_ = 0;
+  size_t wh_;
+  bool has_constraints_ = false;
+  std::vector<int> virtual_slices_;
+  int min_region_size_ = 0;
+  bool flattened_ = false;
+
+  // node arrays
+  DevBuf<int32_t> parent_;
+  DevBuf<float4> desc_sz_;
+  DevBuf<int32_t> cons_;
+  DevBuf<uint8_t> flags_;
+  // N-sized scratch / result arrays
+  DevBuf<int32_t> cc_, label_uf_, label_img_, adjust_;
+  // lists
+  std::vector<ListBuf> lists_;
+  DevBuf<ListDesc> list_desc_dev_;
+  DevBuf<uint32_t> list_slot_base_dev_;
+  std::vector<uint32_t> list_slot_base_;
+  DevBuf<uint8_t> kept_all_;
+  DevBuf<int32_t> bucket_base_dev_;
+  std::vector<int32_t> bucket_base_host_;
+  // temporaries for edge generation / sorting
+  DevBuf<uint16_t> keys_tmp_, keys_sorted_tmp_;
+  DevBuf<uint32_t> vals_tmp_;
+  DevBuf<int32_t> first_label_scratch_;
+  // merge scratch
+  DevBuf<int32_t> e_ra_, e_rb_, e_active_, e_apos_, a_ra_, a_rb_, seg_cnt_, seg_off_;
+  DevBuf<uint32_t> e_gpos_, a_gpos_, a_comp_, a_idx_, s_comp_, s_idx_, seg_key_;
+  DevBuf<int32_t> scalars_;   // num_active, num_segs, misc
+  DevBuf<unsigned long long> stats_;
+  DevBuf<uint8_t> cub_temp_;
+  size_t scratch_edges_ = 0;
+  // readout scratch
+  DevBuf<int32_t> row_counts_, row_offsets_;
+  DevBuf<int32_t> iv_label_, iv_lx_, iv_rx_;
+  DevBuf<uint32_t> iv_ty_;
+  DevBuf<unsigned long long> pairs_, order_keys_, pairs_sorted_, pairs_unique_;
+  DevBuf<int32_t> small_i32_a_, small_i32_b_, small_i32_c_;
+  DevBuf<float4> small_f4_;
+  std::vector<int32_t> label_uf_host_;
+
+  std::vector<RegionInfo> regions_;
+  std::unordered_map<int, int> key_to_region_;   // representative key -> index into regions_
+  std::unordered_map<int, int> key_size_override_;   // regions erased by N4: size forced to 0
+  int next_region_index_ = 0;
+  GraphTimings timings_;
+};
+
+}  // namespace vsg
+
+#endif  // VSG_DENSE_GRAPH_H_

@@ -1,0 +1,180 @@
+// device_graph.h -- device-side data layout and kernel launch prototypes.
+//
+// HBM layout of one chunk graph (N = W*H*max_frames nodes, node id = t*W*H + y*W + x as in
+// dense_segmentation_graph.h:1180-1228):
+//   parent   int32[N]    union-find parent (FastSegmentationGraph::Region::my_id)
+//   desc_sz  float4[N]   xyz = mean colour descriptor (B,G,R), w = region size as int bits
+//   cons     int32[N]    constraint id (-1 unconstrained)
+//   flags    uint8[N]    bit0 region_finalized, bit1 "no descriptor" (virtual / fresh reps)
+// Edges are never stored as (a,b) pairs.  Every bucket list l (spatial slice t -> l = 2t,
+// temporal slice t -> l = 2t-1, same numbering as the reference) owns
+//   slots    uint32[n_l] edge slot ids, stably sorted by bucket => (bucket, scan order, k)
+//   offsets  int32[2050] start of every bucket inside slots
+//   kept     uint8[n_l]  1 = edge survived the merge (the reference's `remaining_edges`)
+// with slot = pix*4+k (spatial) or pix*9+k (temporal); a temporal list also owns
+// prev_idx int32[W*H], the (flow displaced) centre pixel in the previous slice.
+#ifndef VSG_DEVICE_GRAPH_H_
+#define VSG_DEVICE_GRAPH_H_
+
+#include "common.h"
+
+namespace vsg {
+
+constexpr uint8_t kFlagFinalized = 1;
+constexpr uint8_t kFlagNoDesc = 2;
+
+struct NodeArrays {
+  int32_t* parent;
+  float4* desc_sz;
+  int32_t* cons;
+  uint8_t* flags;
+};
+
+// One bucket list as seen by the merge / neighbour kernels.
+struct ListDesc {
+  const uint32_t* slots;     // sorted slot ids
+  uint8_t* kept;             // per sorted position
+  const int32_t* prev_idx;   // temporal lists only
+  const int32_t* offsets;    // [kBucketSlots]
+  int32_t type;              // 0 spatial, 1 temporal
+  int32_t base_a;            // node id of pixel 0 of the slice owning the edges
+  int32_t base_b;            // temporal: node id of pixel 0 of the previous slice
+  int32_t n;                 // number of slots (valid + invalid)
+};
+
+struct MergeParams {
+  int W, H;
+  int num_lists;
+  int min_region_size;
+  float force_merge_weight;   // 0.001 (L2) / 0.002 (L1), dense_segmentation.cpp:259-264
+  float inv_scale;            // (float)(1.0 / scale_), segmentation_graph.h:348
+};
+
+// ---- build_kernels.hip ----------------------------------------------------------------
+void UploadSpaceWeights(const float* w49, hipStream_t stream);
+void LaunchMinMax(const uint8_t* bgr, size_t stride, int W, int H, int* mm, hipStream_t s);
+void LaunchBilateral(const uint8_t* bgr, size_t stride, int W, int H, const float* lut,
+                     float scale, float* planes, hipStream_t s);
+void LaunchConvertPlanar(const uint8_t* bgr, size_t stride, int W, int H, float* planes,
+                         hipStream_t s);
+void LaunchInterleavedToPlanar(const float* in, size_t n, float* planes, hipStream_t s);
+void LaunchPlanarToInterleaved(const float* planes, size_t n, float* out, hipStream_t s);
+void LaunchSpatialEdges(const float* feat, int W, int H, int l1, uint16_t* keys, uint32_t* vals,
+                        hipStream_t s);
+void LaunchTemporalEdges(const float* cur, const float* prev, const float* flow, int W, int H,
+                         int l1, int is_virtual, uint16_t* keys, uint32_t* vals,
+                         int32_t* prev_idx, hipStream_t s);
+void LaunchBucketOffsets(const uint16_t* sorted_keys, int n, int* offsets, hipStream_t s);
+void LaunchInitNodes(const float* feat, size_t n, int base, const int32_t* cons_in,
+                     NodeArrays nodes, hipStream_t s);
+void LaunchInitVirtualNodes(const int32_t* labels, size_t n, int base, int num_labels,
+                            int32_t* first_scratch, NodeArrays nodes, hipStream_t s);
+
+// ---- sort_scan.hip (hipCUB wrappers) --------------------------------------------------
+size_t SortPairsU16TempBytes(int n);
+void SortPairsU16(void* temp, size_t temp_bytes, const uint16_t* keys_in, uint16_t* keys_out,
+                  const uint32_t* vals_in, uint32_t* vals_out, int n, hipStream_t s);
+size_t SortPairsU32TempBytes(int n);
+void SortPairsU32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                  const uint32_t* vals_in, uint32_t* vals_out, int n, int end_bit, hipStream_t s);
+size_t SortKeysU64TempBytes(int n);
+void SortKeysU64(void* temp, size_t temp_bytes, const unsigned long long* in,
+                 unsigned long long* out, int n,
+                 hipStream_t s);
+size_t ScanTempBytes(int n);
+void ExclusiveSumI32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, int n,
+                     hipStream_t s);
+size_t RleTempBytes(int n);
+// unique_out[num_runs], counts_out[num_runs], *num_runs_out (device)
+void RunLengthEncodeU32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* unique_out,
+                        int32_t* counts_out, int32_t* num_runs_out, int n, hipStream_t s);
+size_t UniqueU64TempBytes(int n);
+void UniqueU64(void* temp, size_t temp_bytes, const unsigned long long* in,
+               unsigned long long* out,
+               int32_t* num_out, int n, hipStream_t s);
+
+// ---- merge_kernels.hip ----------------------------------------------------------------
+struct MergeScratch {
+  // sized for the largest bucket (n_max edges)
+  int32_t* e_ra;         // root of node a at filter time (per bucket edge)
+  int32_t* e_rb;
+  uint32_t* e_gpos;      // global kept position (list_slot_base[l] + pos)
+  int32_t* e_active;     // 0/1
+  int32_t* e_apos;       // exclusive scan of e_active
+  int32_t* a_ra;         // compacted active edges (bucket order)
+  int32_t* a_rb;
+  uint32_t* a_gpos;
+  uint32_t* a_comp;      // component id (cc root) per active edge
+  uint32_t* a_idx;       // 0..n_active-1
+  uint32_t* s_comp;      // sorted by component (stable)
+  uint32_t* s_idx;
+  uint32_t* seg_key;     // run-length encoding of s_comp
+  int32_t* seg_cnt;
+  int32_t* seg_off;
+  int32_t* num_active;   // device scalar
+  int32_t* num_segs;     // device scalar
+  int32_t* cc;           // [N] component scratch (identity outside a stage)
+  unsigned long long* stats;   // [4] forced, regular, small, active-edge total
+  void* cub_temp;
+  size_t cub_temp_bytes;
+};
+
+// bucket_base[b * (L+1) + l] = number of bucket-b edges in lists < l; [.. + L] = total.
+void LaunchBuildBucketTable(const ListDesc* lists, int num_lists, int32_t* bucket_base,
+                            hipStream_t s);
+void LaunchInitIdentity(int32_t* a, size_t n, hipStream_t s);
+// Runs one bucket stage (filter -> components -> exact workers).  n_b = edges in the bucket.
+void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* bucket_base,
+                    const uint32_t* list_slot_base, uint8_t* kept_all, NodeArrays nodes,
+                    const MergeParams& P, bool inert_enabled, MergeScratch& S, hipStream_t s);
+// Marks every edge of bucket 2048 (virtual edges) as kept.
+void LaunchKeepVirtualBucket(const ListDesc* lists, int num_lists, hipStream_t s);
+
+// ---- readout_kernels.hip --------------------------------------------------------------
+void LaunchFlatten(NodeArrays nodes, size_t n, int32_t* label_uf, hipStream_t s);
+// N4 sweep on the listed slices of label_img (one workgroup per slice); adjust[key] receives the
+// per-region size change.
+void LaunchEnforceN4(int32_t* label_img, int W, int H, const int32_t* frames_dev, int num_frames,
+                     int32_t* adjust /* [N] */, hipStream_t s);
+// Run-length encoding of one slice: counts per row, then intervals.
+void LaunchRowRunCounts(const int32_t* label_img, int W, int H, int frame, int32_t* row_counts,
+                        hipStream_t s);
+struct IntervalArrays {
+  int32_t* label;     // region representative key
+  uint32_t* ty;       // frame << 16 | y
+  int32_t* lx;        // left_x
+  int32_t* rx;        // right_x
+};
+void LaunchWriteIntervals(const int32_t* label_img, int W, int H, int frame,
+                          const int32_t* row_offsets /* exclusive, global */, IntervalArrays out,
+                          hipStream_t s);
+// Relabels nodes covered by the given intervals (tube splitting).
+void LaunchRelabelIntervals(const uint32_t* ty, const int32_t* lx, const int32_t* rx,
+                            const int32_t* new_label, int n, int W, int H, int32_t* label_uf,
+                            hipStream_t s);
+// Emits (ka << 32 | kb) for every kept edge whose end labels differ.  count is a device scalar.
+void LaunchNeighborPairs(const ListDesc* lists, int num_lists, const int32_t* label_uf, int W,
+                         unsigned long long* pairs, unsigned long long* order_keys,
+                         int32_t* count, int capacity, hipStream_t s);
+void LaunchGatherStates(NodeArrays nodes, const int32_t* ids, int n, float4* desc_sz_out,
+                        int32_t* cons_out, int32_t* flags_out, hipStream_t s);
+void LaunchScatterStates(NodeArrays nodes, const int32_t* ids, int n, const int32_t* parent_in,
+                         const float4* desc_sz_in, const int32_t* cons_in, const int32_t* flags_in,
+                         hipStream_t s);
+// Nodes with own constraint >= 0 in [begin, end): flag array for compaction + their roots.
+void LaunchConstrainedRoots(NodeArrays nodes, int begin, int end, int32_t* flag_out,
+                            int32_t* root_out, hipStream_t s);
+void LaunchCompactI32(const int32_t* flags, const int32_t* offsets, const int32_t* values, int n,
+                      int32_t* out, hipStream_t s);
+void LaunchGatherI32(const int32_t* src, const int32_t* idx, int n, int32_t* out, hipStream_t s);
+
+void LaunchNonzeroFlags(const int32_t* a, int n, int32_t* flags, hipStream_t s);
+void LaunchCompactIndexValue(const int32_t* flags, const int32_t* offsets, const int32_t* values,
+                             int n, int32_t* out_idx, int32_t* out_val, hipStream_t s);
+void LaunchFirstOrderOfKeys(const unsigned long long* pairs, const unsigned long long* order_keys,
+                            int m, const int32_t* keys_sorted, int num_keys,
+                            unsigned long long* out_min, hipStream_t s);
+
+}  // namespace vsg
+
+#endif  // VSG_DEVICE_GRAPH_H_

@@ -1,0 +1,91 @@
+// host_model.h -- host-side data model of the product: scan-interval rasters, region table,
+// SegmentationDesc and its proto2 wire encoding.
+//
+// Mirrors (without copying) the reference's data model:
+//   segment_util/segmentation.proto:55-172        SegmentationDesc and nested messages
+//   segmentation/segmentation_common.h:39-116     RegionInformation
+//   segment_util/segmentation_util.h:230          Rasterization3D
+#ifndef VSG_HOST_MODEL_H_
+#define VSG_HOST_MODEL_H_
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace vsg {
+
+struct Interval {
+  int y, lx, rx;
+};
+typedef std::vector<Interval> Raster;
+
+struct RasterSlice {
+  int frame;
+  Raster raster;
+};
+typedef std::vector<RasterSlice> Raster3D;   // ordered by frame
+
+struct Moments {
+  float size = 0, mean_x = 0, mean_y = 0, xx = 0, xy = 0, yy = 0;
+};
+
+// One over-segmentation region (RegionInformation restricted to what the dense path uses).
+struct RegionInfo {
+  int index = -1;
+  int size = 0;
+  bool removed = false;        // FLAGGED_FOR_REMOVAL
+  bool has_raster = false;     // raster != nullptr in the reference
+  std::vector<int> neighbors;  // sorted region indices
+  Raster3D raster;
+  int constrained_id = -1;
+  int region_id = -1;
+};
+
+struct Region2DOut {
+  int id = 0;
+  Raster raster;
+  Moments moments;
+};
+
+struct CompoundOut {
+  int id = 0, size = 0;
+  std::vector<int> neighbor_ids;
+  int start_frame = 0, end_frame = 0;
+};
+
+struct SegDesc {
+  std::vector<Region2DOut> regions;
+  bool has_hierarchy = false;
+  std::vector<CompoundOut> hierarchy0;
+  int frame_width = 0, frame_height = 0;
+  int chunk_size = 0, overlap_start = 0, chunk_id = -1, hierarchy_frame_idx = 0;
+  int connectedness = 1;   // N4_CONNECT = 1, N8_CONNECT = 2
+};
+
+// Raster utilities (postprocess.cpp).
+int RasterArea(const Raster& r);                                   // segmentation_util.cpp:644-650
+void MomentsFromRaster(const Raster& r, Moments* m);               // segmentation_util.cpp:652-693
+void MergeRasters(const Raster& a, const Raster& b, Raster* out);  // segmentation_util.cpp:484-570
+// N4 connected components of a raster, ordered by first interval (segmentation_util.cpp:1025-1101).
+void SplitComponentsN4(const Raster& r, std::vector<Raster>* comps);
+
+// Tube analysis of one region (EnforceSpatialConnectedness, dense_segmentation_graph.h:666-861):
+// returns the final tubes (each a Raster3D) and their areas; tube_to_keep = index of the tube
+// that keeps the region's identity.  flows[frame] = W*H*2 f32 or nullptr; flows may be empty.
+struct TubeResult {
+  std::vector<Raster3D> tubes;
+  std::vector<float> areas;
+  int tube_to_keep = -1;
+};
+void SplitRegionIntoTubes(const Raster3D& raster, int W, int H,
+                          const std::vector<const float*>& flows, bool have_flows,
+                          TubeResult* out);
+
+// proto2 wire encoding of SegmentationDesc (field order = field number order).
+std::string EncodeSegDesc(const SegDesc& d);
+// Renders the Region2D ids into a W*H image (SegmentationDescToIdImage, level 0).
+void RenderIdImage(const SegDesc& d, int W, int32_t* out);
+
+}  // namespace vsg
+
+#endif  // VSG_HOST_MODEL_H_

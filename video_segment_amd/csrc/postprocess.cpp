@@ -1,0 +1,597 @@
+// postprocess.cpp -- host-side post-processing of the GPU over-segmentation: scan-interval
+// utilities, shape moments, spatial-connectedness tube analysis and the SegmentationDesc wire
+// encoder.  These stages work on a few 10^4..10^6 scan intervals (not pixels), are full of
+// order-dependent float decisions, and stay on the host (north_star: "host code stays C++").
+//
+// Reference behaviour restated (never copied); numerics follow the reference's C++ promotion
+// rules on baseline x86-64 (float expressions, double where a double literal / double libm
+// overload appears).  Compile with -ffp-contract=off.
+#include "host_model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace vsg {
+
+int RasterArea(const Raster& r) {
+  int area = 0;
+  for (const Interval& s : r) area += s.rx - s.lx + 1;
+  return area;
+}
+
+// segment_util/segmentation_util.cpp:652-693
+void MomentsFromRaster(const Raster& r, Moments* out) {
+  float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0, area = 0;
+  for (const Interval& s : r) {
+    const float m = (float)s.lx, n = (float)s.rx, y = (float)s.y;
+    const float len = (n - m + 1);
+    area += len;
+    const float cx = (float)((double)(n + m) * 0.5);
+    const float row_x = cx * len;
+    const float row_y = y * len;
+    sx += row_x;
+    sy += row_y;
+    sxy += y * row_x;
+    syy += y * row_y;
+    sxx += len * (-m + 2 * m * m + n + 2 * m * n + 2 * n * n) / 6.0f;
+  }
+  const float inv = 1.0f / area;
+  out->size = area;
+  out->mean_x = sx * inv;
+  out->mean_y = sy * inv;
+  out->xx = sxx * inv;
+  out->xy = sxy * inv;
+  out->yy = syy * inv;
+}
+
+// segment_util/segmentation_util.cpp:484-570
+void MergeRasters(const Raster& a, const Raster& b, Raster* out) {
+  Raster res;
+  res.reserve(a.size() + b.size());
+  size_t ia = 0, ib = 0;
+  std::vector<int> ends;   // left, right, left, right ... of one scanline, ordered by left
+  const int kInf = 1 << 30;
+  while (ia < a.size() || ib < b.size()) {
+    const int ya = ia < a.size() ? a[ia].y : kInf;
+    const int yb = ib < b.size() ? b[ib].y : kInf;
+    if (ya < yb) {
+      res.push_back(a[ia++]);
+      continue;
+    }
+    if (yb < ya) {
+      res.push_back(b[ib++]);
+      continue;
+    }
+    const int y = ya;
+    ends.clear();
+    while (true) {
+      const bool ha = ia < a.size() && a[ia].y == y;
+      const bool hb = ib < b.size() && b[ib].y == y;
+      if (!ha && !hb) break;
+      const int xa = ha ? a[ia].lx : std::numeric_limits<int>::max();
+      const int xb = hb ? b[ib].lx : std::numeric_limits<int>::max();
+      if (xa < xb) {
+        ends.push_back(a[ia].lx);
+        ends.push_back(a[ia].rx);
+        ++ia;
+      } else {
+        ends.push_back(b[ib].lx);
+        ends.push_back(b[ib].rx);
+        ++ib;
+      }
+    }
+    // join runs that abut (next.left - 1 == cur.right)
+    const int n = (int)ends.size();
+    int start = 0, k = 0;
+    while (k < n) {
+      if (k + 2 == n) {
+        res.push_back(Interval{y, ends[start], ends[k + 1]});
+        break;
+      }
+      if (ends[k + 2] - 1 == ends[k + 1]) {
+        k += 2;
+      } else {
+        res.push_back(Interval{y, ends[start], ends[k + 1]});
+        k += 2;
+        start = k;
+      }
+    }
+  }
+  out->swap(res);
+}
+
+// segment_util/segmentation_util.cpp:1009-1101 (N4_CONNECT branch)
+void SplitComponentsN4(const Raster& r, std::vector<Raster>* comps) {
+  const int n = (int)r.size();
+  std::vector<int> uf(n);
+  auto root = [&uf](int i) {
+    while (uf[i] != i) {
+      uf[i] = uf[uf[i]];
+      i = uf[i];
+    }
+    return i;
+  };
+  int row_start = -1, prev_y = -2, first_test = 0;
+  for (int i = 0; i < n; ++i) {
+    uf[i] = i;
+    if (r[i].y != prev_y) {
+      first_test = (prev_y + 1 == r[i].y) ? row_start : i;
+      prev_y = r[i].y;
+      row_start = i;
+    }
+    for (int k = first_test; k < i; ++k) {
+      if (std::abs(r[i].y - r[k].y) <= 1 &&
+          std::max(r[i].lx, r[k].lx) <= std::min(r[i].rx, r[k].rx)) {
+        const int a = root(i), b = root(k);
+        if (a != b) uf[a] = b;
+      }
+    }
+  }
+  int num = 0;
+  for (int i = 0; i < n; ++i) num += (root(i) == i);
+  if (num == 1) {
+    comps->push_back(r);
+    return;
+  }
+  std::vector<int> comp_of_root(n, -1);
+  for (int i = 0; i < n; ++i) {
+    const int rt = root(i);
+    if (comp_of_root[rt] < 0) {
+      comp_of_root[rt] = (int)comps->size();
+      comps->emplace_back();
+    }
+    (*comps)[comp_of_root[rt]].push_back(r[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Shape descriptor (segment_util/segmentation_util.h:138-151, .cpp:243-410).
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct V2 {
+  float x = 0, y = 0;
+};
+inline V2 Add(V2 a, V2 b) { return V2{a.x + b.x, a.y + b.y}; }
+inline V2 Sub(V2 a, V2 b) { return V2{a.x - b.x, a.y - b.y}; }
+inline V2 Mul(V2 a, float s) { return V2{a.x * s, a.y * s}; }
+inline float HypotYX(float y, float x) { return (float)std::hypot((double)y, (double)x); }
+
+struct Shape {
+  V2 center;
+  float mag_major = 0, mag_minor = 0;
+  V2 dir_major{1.0f, 0.0f};
+  V2 dir_minor{0.0f, 1.0f};
+  int size = 0;
+};
+
+// Updates center and size always; axes only when they are reliable (return value true).
+bool ShapeFromMoments(const Moments& mo, Shape* sh) {
+  float mx = 0, my = 0, mxx = 0, mxy = 0, myy = 0, area_sum = 0;
+  const float area = mo.size;
+  area_sum += area;
+  mx += mo.mean_x * area;
+  my += mo.mean_y * area;
+  mxx += mo.xx * area;
+  mxy += mo.xy * area;
+  myy += mo.yy * area;
+  const float inv = 1.0f / area_sum;
+  mx *= inv;
+  my *= inv;
+  mxx *= inv;
+  mxy *= inv;
+  myy *= inv;
+  sh->center = V2{mx, my};
+  sh->size = (int)area_sum;
+  if (area_sum < 10) return false;
+  const float vxx = mxx - mx * mx;
+  const float vxy = mxy - mx * my;
+  const float vyy = myy - my * my;
+  const float trace = vxx + vyy;
+  const float det = vxx * vyy - vxy * vxy;
+  float disc = (float)(0.25 * (double)trace * (double)trace - (double)det);
+  disc = std::max(0.0f, disc);
+  const float sq = (float)std::sqrt((double)disc);
+  const float e1 = (float)((double)trace * 0.5 - (double)sq);
+  const float e2 = (float)((double)trace * 0.5 + (double)sq);
+  if (std::min(std::fabs((double)e1), std::fabs((double)e2)) < 1) return false;
+  V2 ev1{1.0f, 0.0f}, ev2{0.0f, 1.0f};
+  const V2 v1{e1 - vyy, vxy};
+  const V2 v2{e2 - vyy, vxy};
+  const float n1 = HypotYX(v1.y, v1.x);
+  const float n2 = HypotYX(v2.y, v2.x);
+  if (n1 > 1e-6f && n2 > 1e-6f && (double)disc > 0.1) {
+    ev1 = Mul(v1, 1.0f / n1);
+    ev2 = Mul(v2, 1.0f / n2);
+  }
+  float s1 = (float)std::sqrt(std::fabs((double)e1));
+  float s2 = (float)std::sqrt(std::fabs((double)e2));
+  if (s1 < s2) {
+    std::swap(s1, s2);
+    std::swap(ev1, ev2);
+  }
+  const V2 normal{-ev1.y, ev1.x};
+  if (ev2.x * normal.x + ev2.y * normal.y < 0) ev2 = V2{-ev2.x, -ev2.y};
+  sh->center = V2{mx, my};
+  sh->mag_major = s1;
+  sh->mag_minor = s2;
+  sh->dir_major = ev1;
+  sh->dir_minor = ev2;
+  return true;
+}
+
+void ShapeBox(const Shape& s, float border, V2* c) {
+  const V2 major = Mul(s.dir_major, s.mag_major * 1.65f + border);
+  const V2 minor = Mul(s.dir_minor, s.mag_minor * 1.65f + border);
+  c[0] = Add(Sub(s.center, major), minor);
+  c[1] = Sub(Sub(s.center, major), minor);
+  c[2] = Sub(Add(s.center, major), minor);
+  c[3] = Add(Add(s.center, major), minor);
+}
+
+bool BoxesIntersect(const V2* p, const V2* q) {
+  for (int k = 0; k < 4; ++k) {
+    const V2 pd = Sub(p[(k + 1) % 4], p[k]);
+    const double pdx = pd.x, pdy = pd.y;
+    for (int l = 0; l < 4; ++l) {
+      const V2 qd = Sub(q[(l + 1) % 4], q[l]);
+      const double qdx = qd.x, qdy = qd.y;
+      const V2 dl = Sub(q[l], p[k]);
+      const double dx = dl.x, dy = dl.y;
+      const double kross = pdx * qdy - pdy * qdx;
+      if (std::fabs(kross) < 1e-6) continue;
+      const float inv_kross = (float)(1.0f / kross);
+      const double t = (dx * qdy - dy * qdx) * inv_kross;
+      const double s = (dx * pdy - dy * pdx) * inv_kross;
+      if (t > -1e-6f && t < 1.0f + 1e-6f && s > -1e-6f && s < 1.0f + 1e-6f) return true;
+    }
+  }
+  return false;
+}
+
+struct TSlice {
+  int frame = -1;
+  Raster raster;
+  Shape shape;
+  void Recompute() {
+    Moments m;
+    MomentsFromRaster(raster, &m);
+    ShapeFromMoments(m, &shape);   // keeps previous axes if unreliable (reference behaviour)
+  }
+};
+typedef std::vector<TSlice> Tube;
+
+float MeanSliceSize(const Tube& t) {   // dense_segmentation_graph.cpp:35-45
+  if (t.empty()) return 0;
+  float s = 0;
+  for (const TSlice& sl : t) s += (float)sl.shape.size;
+  return s / (float)t.size();
+}
+
+void JoinTubes(const Tube& a, const Tube& b, Tube* out) {   // .cpp:47-88
+  if (a.empty()) {
+    *out = b;
+    return;
+  }
+  if (b.empty()) {
+    *out = a;
+    return;
+  }
+  size_t i = 0, j = 0;
+  while (i < a.size() && j < b.size()) {
+    if (a[i].frame < b[j].frame) {
+      out->push_back(a[i++]);
+    } else if (a[i].frame > b[j].frame) {
+      out->push_back(b[j++]);
+    } else {
+      TSlice m = a[i];
+      MergeRasters(m.raster, b[j].raster, &m.raster);
+      m.Recompute();
+      out->push_back(m);
+      ++i;
+      ++j;
+    }
+  }
+  while (i < a.size()) out->push_back(a[i++]);
+  while (j < b.size()) out->push_back(b[j++]);
+}
+
+bool TemporalNeighbors(const Tube& a, const Tube& b) {   // .cpp:90-110
+  if (a.empty() || b.empty()) return false;
+  const Shape *p, *q;
+  if (a[0].frame - 1 == b.back().frame) {
+    p = &a[0].shape;
+    q = &b.back().shape;
+  } else if (a.back().frame + 1 == b[0].frame) {
+    p = &a.back().shape;
+    q = &b[0].shape;
+  } else {
+    return false;
+  }
+  const float ratio = (float)std::min(p->size, q->size) * (1.0f / (float)std::max(p->size, q->size));
+  const V2 d = Sub(p->center, q->center);
+  return (double)ratio > 0.9 && std::hypot((double)d.y, (double)d.x) < 20;
+}
+
+float MeanCentreDistance(const Tube& a, const Tube& b) {   // .cpp:112-148
+  if (a.empty() || b.empty()) return std::numeric_limits<float>::max();
+  const int f0 = std::max(a[0].frame, b[0].frame);
+  const int f1 = std::min(a.back().frame, b.back().frame);
+  int i = 0, j = 0, w = 0;
+  float sum = 0;
+  for (int f = f0; f <= f1; ++f) {
+    while (a[i].frame < f) ++i;
+    while (b[j].frame < f) ++j;
+    if (a[i].frame != f || b[j].frame != f) continue;
+    const V2 d = Sub(a[i].shape.center, b[j].shape.center);
+    sum = (float)((double)sum + std::hypot((double)d.y, (double)d.x));
+    ++w;
+  }
+  return w > 0 ? sum / (float)w : std::numeric_limits<float>::max();
+}
+
+float BoxOverlapFraction(const Tube& a, const Tube& b) {   // .cpp:150-191
+  if (a.empty() || b.empty()) return std::numeric_limits<float>::max();
+  const int f0 = std::max(a[0].frame, b[0].frame);
+  const int f1 = std::min(a.back().frame, b.back().frame);
+  int i = 0, j = 0, w = 0, hits = 0;
+  for (int f = f0; f <= f1; ++f) {
+    while (a[i].frame < f) ++i;
+    while (b[j].frame < f) ++j;
+    if (a[i].frame != f || b[j].frame != f) continue;
+    V2 pa[4], pb[4];
+    ShapeBox(a[i].shape, 10, pa);
+    ShapeBox(b[j].shape, 10, pb);
+    if (BoxesIntersect(pa, pb)) ++hits;
+    ++w;
+  }
+  return w > 0 ? (float)hits * (1.0f / (float)w) : std::numeric_limits<float>::max();
+}
+
+int ClosestTube(const Tube& t, const std::vector<Tube>& all, int skip) {   // .cpp:193-210
+  float best = std::numeric_limits<float>::max();
+  int best_idx = -1;
+  for (int k = 0; k < (int)all.size(); ++k) {
+    if (k == skip) continue;
+    const float d = MeanCentreDistance(t, all[k]);
+    if (d < best) {
+      best = d;
+      best_idx = k;
+    }
+  }
+  return best_idx;
+}
+
+}  // namespace
+
+// dense_segmentation_graph.h:666-861
+void SplitRegionIntoTubes(const Raster3D& raster, int W, int H,
+                          const std::vector<const float*>& flows, bool have_flows,
+                          TubeResult* out) {
+  out->tubes.clear();
+  out->areas.clear();
+  out->tube_to_keep = -1;
+  std::vector<Tube> done, active;
+  const float inv_diam = (float)(1.0f / std::hypot((double)W, (double)H));
+
+  for (const RasterSlice& rs : raster) {
+    const int frame = rs.frame;
+    std::vector<Raster> comps;
+    SplitComponentsN4(rs.raster, &comps);
+    std::vector<TSlice> slices(comps.size());
+    for (size_t c = 0; c < comps.size(); ++c) {
+      slices[c].frame = frame;
+      slices[c].raster.swap(comps[c]);
+      slices[c].Recompute();
+    }
+    if (active.empty()) {
+      for (TSlice& s : slices) active.push_back(Tube{std::move(s)});
+      continue;
+    }
+    std::vector<Tube> next;
+    std::vector<char> continued(active.size(), 0);
+    for (TSlice& s : slices) {
+      // FindPreviousTube, dense_segmentation_graph.h:601-629
+      V2 c = s.shape.center;
+      if (have_flows) {
+        const float* flow = flows[frame];
+        const float* fp = flow + ((size_t)(int)c.y * W) * 2 + 2 * (int)c.x;
+        c = Add(c, V2{fp[0], fp[1]});
+      }
+      float best = std::numeric_limits<float>::max();
+      float best_idx = -1;   // float in the reference
+      for (int k = 0; k < (int)active.size(); ++k) {
+        if (active[k].empty() || active[k].back().frame >= frame) continue;
+        const V2 d = Sub(active[k].back().shape.center, c);
+        const float dist = HypotYX(d.y, d.x);
+        if (dist < best) {
+          best = dist;
+          best_idx = (float)k;
+        }
+      }
+      const int prev = (int)best_idx;
+      if (prev < 0) {
+        next.push_back(Tube{std::move(s)});
+        continue;
+      }
+      const int sa = active[prev].back().shape.size, sb = s.shape.size;
+      const float ratio = (float)((double)std::min(sa, sb) / ((double)std::max(sa, sb) + 1e-6));
+      if ((double)ratio > 0.75 && best * inv_diam < 0.04f) {
+        continued[prev] = 1;
+        active[prev].push_back(std::move(s));
+        next.emplace_back();
+        next.back().swap(active[prev]);
+      } else {
+        next.push_back(Tube{std::move(s)});
+      }
+    }
+    for (size_t k = 0; k < active.size(); ++k) {
+      if (!continued[k]) done.push_back(std::move(active[k]));
+    }
+    next.swap(active);
+  }
+  for (Tube& t : active) done.push_back(std::move(t));
+
+  if (done.size() > 1) {
+    // pass 1: small or overlapping tubes join their closest tube (:795-816)
+    for (int k = 0; k < (int)done.size();) {
+      bool merge = MeanSliceSize(done[k]) < 20;
+      if (!merge) {
+        for (int l = 0; l < (int)done.size(); ++l) {
+          if (l != k && (double)BoxOverlapFraction(done[k], done[l]) > 0.8) {
+            merge = true;
+            break;
+          }
+        }
+      }
+      bool merged = false;
+      if (merge) {
+        const int idx = ClosestTube(done[k], done, k);
+        if (idx >= 0) {
+          Tube j;
+          JoinTubes(done[idx], done[k], &j);
+          done[idx].swap(j);
+          done.erase(done.begin() + k);
+          merged = true;
+        }
+      }
+      if (!merged) ++k;
+    }
+    // pass 2: tubes abutting in time (:819-839)
+    for (int k = 0; k < (int)done.size();) {
+      bool merged = false;
+      for (int l = 0; l < (int)done.size(); ++l) {
+        if (l == k) continue;
+        if (TemporalNeighbors(done[k], done[l])) {
+          Tube j;
+          JoinTubes(done[k], done[l], &j);
+          done[l].swap(j);
+          done.erase(done.begin() + k);
+          merged = true;
+          break;
+        }
+      }
+      if (!merged) ++k;
+    }
+  }
+
+  // largest tube keeps the region (:841-861)
+  int keep = -1, keep_score = 0;
+  out->areas.resize(done.size());
+  for (int k = 0; k < (int)done.size(); ++k) {
+    float area = 0;
+    for (const TSlice& s : done[k]) area += (float)s.shape.size;
+    out->areas[k] = area;
+    if (area > (float)keep_score) {
+      keep_score = (int)area;
+      keep = k;
+    }
+  }
+  out->tube_to_keep = keep;
+  out->tubes.resize(done.size());
+  for (size_t k = 0; k < done.size(); ++k) {
+    for (TSlice& s : done[k]) {
+      out->tubes[k].push_back(RasterSlice{s.frame, Raster()});
+      out->tubes[k].back().raster.swap(s.raster);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// SegmentationDesc wire encoding (segment_util/segmentation.proto).
+// ---------------------------------------------------------------------------------------
+namespace {
+inline void PutVarint(std::string* s, uint64_t v) {
+  while (v >= 0x80) {
+    s->push_back((char)((v & 0x7f) | 0x80));
+    v >>= 7;
+  }
+  s->push_back((char)v);
+}
+inline void PutInt(std::string* s, int field, int32_t v) {
+  PutVarint(s, ((uint64_t)field << 3) | 0);
+  PutVarint(s, (uint64_t)(int64_t)v);
+}
+inline void PutFloat(std::string* s, int field, float f) {
+  PutVarint(s, ((uint64_t)field << 3) | 5);
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  char b[4] = {(char)(u & 0xff), (char)((u >> 8) & 0xff), (char)((u >> 16) & 0xff), (char)(u >> 24)};
+  s->append(b, 4);
+}
+inline void PutMsg(std::string* s, int field, const std::string& m) {
+  PutVarint(s, ((uint64_t)field << 3) | 2);
+  PutVarint(s, m.size());
+  s->append(m);
+}
+inline size_t VarintLen(uint64_t v) {
+  size_t n = 1;
+  while (v >= 0x80) {
+    v >>= 7;
+    ++n;
+  }
+  return n;
+}
+}  // namespace
+
+std::string EncodeSegDesc(const SegDesc& d) {
+  std::string out;
+  std::string region, raster, tmp;
+  for (const Region2DOut& r : d.regions) {
+    region.clear();
+    PutInt(&region, 1, r.id);                       // Region2D.id = 1
+    raster.clear();
+    for (const Interval& iv : r.raster) {           // Rasterization.scan_inter = 1
+      tmp.clear();
+      PutInt(&tmp, 1, iv.y);
+      PutInt(&tmp, 2, iv.lx);
+      PutInt(&tmp, 3, iv.rx);
+      PutMsg(&raster, 1, tmp);
+    }
+    PutMsg(&region, 3, raster);                     // Region2D.raster = 3
+    tmp.clear();
+    PutFloat(&tmp, 1, r.moments.size);
+    PutFloat(&tmp, 2, r.moments.mean_x);
+    PutFloat(&tmp, 3, r.moments.mean_y);
+    PutFloat(&tmp, 4, r.moments.xx);
+    PutFloat(&tmp, 5, r.moments.xy);
+    PutFloat(&tmp, 6, r.moments.yy);
+    PutMsg(&region, 5, tmp);                        // Region2D.shape_moments = 5
+    PutMsg(&out, 2, region);                        // SegmentationDesc.region = 2
+  }
+  if (d.has_hierarchy) {
+    std::string level, c;
+    for (const CompoundOut& cr : d.hierarchy0) {
+      c.clear();
+      PutInt(&c, 1, cr.id);
+      PutInt(&c, 2, cr.size);
+      for (int n : cr.neighbor_ids) PutInt(&c, 3, n);
+      PutInt(&c, 6, cr.start_frame);
+      PutInt(&c, 7, cr.end_frame);
+      PutMsg(&level, 2, c);                         // HierarchyLevel.region = 2
+    }
+    PutMsg(&out, 3, level);                         // SegmentationDesc.hierarchy = 3
+  }
+  PutInt(&out, 4, d.frame_width);
+  PutInt(&out, 5, d.frame_height);
+  PutInt(&out, 6, d.chunk_size);
+  PutInt(&out, 7, d.overlap_start);
+  PutInt(&out, 8, d.chunk_id);
+  PutInt(&out, 9, d.hierarchy_frame_idx);
+  PutInt(&out, 12, d.connectedness);
+  (void)VarintLen;
+  return out;
+}
+
+void RenderIdImage(const SegDesc& d, int W, int32_t* out) {
+  for (const Region2DOut& r : d.regions) {
+    for (const Interval& iv : r.raster) {
+      int32_t* p = out + (size_t)iv.y * W;
+      for (int x = iv.lx; x <= iv.rx; ++x) p[x] = r.id;
+    }
+  }
+}
+
+}  // namespace vsg

@@ -1,0 +1,94 @@
+// sort_scan.hip -- thin wrappers around rocPRIM/hipCUB device-wide primitives.
+//
+// Only generic building blocks (stable LSD radix sort, exclusive scan, run-length encode,
+// unique) come from the library; every kernel that encodes the segmentation algorithm itself
+// is hand-written in build_kernels.hip / merge_kernels.hip / readout_kernels.hip.
+// The stable radix sort is what realises the reference's implicit counting sort: edges are
+// generated in (scan order, neighbour order) and pushed back into per-bucket vectors
+// (segmentation_graph.h:158-162), i.e. a stable sort by bucket index.
+#include <hipcub/hipcub.hpp>
+
+#include "device_graph.h"
+
+namespace vsg {
+
+size_t SortPairsU16TempBytes(int n) {
+  size_t bytes = 0;
+  VSG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint16_t*)nullptr,
+                                             (uint16_t*)nullptr, (const uint32_t*)nullptr,
+                                             (uint32_t*)nullptr, n, 0, 12));
+  return bytes;
+}
+
+void SortPairsU16(void* temp, size_t temp_bytes, const uint16_t* keys_in, uint16_t* keys_out,
+                  const uint32_t* vals_in, uint32_t* vals_out, int n, hipStream_t s) {
+  // 12 key bits: buckets 0..2047, 2048 (virtual edges), 0xFFF (non-existent border edges).
+  VSG_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in,
+                                             vals_out, n, 0, 12, s));
+}
+
+size_t SortPairsU32TempBytes(int n) {
+  size_t bytes = 0;
+  VSG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr,
+                                             (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                             (uint32_t*)nullptr, n, 0, 32));
+  return bytes;
+}
+
+void SortPairsU32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                  const uint32_t* vals_in, uint32_t* vals_out, int n, int end_bit, hipStream_t s) {
+  VSG_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in,
+                                             vals_out, n, 0, end_bit, s));
+}
+
+size_t SortKeysU64TempBytes(int n) {
+  size_t bytes = 0;
+  VSG_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const unsigned long long*)nullptr,
+                                            (unsigned long long*)nullptr, n, 0, 64));
+  return bytes;
+}
+
+void SortKeysU64(void* temp, size_t temp_bytes, const unsigned long long* in, unsigned long long* out, int n,
+                 hipStream_t s) {
+  VSG_HIP(hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, in, out, n, 0, 64, s));
+}
+
+size_t ScanTempBytes(int n) {
+  size_t bytes = 0;
+  VSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int32_t*)nullptr,
+                                           (int32_t*)nullptr, n));
+  return bytes;
+}
+
+void ExclusiveSumI32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, int n,
+                     hipStream_t s) {
+  VSG_HIP(hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, n, s));
+}
+
+size_t RleTempBytes(int n) {
+  size_t bytes = 0;
+  VSG_HIP(hipcub::DeviceRunLengthEncode::Encode(nullptr, bytes, (const uint32_t*)nullptr,
+                                                (uint32_t*)nullptr, (int32_t*)nullptr,
+                                                (int32_t*)nullptr, n));
+  return bytes;
+}
+
+void RunLengthEncodeU32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* unique_out,
+                        int32_t* counts_out, int32_t* num_runs_out, int n, hipStream_t s) {
+  VSG_HIP(hipcub::DeviceRunLengthEncode::Encode(temp, temp_bytes, in, unique_out, counts_out,
+                                                num_runs_out, n, s));
+}
+
+size_t UniqueU64TempBytes(int n) {
+  size_t bytes = 0;
+  VSG_HIP(hipcub::DeviceSelect::Unique(nullptr, bytes, (const unsigned long long*)nullptr,
+                                       (unsigned long long*)nullptr, (int32_t*)nullptr, n));
+  return bytes;
+}
+
+void UniqueU64(void* temp, size_t temp_bytes, const unsigned long long* in, unsigned long long* out,
+               int32_t* num_out, int n, hipStream_t s) {
+  VSG_HIP(hipcub::DeviceSelect::Unique(temp, temp_bytes, in, out, num_out, n, s));
+}
+
+}  // namespace vsg

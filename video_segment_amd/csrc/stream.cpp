@@ -1,0 +1,455 @@
+// stream.cpp -- see stream.h.  Reference behaviour restated from
+// segmentation/dense_segmentation.cpp:50-432 and segmentation/segmentation.cpp:392-773.
+#include "stream.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace vsg {
+
+namespace {
+double NowMs() {
+  using clk = std::chrono::steady_clock;
+  return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Preprocessor
+// ---------------------------------------------------------------------------------------------
+Preprocessor::Preprocessor(int W, int H, hipStream_t stream) : W_(W), H_(H), stream_(stream) {
+  minmax_dev_.alloc(2);
+}
+
+// Bilateral tables exactly as imagefilter/image_filter.cpp:208-250 builds them on the host:
+// space weights and the 12288-bin exp LUT use the double libm exp() rounded to float.
+const Preprocessor::Lut& Preprocessor::GetLut(int umin, int umax) {
+  auto key = std::make_pair(umin, umax);
+  auto it = luts_.find(key);
+  if (it != luts_.end()) return *it->second;
+  const float c255 = (float)(1.0 / 255.0);
+  const double min_val = (double)((float)umin * c255);
+  const double max_val = (double)((float)umax * c255);
+  const int cn = 3;
+  const float sigma_color = 0.25f;
+  const float diff_range = std::max<float>(
+      1e-3f, (float)((max_val - min_val) * (max_val - min_val) * cn * (double)1.02f));
+  const int num_bins = (1 << 12) * cn;
+  const float scale = (float)num_bins / diff_range;
+  const float color_coeff = (float)(-0.5 / (double)(sigma_color * sigma_color));
+  std::vector<float> lut(num_bins);
+  bool zero_reached = false;
+  for (int i = 0; i < num_bins; ++i) {
+    if (!zero_reached) {
+      lut[i] = (float)std::exp((double)((float)i / scale * color_coeff));
+      zero_reached = ((double)lut[i] < 1e-10);
+    } else {
+      lut[i] = 0;
+    }
+  }
+  std::unique_ptr<Lut> l(new Lut);
+  l->table.alloc((size_t)num_bins);
+  l->scale = scale;
+  VSG_HIP(hipMemcpyAsync(l->table.get(), lut.data(), lut.size() * sizeof(float),
+                         hipMemcpyHostToDevice, stream_));
+  VSG_HIP(hipStreamSynchronize(stream_));
+  if (luts_.size() > 64) luts_.clear();   // bounded cache
+  auto res = luts_.emplace(key, std::move(l));
+  return *res.first->second;
+}
+
+void Preprocessor::Run(const uint8_t* bgr_dev, size_t stride, int presmoothing, float* out) {
+  const double t0 = NowMs();
+  if (presmoothing == 0) {
+    LaunchConvertPlanar(bgr_dev, stride, W_, H_, out, stream_);
+  } else {
+    VSG_REQUIRE(presmoothing == 2, -1,
+                "only PRESMOOTH_NONE and PRESMOOTH_BILATERAL are supported (gaussian needs "
+                "cv::GaussianBlur)");
+    if (!space_uploaded_) {
+      // space_weights, image_filter.cpp:216-225 (radius 4, sigma_space 3.0)
+      float w[49];
+      const float sigma_space = 3.0f;
+      const int radius = (int)(sigma_space * 1.5f);
+      const float coeff = -0.5f / (sigma_space * sigma_space);
+      int k = 0;
+      for (int i = -radius; i <= radius; ++i) {
+        for (int j = -radius; j <= radius; ++j) {
+          const int r2 = i * i + j * j;
+          if (r2 > radius * radius) continue;
+          w[k++] = (float)std::exp((double)(coeff * (float)r2));
+        }
+      }
+      VSG_REQUIRE(k == 49, -4, "unexpected bilateral window");
+      UploadSpaceWeights(w, stream_);
+      space_uploaded_ = true;
+    }
+    LaunchMinMax(bgr_dev, stride, W_, H_, minmax_dev_.get(), stream_);
+    int mm[2] = {0, 0};
+    VSG_HIP(hipMemcpyAsync(mm, minmax_dev_.get(), sizeof(mm), hipMemcpyDeviceToHost, stream_));
+    VSG_HIP(hipStreamSynchronize(stream_));
+    const Lut& lut = GetLut(mm[0], mm[1]);
+    LaunchBilateral(bgr_dev, stride, W_, H_, lut.table.get(), lut.scale, out, stream_);
+  }
+  last_ms_ = (float)(NowMs() - t0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// DenseSegmentationHip
+// ---------------------------------------------------------------------------------------------
+DenseSegmentationHip::DenseSegmentationHip(const vsg_options& o, int W, int H)
+    : options_(o), W_(W), H_(H), wh_((size_t)W * H) {
+  VSG_REQUIRE(options_.chunk_size >= 3, -1, "Chunk size needs to be at least 3 frames.");
+  overlap_frames_ = (int)(options_.chunk_overlap_ratio * (float)options_.chunk_size + 0.5f);
+  overlap_frames_ = std::min(overlap_frames_, 2);
+  VSG_REQUIRE(overlap_frames_ < options_.chunk_size, -1, "Overlap needs to be smaller than chunk_size.");
+  VSG_REQUIRE(overlap_frames_ == 2, -1, "chunk_overlap_ratio too small: the reference needs a 2 frame overlap");
+  VSG_REQUIRE(options_.num_constraint_frames >= 1, -1, "num_constraint_frames >= 1");
+  constraint_frames_ = std::min(options_.num_constraint_frames, overlap_frames_ - 1);
+  if (options_.device >= 0) VSG_HIP(hipSetDevice(options_.device));
+  VSG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  graph_.reset(new DenseGraphHip(W, H, options_.chunk_size + 1, options_.color_distance == 0, stream_));
+  pre_.reset(new Preprocessor(W, H, stream_));
+  std::memset(&last_timings_, 0, sizeof(last_timings_));
+  std::memset(&accum_, 0, sizeof(accum_));
+}
+
+DenseSegmentationHip::~DenseSegmentationHip() {
+  if (stream_) {
+    (void)hipStreamSynchronize(stream_);
+    graph_.reset();
+    pre_.reset();
+    (void)hipStreamDestroy(stream_);
+  }
+}
+
+// dense_segmentation.cpp:268-279: float product truncated to int.
+int DenseSegmentationHip::MinRegionSize() const {
+  return (int)(options_.frac_min_region_size * (float)W_ * options_.frac_min_region_size *
+               (float)H_ * (float)options_.chunk_size);
+}
+
+int DenseSegmentationHip::ProcessFrame(bool flush, const uint8_t* bgr, size_t stride,
+                                       const float* flow, bool has_flow_stream, int mem) {
+  results_.clear();
+  encoded_.clear();
+  if (!graph_open_) {
+    graph_->Reset(options_.chunk_size);
+    graph_open_ = true;
+    seg_chunk_id_ = chunk_id_;
+  }
+  if (bgr) {
+    VSG_REQUIRE(stride >= (size_t)W_ * 3, -1, "stride smaller than a row");
+    const uint8_t* bgr_dev = bgr;
+    if (mem == VSG_MEM_HOST) {
+      staging_bgr_.ensure(stride * (size_t)H_);
+      VSG_HIP(hipMemcpyAsync(staging_bgr_.get(), bgr, stride * (size_t)(H_ - 1) + (size_t)W_ * 3,
+                             hipMemcpyHostToDevice, stream_));
+      bgr_dev = staging_bgr_.get();
+    }
+    DevPlane feat(new DevBuf<float>(3 * wh_));
+    pre_->Run(bgr_dev, stride, options_.presmoothing, feat->get());
+    accum_.preprocess_ms += pre_->last_ms();
+    accum_.preprocess_launches += 1;
+
+    if (has_flow_stream) {
+      flow_stream_seen_ = true;
+      if (input_frames_ == 0 && !pending_import_) {
+        flow_dev_buffer_.push_back(nullptr);
+        flow_host_buffer_.push_back(nullptr);
+      } else {
+        VSG_REQUIRE(flow != nullptr, -1, "Flow always has to be passed or be absent.");
+        DevPlane fd(new DevBuf<float>(2 * wh_));
+        HostFlow fh(new std::vector<float>(2 * wh_));
+        if (mem == VSG_MEM_HOST) {
+          std::memcpy(fh->data(), flow, 2 * wh_ * sizeof(float));
+          VSG_HIP(hipMemcpyAsync(fd->get(), flow, 2 * wh_ * sizeof(float), hipMemcpyHostToDevice,
+                                 stream_));
+        } else {
+          VSG_HIP(hipMemcpyAsync(fd->get(), flow, 2 * wh_ * sizeof(float),
+                                 hipMemcpyDeviceToDevice, stream_));
+          VSG_HIP(hipMemcpyAsync(fh->data(), flow, 2 * wh_ * sizeof(float), hipMemcpyDeviceToHost,
+                                 stream_));
+        }
+        flow_dev_buffer_.push_back(fd);
+        flow_host_buffer_.push_back(fh);
+      }
+    }
+
+    const double te = NowMs();
+    if (pending_import_) {
+      // First frame after vsg_stream_import_halo: it is the constrained overlap frame.
+      feature_buffer_.push_back(nullptr);   // virtual slot
+      feature_buffer_.push_back(feat);
+      if (has_flow_stream) {
+        // keep [empty, flow] layout like after a chunk boundary
+        DevPlane fd = flow_dev_buffer_.back();
+        HostFlow fh = flow_host_buffer_.back();
+        flow_dev_buffer_.clear();
+        flow_host_buffer_.clear();
+        flow_dev_buffer_.push_back(nullptr);
+        flow_host_buffer_.push_back(nullptr);
+        flow_dev_buffer_.push_back(fd);
+        flow_host_buffer_.push_back(fh);
+      }
+      curr_chunk_start_ = 1;
+      StartConstrainedGraph(halo_ids_dev_[0].get(), halo_ids_dev_[1].get(), pending_max_label_);
+      pending_import_ = false;
+    } else {
+      feature_buffer_.push_back(feat);
+      graph_->AddFrame(feat->get(), nullptr);
+      if (feature_buffer_.size() > 1) {
+        const float* fl = flow_dev_buffer_.empty() ? nullptr : flow_dev_buffer_.back()->get();
+        graph_->AddTemporal(feature_buffer_.end()[-1]->get(), feature_buffer_.end()[-2]->get(), fl,
+                            false);
+      }
+    }
+    VSG_HIP(hipStreamSynchronize(stream_));
+    accum_.edges_ms += (float)(NowMs() - te);
+    accum_.edge_launches += 1;
+    ++input_frames_;
+  }
+  if (flush || (int)feature_buffer_.size() - curr_chunk_start_ >= options_.chunk_size) {
+    ChunkBoundaryOutput(flush);
+    return (int)results_.size();
+  }
+  return 0;
+}
+
+// AddVirtualImageConstrained + constrained AddFrame + virtual temporal edges
+// (dense_segmentation.cpp:291-315).
+void DenseSegmentationHip::StartConstrainedGraph(const int32_t* virt_ids_dev,
+                                                 const int32_t* cons_ids_dev, int max_label) {
+  graph_->Reset(curr_chunk_start_ + options_.chunk_size);
+  graph_open_ = true;
+  seg_chunk_id_ = chunk_id_;
+  graph_->AddVirtualFrame(virt_ids_dev, std::max(max_label, 1));
+  graph_->AddFrame(feature_buffer_[1]->get(), cons_ids_dev);
+  const float* fl = flow_dev_buffer_.empty() ? nullptr : flow_dev_buffer_[1]->get();
+  graph_->AddTemporal(nullptr, nullptr, fl, true);
+}
+
+void DenseSegmentationHip::ChunkBoundaryOutput(bool flush) {
+  SegmentAndOutputChunk(flush);
+  if (flush) {
+    graph_open_ = false;
+    return;
+  }
+  VSG_REQUIRE((int)overlap_segmentations_.size() == constraint_frames_ + 1, -4, "overlap size");
+  // Render the two overlap segmentations to id images (SegmentationDescToIdImage).
+  std::vector<int32_t> ids(wh_);
+  for (int k = 0; k < 2; ++k) {
+    std::fill(ids.begin(), ids.end(), -1);
+    RenderIdImage(*overlap_segmentations_[k], W_, ids.data());
+    halo_ids_dev_[k].ensure(wh_);
+    VSG_HIP(hipMemcpyAsync(halo_ids_dev_[k].get(), ids.data(), wh_ * sizeof(int32_t),
+                           hipMemcpyHostToDevice, stream_));
+    VSG_HIP(hipStreamSynchronize(stream_));
+  }
+  halo_valid_ = true;
+  StartConstrainedGraph(halo_ids_dev_[0].get(), halo_ids_dev_[1].get(), max_region_id_);
+  overlap_segmentations_.clear();
+}
+
+void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
+  std::vector<const float*> flows;
+  const bool have_flows = !flow_host_buffer_.empty();
+  if (have_flows) {
+    for (const auto& f : flow_host_buffer_) flows.push_back(f ? f->data() : nullptr);
+  }
+  // RunOverSegmentation (segmentation.cpp:272-303)
+  graph_->FinishBuilding();
+  graph_->Segment(MinRegionSize(), true);
+  graph_->ObtainResults(have_flows ? &flows : nullptr, options_.enforce_n4_connectivity != 0,
+                        options_.enforce_spatial_connectedness != 0);
+  const double t_host0 = NowMs();
+  const GraphTimings& gt = graph_->timings();
+  last_merge_stats_[0] = gt.merges[0];
+  last_merge_stats_[1] = gt.merges[1];
+  last_merge_stats_[2] = gt.merges[2];
+
+  const int buffered = (int)feature_buffer_.size();
+  const int overlap_start = buffered - (flush ? 0 : overlap_frames_);
+  const int last_output_frame = std::min(buffered - 1, overlap_start);
+  VSG_REQUIRE(overlap_start > curr_chunk_start_, -3, "flush without buffered frames");
+  const int max_result_frame = std::min(buffered - 1, last_output_frame + constraint_frames_);
+
+  std::vector<RegionInfo>& regions = graph_->regions();
+  const int lhs = 0, rhs = last_output_frame + 1;
+  // ConstrainSegmentationToFrameInterval (segmentation.cpp:392-420)
+  for (RegionInfo& r : regions) {
+    if (!r.has_raster || r.raster.empty() || r.raster.front().frame >= rhs ||
+        r.raster.back().frame < lhs) {
+      r.removed = true;
+    }
+  }
+  // AdjustRegionAreaToFrameInterval (segmentation.cpp:422-456)
+  for (RegionInfo& r : regions) {
+    if (!r.has_raster) continue;
+    int inc = 0;
+    for (const RasterSlice& sl : r.raster) {
+      if (sl.frame < lhs || sl.frame >= rhs) inc -= RasterArea(sl.raster);
+    }
+    r.size += inc;
+  }
+  // AssignUniqueRegionIds (segmentation.cpp:537-582)
+  const bool use_constraints = chunk_id_ > 0;
+  assigned_constrained_ids_ = use_constraints;
+  int max_id = -1;
+  for (RegionInfo& r : regions) {
+    r.region_id = (use_constraints && r.constrained_id >= 0) ? r.constrained_id
+                                                             : r.index + max_region_id_;
+    max_id = std::max(max_id, r.region_id);
+  }
+  max_region_id_ = std::max(max_region_id_, max_id + 1);
+
+  const int chunk_size = last_output_frame - curr_chunk_start_ + 1;
+  overlap_segmentations_.clear();
+  const int hierarchy_frame_idx = num_output_frames_;
+  for (int frame_idx = curr_chunk_start_; frame_idx <= max_result_frame; ++frame_idx) {
+    std::unique_ptr<SegDesc> desc(new SegDesc());
+    Retrieve(frame_idx, frame_idx == curr_chunk_start_, desc.get());
+    desc->chunk_size = chunk_size;
+    desc->overlap_start = chunk_size;
+    desc->hierarchy_frame_idx = hierarchy_frame_idx;
+    if (frame_idx < last_output_frame) {
+      results_.push_back(std::move(desc));
+      ++num_output_frames_;
+      continue;
+    }
+    if (frame_idx == last_output_frame) {
+      results_.push_back(std::unique_ptr<SegDesc>(new SegDesc(*desc)));
+      ++num_output_frames_;
+    }
+    overlap_segmentations_.push_back(std::move(desc));
+  }
+
+  feature_buffer_.erase(feature_buffer_.begin(), feature_buffer_.begin() + last_output_frame);
+  if (!flow_dev_buffer_.empty()) {
+    flow_dev_buffer_.erase(flow_dev_buffer_.begin(), flow_dev_buffer_.begin() + last_output_frame);
+    flow_host_buffer_.erase(flow_host_buffer_.begin(),
+                            flow_host_buffer_.begin() + last_output_frame);
+  }
+  curr_chunk_start_ = flush ? 0 : 1;
+  if (!flush) {
+    VSG_REQUIRE(overlap_frames_ == (int)feature_buffer_.size(), -4, "overlap buffer size");
+    feature_buffer_[0].reset();
+    if (!flow_dev_buffer_.empty()) {
+      flow_dev_buffer_[0].reset();
+      flow_host_buffer_[0].reset();
+    }
+  }
+  ++chunk_id_;
+
+  std::memset(&last_timings_, 0, sizeof(last_timings_));
+  last_timings_.preprocess_ms = accum_.preprocess_ms;
+  last_timings_.edges_ms = accum_.edges_ms;
+  last_timings_.preprocess_launches = accum_.preprocess_launches;
+  last_timings_.edge_launches = accum_.edge_launches;
+  last_timings_.merge_ms = gt.merge_ms;
+  last_timings_.readout_ms = gt.readout_ms;
+  last_timings_.host_post_ms = gt.host_post_ms + (float)(NowMs() - t_host0);
+  last_timings_.edges_total = gt.edges_total;
+  last_timings_.edges_active = gt.edges_active;
+  last_timings_.merges = gt.merges[0] + gt.merges[1] + gt.merges[2];
+  std::memset(&accum_, 0, sizeof(accum_));
+}
+
+// RetrieveSegmentation3D (segmentation.cpp:458-533, 671-773) without descriptors/vectorization.
+void DenseSegmentationHip::Retrieve(int frame, bool output_hierarchy, SegDesc* desc) const {
+  const std::vector<RegionInfo>& regions = graph_->regions();
+  desc->frame_width = W_;
+  desc->frame_height = H_;
+  desc->chunk_id = seg_chunk_id_;
+  desc->connectedness = options_.enforce_n4_connectivity ? 1 : 2;
+  for (const RegionInfo& r : regions) {
+    if (!r.has_raster) continue;
+    auto it = std::lower_bound(r.raster.begin(), r.raster.end(), frame,
+                               [](const RasterSlice& s, int f) { return s.frame < f; });
+    if (it == r.raster.end() || it->frame != frame) continue;
+    desc->regions.emplace_back();
+    Region2DOut& o = desc->regions.back();
+    o.id = r.region_id;
+    o.raster = it->raster;
+    MomentsFromRaster(o.raster, &o.moments);
+  }
+  if (assigned_constrained_ids_) {
+    std::sort(desc->regions.begin(), desc->regions.end(),
+              [](const Region2DOut& a, const Region2DOut& b) { return a.id < b.id; });
+  }
+  if (output_hierarchy) {
+    desc->has_hierarchy = true;
+    for (const RegionInfo& r : regions) {
+      if (r.removed) continue;
+      desc->hierarchy0.emplace_back();
+      CompoundOut& c = desc->hierarchy0.back();
+      c.id = r.region_id;
+      c.size = r.size;
+      for (int n : r.neighbors) {
+        if (regions[n].removed) continue;
+        c.neighbor_ids.push_back(regions[n].region_id);
+      }
+      if (assigned_constrained_ids_) std::sort(c.neighbor_ids.begin(), c.neighbor_ids.end());
+      c.start_frame = r.raster.front().frame;
+      c.end_frame = r.raster.back().frame;
+    }
+    if (assigned_constrained_ids_) {
+      std::sort(desc->hierarchy0.begin(), desc->hierarchy0.end(),
+                [](const CompoundOut& a, const CompoundOut& b) { return a.id < b.id; });
+    }
+  }
+}
+
+const std::string& DenseSegmentationHip::result_bytes(int i) {
+  if (encoded_.size() != results_.size()) {
+    encoded_.clear();
+    for (const auto& r : results_) encoded_.push_back(EncodeSegDesc(*r));
+  }
+  return encoded_[i];
+}
+
+void DenseSegmentationHip::last_merge_stats(int64_t* s3) const {
+  s3[0] = last_merge_stats_[0];
+  s3[1] = last_merge_stats_[1];
+  s3[2] = last_merge_stats_[2];
+}
+
+void DenseSegmentationHip::CopyLastSmoothed(float* out) {
+  VSG_REQUIRE(!feature_buffer_.empty() && feature_buffer_.back(), -3, "no buffered frame");
+  DevBuf<float> tmp(3 * wh_);
+  LaunchPlanarToInterleaved(feature_buffer_.back()->get(), wh_, tmp.get(), stream_);
+  VSG_HIP(hipMemcpyAsync(out, tmp.get(), 3 * wh_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  VSG_HIP(hipStreamSynchronize(stream_));
+}
+
+void DenseSegmentationHip::ExportHalo(const int32_t** virt, const int32_t** cons,
+                                      int64_t scalars[4]) {
+  VSG_REQUIRE(halo_valid_, -3, "no chunk boundary has been processed yet");
+  *virt = halo_ids_dev_[0].get();
+  *cons = halo_ids_dev_[1].get();
+  scalars[0] = max_region_id_;
+  scalars[1] = chunk_id_;
+  scalars[2] = num_output_frames_;
+  scalars[3] = input_frames_;
+}
+
+void DenseSegmentationHip::ImportHalo(const int32_t* virt, const int32_t* cons, int mem,
+                                      const int64_t scalars[4]) {
+  VSG_REQUIRE(input_frames_ == 0 && !graph_open_, -3, "import_halo needs a fresh stream");
+  const hipMemcpyKind kind = mem == VSG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  halo_ids_dev_[0].ensure(wh_);
+  halo_ids_dev_[1].ensure(wh_);
+  VSG_HIP(hipMemcpyAsync(halo_ids_dev_[0].get(), virt, wh_ * sizeof(int32_t), kind, stream_));
+  VSG_HIP(hipMemcpyAsync(halo_ids_dev_[1].get(), cons, wh_ * sizeof(int32_t), kind, stream_));
+  VSG_HIP(hipStreamSynchronize(stream_));
+  max_region_id_ = (int)scalars[0];
+  chunk_id_ = (int)scalars[1];
+  num_output_frames_ = (int)scalars[2];
+  input_frames_ = (int)scalars[3] - 1;   // the constrained frame is fed again
+  pending_max_label_ = max_region_id_;
+  pending_import_ = true;
+}
+
+}  // namespace vsg

@@ -1,0 +1,243 @@
+"""Python host mirror of the reference's operator interface for the dense over-segmentation path.
+
+``DenseSegmentation`` mirrors segmentation::DenseSegmentation (segmentation/dense_segmentation.h:
+112-186): ``process_frame(flush, features, flow)`` returns the number of results and the results
+are serialized ``SegmentationDesc`` protobuf messages.  ``DenseSegGraph`` mirrors
+segmentation::DenseSegGraphInterface (dense_seg_graph_interface.h:107-159).
+
+Everything below is a thin ctypes layer over the C ABI (include/vsg.h); all computation happens in
+the HIP library.  Inputs may be numpy arrays (host memory) or torch CUDA tensors (device memory,
+used as plain device pointers).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import VsgOptions, VsgTimings, check, lib
+
+
+def default_options(**kw):
+    o = VsgOptions()
+    lib().vsg_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr_mem(x):
+    """Returns (pointer, mem kind) of a numpy array or torch tensor (None -> (None, host))."""
+    if x is None:
+        return None, _lib.VSG_MEM_HOST
+    if _is_torch(x):
+        assert x.is_contiguous() or x.dim() == 3
+        mem = _lib.VSG_MEM_DEVICE if x.is_cuda else _lib.VSG_MEM_HOST
+        return C.c_void_p(x.data_ptr()), mem
+    return x.ctypes.data_as(C.c_void_p), _lib.VSG_MEM_HOST
+
+
+def _row_stride(bgr):
+    if _is_torch(bgr):
+        assert bgr.stride(2) == 1 and bgr.stride(1) == 3
+        return bgr.stride(0) * bgr.element_size()
+    assert bgr.strides[2] == 1 and bgr.strides[1] == 3
+    return bgr.strides[0]
+
+
+class DenseSegmentation:
+    """Drop-in for segmentation::DenseSegmentation running on one MI355X."""
+
+    def __init__(self, width, height, options=None, has_flow=False):
+        self.W, self.H = width, height
+        self.has_flow = has_flow
+        self.opts = options if options is not None else default_options()
+        h = C.c_void_p()
+        check(lib().vsg_stream_create(C.byref(self.opts), width, height, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().vsg_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def chunk_size(self):
+        return lib().vsg_stream_chunk_size(self.h)
+
+    def process_frame(self, bgr, flow=None, flush=False):
+        """bgr: HxWx3 uint8 (numpy or torch cuda), or None for a pure flush; flow: HxWx2 f32."""
+        stride = 0
+        if bgr is not None:
+            assert tuple(bgr.shape) == (self.H, self.W, 3)
+            stride = _row_stride(bgr)
+        p_bgr, mem = _ptr_mem(bgr)
+        if flow is not None:
+            assert tuple(flow.shape) == (self.H, self.W, 2)
+            if not _is_torch(flow):
+                flow = np.ascontiguousarray(flow, dtype=np.float32)
+            p_flow, mem_f = _ptr_mem(flow)
+            assert bgr is None or mem_f == mem, "frame and flow must live in the same memory kind"
+        else:
+            p_flow = None
+        n = C.c_int()
+        check(lib().vsg_stream_process_frame(self.h, int(flush), p_bgr, stride, p_flow,
+                                             int(self.has_flow), mem, C.byref(n)))
+        self._n = n.value
+        return n.value
+
+    def result_bytes(self, i):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        check(lib().vsg_stream_result_bytes(self.h, i, C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value)
+
+    def result_id_image(self, i):
+        out = np.empty((self.H, self.W), np.int32)
+        check(lib().vsg_stream_result_id_image(self.h, i, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def last_merge_stats(self):
+        s = np.zeros(3, np.int64)
+        check(lib().vsg_stream_last_merge_stats(self.h, s.ctypes.data_as(C.c_void_p)))
+        return s
+
+    def last_timings(self):
+        t = VsgTimings()
+        check(lib().vsg_stream_last_timings(self.h, C.byref(t)))
+        return t
+
+    def last_smoothed(self):
+        out = np.empty((self.H, self.W, 3), np.float32)
+        check(lib().vsg_stream_last_smoothed(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def export_halo(self):
+        """Returns (dev_ptr_virtual, dev_ptr_constrained, scalars[4]) after a chunk boundary."""
+        a, b = C.c_void_p(), C.c_void_p()
+        s = np.zeros(4, np.int64)
+        check(lib().vsg_stream_export_halo(self.h, C.byref(a), C.byref(b),
+                                           s.ctypes.data_as(C.c_void_p)))
+        return a.value, b.value, s
+
+    def import_halo(self, labels_virtual, labels_constrained, scalars):
+        pa, mem = _ptr_mem(labels_virtual)
+        pb, mem_b = _ptr_mem(labels_constrained)
+        assert mem == mem_b
+        s = np.ascontiguousarray(scalars, dtype=np.int64)
+        check(lib().vsg_stream_import_halo(self.h, pa, pb, mem, s.ctypes.data_as(C.c_void_p)))
+
+
+class DenseSegGraph:
+    """Drop-in for segmentation::DenseSegGraphInterface (one chunk graph)."""
+
+    def __init__(self, width, height, max_frames, l1=False, device=-1):
+        self.W, self.H, self.max_frames = width, height, max_frames
+        h = C.c_void_p()
+        check(lib().vsg_graph_create(width, height, max_frames, int(l1), device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().vsg_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def add_frame_bgr(self, bgr, presmoothing=2, constraint_ids=None):
+        p, mem = _ptr_mem(bgr)
+        if constraint_ids is not None and not _is_torch(constraint_ids):
+            constraint_ids = np.ascontiguousarray(constraint_ids, np.int32)
+        pc, _ = _ptr_mem(constraint_ids)
+        check(lib().vsg_graph_add_frame_bgr(self.h, p, _row_stride(bgr), presmoothing, pc, mem))
+
+    def add_frame_features(self, feat, constraint_ids=None):
+        if not _is_torch(feat):
+            feat = np.ascontiguousarray(feat, np.float32)
+        p, mem = _ptr_mem(feat)
+        if constraint_ids is not None and not _is_torch(constraint_ids):
+            constraint_ids = np.ascontiguousarray(constraint_ids, np.int32)
+        pc, _ = _ptr_mem(constraint_ids)
+        check(lib().vsg_graph_add_frame_features(self.h, p, pc, mem))
+
+    def add_virtual_frame(self, constraint_ids):
+        if not _is_torch(constraint_ids):
+            constraint_ids = np.ascontiguousarray(constraint_ids, np.int32)
+        p, mem = _ptr_mem(constraint_ids)
+        check(lib().vsg_graph_add_virtual_frame(self.h, p, mem))
+
+    def add_temporal(self, flow=None, is_virtual=False):
+        if flow is not None and not _is_torch(flow):
+            flow = np.ascontiguousarray(flow, np.float32)
+        p, mem = _ptr_mem(flow)
+        check(lib().vsg_graph_add_temporal(self.h, p, int(is_virtual), mem))
+
+    def finish_building(self):
+        check(lib().vsg_graph_finish_building(self.h))
+
+    def segment(self, min_region_size, force_constraints):
+        check(lib().vsg_graph_segment(self.h, int(min_region_size), int(force_constraints)))
+
+    def obtain_results(self, use_flows=False, enforce_n4=True, enforce_spatial_connectedness=True):
+        check(lib().vsg_graph_obtain_results(self.h, int(use_flows), int(enforce_n4),
+                                             int(enforce_spatial_connectedness)))
+
+    def num_frames(self):
+        return lib().vsg_graph_num_frames(self.h)
+
+    def num_regions(self):
+        return lib().vsg_graph_num_regions(self.h)
+
+    def num_neighbor_links(self):
+        return lib().vsg_graph_num_neighbor_links(self.h)
+
+    def region_sizes(self):
+        n = self.num_regions()
+        s = np.empty(n, np.int32)
+        c = np.empty(n, np.int32)
+        check(lib().vsg_graph_region_sizes(self.h, s.ctypes.data_as(C.c_void_p),
+                                           c.ctypes.data_as(C.c_void_p)))
+        return s, c
+
+    def index_image(self, t):
+        out = np.empty((self.H, self.W), np.int32)
+        check(lib().vsg_graph_index_image(self.h, t, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def smoothed(self, t):
+        out = np.empty((self.H, self.W, 3), np.float32)
+        check(lib().vsg_graph_smoothed(self.h, t, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def spatial_buckets(self, t):
+        out = np.empty((4, self.H, self.W), np.uint16)
+        check(lib().vsg_graph_spatial_buckets(self.h, t, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def temporal_buckets(self, t):
+        out = np.empty((9, self.H, self.W), np.uint16)
+        pidx = np.empty((self.H, self.W), np.int32)
+        check(lib().vsg_graph_temporal_buckets(self.h, t, out.ctypes.data_as(C.c_void_p),
+                                               pidx.ctypes.data_as(C.c_void_p)))
+        return out, pidx
+
+    def node_roots(self):
+        out = np.empty(self.W * self.H * self.num_frames(), np.int32)
+        check(lib().vsg_graph_node_roots(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def merge_stats(self):
+        s = np.zeros(3, np.int64)
+        check(lib().vsg_graph_merge_stats(self.h, s.ctypes.data_as(C.c_void_p)))
+        return s
+
+    def timings(self):
+        t = VsgTimings()
+        check(lib().vsg_graph_timings(self.h, C.byref(t)))
+        return t
