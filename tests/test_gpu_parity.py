@@ -172,7 +172,7 @@ def run_streams(vsg, W, H, N, kind, flow, chunk, seed=5, frames=None):
     (64, 48, 8, "probe", True, 20),
     (64, 48, 45, "probe", True, 20),      # 3 chunks: virtual + constrained slices
     (64, 48, 30, "noise", True, 8),       # many chunks, heavy min-size merging
-    (50, 36, 12, "const", False, 5),      # single region
+    (50, 36, 20, "const", False, 8),      # single region
     (64, 48, 1, "probe", False, 20),      # one frame
     (96, 64, 26, "smooth", True, 10),
     (128, 96, 24, "bench", True, 20),

@@ -85,6 +85,13 @@ def lib():
         raise RuntimeError(
             "libvsg_hip.so is missing (%s): build the HIP extension first; there is no fallback "
             "path" % LIB_PATH)
+    # PyTorch-ROCm wheels bundle their own libamdhip64.  Two HIP runtimes in one process do not
+    # work (whichever is loaded second sees no device), so when torch is installed it is imported
+    # first and libvsg_hip.so then binds to the runtime torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.vsg_last_error.restype = C.c_char_p

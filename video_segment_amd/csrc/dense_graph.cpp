@@ -294,13 +294,13 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
   }
   if (cursor < N) nvranges.emplace_back(cursor, N);
 
-  // scratch: label_uf_ = flags, label_img_ = roots, adjust_ = offsets / compacted (all N ints)
+  // scratch: label_uf_ = flags, label_img_ = roots, adjust_ = offsets (all N ints)
   int32_t* d_flags = label_uf_.get();
   int32_t* d_roots = label_img_.get();
   int32_t* d_offs = adjust_.get();
-  // The run lists are small; collect them per range.
-  auto collect_runs = [&](int begin, int end, std::vector<int32_t>* run_roots,
-                          std::vector<int32_t>* run_counts) {
+  // Flagged nodes (own constraint >= 0) with their representative, in node order.
+  auto collect = [&](int begin, int end, std::vector<int32_t>* node_ids,
+                     std::vector<int32_t>* node_roots) {
     const int n = end - begin;
     if (n <= 0) return;
     LaunchConstrainedRoots(nodes(), begin, end, d_flags, d_roots, stream_);
@@ -312,26 +312,19 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
     const int k = last_off + last_flag;
     if (k == 0) return;
     EnsureScratch((size_t)k);
-    // compact roots into a_ra_ (as int32), then RLE into seg_key_/seg_cnt_
-    LaunchCompactI32(d_flags, d_offs, d_roots, n, a_ra_.get(), stream_);
-    RunLengthEncodeU32(cub_temp_.get(), cub_temp_.size(),
-                       reinterpret_cast<const uint32_t*>(a_ra_.get()), seg_key_.get(),
-                       seg_cnt_.get(), scalars_.get() + 2, k, stream_);
-    int runs = 0;
-    D2H(&runs, scalars_.get() + 2, 1, stream_);
+    LaunchCompactIndexValue(d_flags, d_offs, d_roots, n, a_ra_.get(), a_rb_.get(), stream_);
+    const size_t old = node_ids->size();
+    node_ids->resize(old + k);
+    node_roots->resize(old + k);
+    D2H(node_ids->data() + old, a_ra_.get(), (size_t)k, stream_);
+    D2H(node_roots->data() + old, a_rb_.get(), (size_t)k, stream_);
     VSG_HIP(hipStreamSynchronize(stream_));
-    const size_t old = run_roots->size();
-    run_roots->resize(old + runs);
-    run_counts->resize(old + runs);
-    D2H(run_roots->data() + old, reinterpret_cast<const int32_t*>(seg_key_.get()), (size_t)runs,
-        stream_);
-    D2H(run_counts->data() + old, seg_cnt_.get(), (size_t)runs, stream_);
-    VSG_HIP(hipStreamSynchronize(stream_));
+    for (size_t i = old; i < old + (size_t)k; ++i) (*node_ids)[i] += begin;
   };
 
-  std::vector<int32_t> nv_roots, nv_counts, v_roots, v_counts;
-  for (auto& r : nvranges) collect_runs(r.first, r.second, &nv_roots, &nv_counts);
-  for (auto& r : vranges) collect_runs(r.first, r.second, &v_roots, &v_counts);
+  std::vector<int32_t> nv_nodes, nv_roots, v_nodes, v_roots;
+  for (auto& r : nvranges) collect(r.first, r.second, &nv_nodes, &nv_roots);
+  for (auto& r : vranges) collect(r.first, r.second, &v_nodes, &v_roots);
 
   // Distinct representatives and their states.
   std::vector<int32_t> ids;
@@ -407,58 +400,107 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
   };
 
   std::unordered_map<int, int> c2r;
-  // non-virtual pass
-  for (size_t k = 0; k < nv_roots.size(); ++k) {
-    for (int rep = 0; rep < nv_counts[k]; ++rep) {
-      const int my = find(nv_roots[k]);
-      SimRegion& me = sim.at(my);
-      auto pos = c2r.find(me.cons);
-      if (pos == c2r.end()) {
-        c2r.emplace(me.cons, my);
-        continue;   // map changed
+  // One visit of the reference's loop body for a node whose representative (before the pass)
+  // is r0.  Returns true if anything changed.
+  auto visit_nonvirtual = [&](int r0) -> bool {
+    const int my = find(r0);
+    SimRegion& me = sim.at(my);
+    auto pos = c2r.find(me.cons);
+    if (pos == c2r.end()) {
+      c2r.emplace(me.cons, my);
+      return true;
+    }
+    const int crep = find(pos->second);
+    if (crep == my) return false;
+    SimRegion& cr = sim.at(crep);
+    const float dist = distance(me, cr, 1.0f);
+    if (dist > 0.15f) {
+      if ((double)me.sz < (double)cr.sz * 0.3) {
+        const bool ch = me.cons != -1;
+        me.cons = -1;
+        me.dirty = true;
+        return ch;
+      } else if ((double)cr.sz < (double)me.sz * 0.3) {
+        const bool ch = (cr.cons != -1) || (pos->second != my);
+        cr.cons = -1;
+        cr.dirty = true;
+        pos->second = my;
+        return ch;
       }
-      const int crep = find(pos->second);
-      if (crep == my) break;   // no-op from here on
-      SimRegion& cr = sim.at(crep);
-      const float dist = distance(me, cr, 1.0f);
-      bool changed = false;
-      if (dist > 0.15f) {
-        if ((double)me.sz < (double)cr.sz * 0.3) {
-          changed = me.cons != -1;
-          me.cons = -1;
-          me.dirty = true;
-        } else if ((double)cr.sz < (double)me.sz * 0.3) {
-          changed = (cr.cons != -1) || (pos->second != my);
-          cr.cons = -1;
-          cr.dirty = true;
-          pos->second = my;
-        } else {
-          me.cons = -1;
-          cr.cons = -1;
-          me.dirty = cr.dirty = true;
-          c2r.erase(pos);
-          changed = true;
+      me.cons = -1;
+      cr.cons = -1;
+      me.dirty = cr.dirty = true;
+      c2r.erase(pos);
+      return true;
+    }
+    merge(my, crep);
+    return true;
+  };
+
+  // Non-virtual pass.  Visit order = node id order.  A node that is (or was) a representative
+  // is tested with its *current* own constraint field (it changes when the region is
+  // unconstrained or inherits a constraint through a merge); other nodes keep the value they had
+  // before the pass (>= 0 for every listed node).  Representatives whose own field was < 0 before
+  // the pass are not in the flagged list and are visited through `extra`.
+  std::vector<int32_t> extra;
+  {
+    std::vector<std::pair<int, int>> nvr = nvranges;
+    for (int id : ids) {
+      const SimRegion& r = sim.at(id);
+      if (r.cons >= 0) continue;
+      for (auto& rg : nvr) {
+        if (id >= rg.first && id < rg.second) {
+          extra.push_back(id);
+          break;
         }
-      } else {
-        merge(my, crep);
-        changed = true;
       }
-      if (!changed) break;
+    }
+  }   // ids is sorted, so extra is sorted
+  {
+    size_t ia = 0, ib = 0;
+    int noop_root = -1;   // representative whose plain member visits are currently no-ops
+    while (ia < nv_nodes.size() || ib < extra.size()) {
+      int node, r0;
+      if (ib >= extra.size() || (ia < nv_nodes.size() && nv_nodes[ia] < extra[ib])) {
+        node = nv_nodes[ia];
+        r0 = nv_roots[ia];
+        ++ia;
+      } else {
+        node = extra[ib];
+        r0 = node;
+        ++ib;
+      }
+      auto self = sim.find(node);
+      if (self != sim.end()) {
+        if (self->second.cons < 0) continue;   // region->constraint_id < 0
+      } else if (r0 == noop_root) {
+        continue;   // same state, same input as the previous no-op visit
+      }
+      const bool changed = visit_nonvirtual(r0);
+      noop_root = changed ? -1 : r0;
     }
   }
-  // virtual pass
-  for (size_t k = 0; k < v_roots.size(); ++k) {
-    for (int rep = 0; rep < v_counts[k]; ++rep) {
-      const int my = find(v_roots[k]);
+  // Virtual pass: never reset, always merge.
+  {
+    int noop_root = -1;
+    for (size_t k = 0; k < v_nodes.size(); ++k) {
+      const int r0 = v_roots[k];
+      if (r0 == noop_root) continue;
+      const int my = find(r0);
       SimRegion& me = sim.at(my);
       auto pos = c2r.find(me.cons);
+      bool changed = true;
       if (pos == c2r.end()) {
         c2r.emplace(me.cons, my);
-        continue;
+      } else {
+        const int crep = find(pos->second);
+        if (crep == my) {
+          changed = false;
+        } else {
+          merge(my, crep);
+        }
       }
-      const int crep = find(pos->second);
-      if (crep == my) break;
-      merge(my, crep);
+      noop_root = changed ? -1 : r0;
     }
   }
 

@@ -58,10 +58,11 @@ class DenseSegmentation:
         h = C.c_void_p()
         check(lib().vsg_stream_create(C.byref(self.opts), width, height, C.byref(h)))
         self.h = h
+        self._destroy = lib().vsg_stream_destroy
 
     def close(self):
         if getattr(self, "h", None):
-            lib().vsg_stream_destroy(self.h)
+            self._destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -141,10 +142,11 @@ class DenseSegGraph:
         h = C.c_void_p()
         check(lib().vsg_graph_create(width, height, max_frames, int(l1), device, C.byref(h)))
         self.h = h
+        self._destroy = lib().vsg_graph_destroy
 
     def close(self):
         if getattr(self, "h", None):
-            lib().vsg_graph_destroy(self.h)
+            self._destroy(self.h)
             self.h = None
 
     def __del__(self):
