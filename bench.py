@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X dense over-segmentation hot path.
+
+Metric (BASELINE.json): over-segmented frames/sec at 1080p.
+Workload at N=1 (BASELINE.json configs[2]): 1920x1080 synthetic gradient + moving checker + noise
+video with a precomputed constant backward flow, chunk_size 20, spatial + temporal dense graph,
+streamed through the DenseSegmentation drop-in (vsg_stream_*) with frames and flow already
+resident in HBM.
+
+A *step* is one chunk boundary of the stream: the call that segments the buffered chunk graph and
+returns chunk_size-1 = 19 SegmentationDesc (steady state; every timed step is a constrained
+chunk).  Warm-up steps include the first (unconstrained) chunk.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): every rank segments its own,
+independent 1080p stream (different noise seed) -- the path partitions by video; the chunks of ONE
+video form a dependency chain (chunk c+1 is constrained by chunk c's labels), see DESIGN.md.
+No data-path collective is needed; ranks only meet for the timing barrier and the reductions.
+`--mode chain` instead shards the chunks of one video round-robin over the ranks and hands the
+two label planes + counters to the next rank with RCCL send/recv (the reference-exact multi-GPU
+mode; it cannot scale because of the chain).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (first: a single HIP runtime per process, see video_segment_amd/_lib.py)
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_PX_FRAME = 111.0      # spatial + temporal + flow
+# Algorithmic bytes of the dominant kernel (k_merge_wave) per replayed edge, see DESIGN.md:
+# edge record (sorted index 4 + two root hints 8 + kept position 4) + two parent words 8
+# + two 21-byte region states (desc_sz 16, cons 4, flags 1).
+WAVE_BYTES_PER_EDGE = 4 + 8 + 4 + 8 + 2 * 21
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--chunk", type=int, default=20)
+    ap.add_argument("--mode", choices=["streams", "chain"], default="streams")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(W, H, chunk, n_frames):
+    """Times the CPU oracle (single thread) on the first n_frames frames of the same workload
+    (one flushed chunk).  Reported baseline only."""
+    import oracle_lib as ol
+    import synth
+    s = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
+    fl = synth.const_flow(W, H)
+    frames = [synth.bench_frame(W, H, k) for k in range(n_frames)]
+    t0 = time.perf_counter()
+    out = 0
+    for k in range(n_frames):
+        out += s.process_frame(frames[k], fl if k > 0 else None, flush=(k == n_frames - 1))
+    dt = time.perf_counter() - t0
+    s.close()
+    assert out == n_frames
+    return {
+        "value": n_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": "first %d frames of the same %dx%d workload (flow, chunk %d) as one flushed "
+                  "chunk, oracle/libvs_oracle.so, %.1f s" % (n_frames, W, H, chunk, dt),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    import synth
+    import video_segment_amd as vsg
+
+    W, H, chunk = args.width, args.height, args.chunk
+    K, Wm = args.steps, args.warmup
+    dev = torch.device("cuda", local_rank)
+
+    if args.mode == "chain" and world > 1:
+        from video_segment_amd.multi_gpu import run_chain_bench
+        result = run_chain_bench(args, rank, world, local_rank)
+    else:
+        # ---- independent stream per rank --------------------------------------------------
+        n_frames = chunk + (chunk - 1) * (Wm + K - 1) if (Wm + K) > 0 else 0
+        seed_shift = 1000 * rank
+        flow = torch.from_numpy(synth.const_flow(W, H)).to(dev)
+        frames = []
+        for k in range(n_frames):
+            f = synth.bench_frame(W, H, k + seed_shift) if rank else synth.bench_frame(W, H, k)
+            frames.append(torch.from_numpy(f).to(dev))
+        stream = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=local_rank),
+                                       has_flow=True)
+        torch.cuda.synchronize()
+
+        def barrier():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+
+        k = 0
+        steps_done = 0
+        # warm-up
+        while steps_done < Wm:
+            n = stream.process_frame(frames[k], flow if k > 0 else None)
+            k += 1
+            steps_done += 1 if n else 0
+        barrier()
+        t0 = time.perf_counter()
+        frames_out = 0
+        timed = 0
+        acc = {"wave_ms": 0.0, "wave_launches": 0, "wave_edges": 0, "merge_ms": 0.0,
+               "pre_ms": 0.0, "edges_ms": 0.0, "readout_ms": 0.0, "host_ms": 0.0,
+               "filter_ms": 0.0, "filter_launches": 0, "edges_total": 0, "merges": 0}
+        while timed < K:
+            n = stream.process_frame(frames[k], flow if k > 0 else None)
+            k += 1
+            if n:
+                timed += 1
+                frames_out += n
+                t = stream.last_timings()
+                acc["wave_ms"] += t.wave_kernel_ms
+                acc["wave_launches"] += t.wave_kernel_launches
+                acc["wave_edges"] += t.wave_kernel_edges
+                acc["filter_ms"] += t.filter_kernel_ms
+                acc["filter_launches"] += t.filter_kernel_launches
+                acc["merge_ms"] += t.merge_ms
+                acc["pre_ms"] += t.preprocess_ms
+                acc["edges_ms"] += t.edges_ms
+                acc["readout_ms"] += t.readout_ms
+                acc["host_ms"] += t.host_post_ms
+                acc["edges_total"] += t.edges_total
+                acc["merges"] += t.merges
+        barrier()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        fo = torch.tensor([frames_out], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(fo, op=dist.ReduceOp.SUM)
+        result = {"dt": float(tt.item()), "frames": float(fo.item()), "acc": acc,
+                  "parallelism": "1 independent 1080p stream per GPU x %d" % world}
+        stream.close()
+
+    if rank == 0:
+        dt, frames_total, acc = result["dt"], result["frames"], result["acc"]
+        fps = frames_total / dt
+        px = W * H
+        wave_launches = max(acc["wave_launches"], 1)
+        wave_avg_s = acc["wave_ms"] / 1e3 / wave_launches
+        wave_bytes_per_launch = WAVE_BYTES_PER_EDGE * acc["wave_edges"] / wave_launches
+        achieved = wave_bytes_per_launch / wave_avg_s / 1e9 if wave_avg_s > 0 else 0.0
+        out = {
+            "metric": "over-segmented frames/sec at 1080p",
+            "value": fps,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: %dx%d synthetic gradient + moving checker + "
+                            "+-3 noise video, precomputed constant backward flow (-2,0), "
+                            "spatial+temporal dense graph, chunk_size %d, DenseSegmentation "
+                            "stream API, inputs resident in HBM" % (W, H, chunk),
+                "frames_per_step": chunk - 1,
+                "parallelism": result["parallelism"],
+                "mode": args.mode,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "vsg::k_merge_wave (ordered per-component union-find replay)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "launches": acc["wave_launches"],
+                "avg_launch_ms": wave_avg_s * 1e3,
+                "bytes_per_launch": wave_bytes_per_launch,
+                "note": "dependency-bound serial replay: algorithmic bytes = %d B per replayed "
+                        "edge (DESIGN.md); whole path = %.1f B/px/frame -> %.2f GB/s end to end"
+                        % (WAVE_BYTES_PER_EDGE, BYTES_PER_PX_FRAME,
+                           fps / world * px * BYTES_PER_PX_FRAME / 1e9),
+            },
+            "stage_ms_per_step": {
+                "preprocess": acc["pre_ms"] / K, "edges_sort": acc["edges_ms"] / K,
+                "merge": acc["merge_ms"] / K, "merge_wave_kernel": acc["wave_ms"] / K,
+                "merge_filter_kernel": acc["filter_ms"] / K, "readout": acc["readout_ms"] / K,
+                "host_post": acc["host_ms"] / K,
+            },
+            "edges_per_step": acc["edges_total"] / K,
+            "merges_per_step": acc["merges"] / K,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, H, chunk, args.cpu_frames)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,13 @@ typedef struct vsg_timings {
   int64_t merges;          /* forced + regular + small merges                               */
   int64_t preprocess_launches;
   int64_t edge_launches;
+  /* Dominant kernel (k_merge_wave: per-component ordered replay), measured with HIP events on
+   * the handle's stream around every launch of the chunk. */
+  float wave_kernel_ms;        /* summed launch durations                                    */
+  int64_t wave_kernel_launches;
+  int64_t wave_kernel_edges;   /* active edges replayed by wavefront workers                 */
+  float filter_kernel_ms;      /* k_filter, summed                                           */
+  int64_t filter_kernel_launches;
 } vsg_timings;
 
 const char* vsg_last_error(void);

@@ -213,3 +213,16 @@ def test_device_resident_inputs(vsg):
         assert na == nb
         for i in range(na):
             assert a.result_bytes(i) == b.result_bytes(i)
+
+
+@pytest.mark.parametrize("W,H,N,kind,chunk", [(64, 48, 30, "noise", 8), (96, 64, 26, "smooth", 10),
+                                              (128, 96, 44, "bench", 20)])
+def test_optimistic_stage_rollback_is_exact(vsg, monkeypatch, W, H, N, kind, chunk):
+    """Constrained chunks settle 'kept' edges optimistically and roll a stage back when a marked
+    region changes its constraint.  Forcing the rollback of every optimistic stage, and disabling
+    the optimisation altogether, must give the same bytes as the oracle."""
+    monkeypatch.setenv("VSG_FORCE_ROLLBACK", "1")
+    run_streams(vsg, W, H, N, kind, True, chunk)
+    monkeypatch.delenv("VSG_FORCE_ROLLBACK")
+    monkeypatch.setenv("VSG_INERT_MODE", "0")
+    run_streams(vsg, W, H, N, kind, True, chunk)

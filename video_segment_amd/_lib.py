@@ -44,6 +44,11 @@ class VsgTimings(C.Structure):
         ("merges", C.c_int64),
         ("preprocess_launches", C.c_int64),
         ("edge_launches", C.c_int64),
+        ("wave_kernel_ms", C.c_float),
+        ("wave_kernel_launches", C.c_int64),
+        ("wave_kernel_edges", C.c_int64),
+        ("filter_kernel_ms", C.c_float),
+        ("filter_kernel_launches", C.c_int64),
     ]
 
 

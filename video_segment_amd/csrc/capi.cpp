@@ -411,6 +411,11 @@ int vsg_graph_timings(const vsg_graph* g, vsg_timings* t) {
     t->edges_total = gt.edges_total;
     t->edges_active = gt.edges_active;
     t->merges = gt.merges[0] + gt.merges[1] + gt.merges[2];
+    t->wave_kernel_ms = gt.wave_ms;
+    t->wave_kernel_launches = gt.wave_launches;
+    t->wave_kernel_edges = gt.wave_edges;
+    t->filter_kernel_ms = gt.filter_ms;
+    t->filter_kernel_launches = gt.filter_launches;
   });
 }
 

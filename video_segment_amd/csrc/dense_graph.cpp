@@ -56,14 +56,16 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   keys_sorted_tmp_.alloc(9 * wh_);
   vals_tmp_.alloc(9 * wh_);
   scalars_.alloc(16);
-  stats_.alloc(4);
+  stats_.alloc(16);
   size_t temp = SortPairsU16TempBytes((int)(9 * wh_));
   temp = std::max(temp, ScanTempBytes((int)N));
   cub_temp_.alloc(temp);
   Reset(max_frames);
 }
 
-DenseGraphHip::~DenseGraphHip() {}
+DenseGraphHip::~DenseGraphHip() {
+  for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
+}
 
 void DenseGraphHip::Reset(int max_frames) {
   VSG_REQUIRE(max_frames >= 1 && max_frames <= capacity_frames_, -1, "max_frames above capacity");
@@ -151,6 +153,10 @@ void DenseGraphHip::EnsureScratch(size_t n) {
   seg_key_.alloc(n);
   seg_cnt_.alloc(n);
   seg_off_.alloc(n);
+  e_ti_.alloc(n);
+  bk_ds_.alloc(2 * n);
+  bk_cons_.alloc(2 * n);
+  bk_flags_.alloc(2 * n);
   size_t temp = cub_temp_.size();
   temp = std::max(temp, SortPairsU32TempBytes((int)n));
   temp = std::max(temp, ScanTempBytes((int)n));
@@ -197,7 +203,7 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   LaunchBuildBucketTable(list_desc_dev_.get(), L, bucket_base_dev_.get(), stream_);
   bucket_base_host_.resize((size_t)(kNumBuckets + 1) * (L + 1));
   D2H(bucket_base_host_.data(), bucket_base_dev_.get(), bucket_base_host_.size(), stream_);
-  VSG_HIP(hipMemsetAsync(stats_.get(), 0, 4 * sizeof(unsigned long long), stream_));
+  VSG_HIP(hipMemsetAsync(stats_.get(), 0, 16 * sizeof(unsigned long long), stream_));
   LaunchInitIdentity(cc_.get(), N, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
 
@@ -227,10 +233,26 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   S.seg_off = seg_off_.get();
   S.num_active = scalars_.get();
   S.num_segs = scalars_.get() + 1;
+  S.e_ti = e_ti_.get();
+  S.bk_ds = bk_ds_.get();
+  S.bk_cons = bk_cons_.get();
+  S.bk_flags = bk_flags_.get();
+  S.force_rollback = getenv("VSG_FORCE_ROLLBACK") ? 1 : 0;
+  optimistic_stages_ = 0;
+  rollbacks_ = 0;
+  S.optimistic_stages = &optimistic_stages_;
+  S.rollbacks = &rollbacks_;
   S.cc = cc_.get();
   S.stats = stats_.get();
   S.cub_temp = cub_temp_.get();
   S.cub_temp_bytes = cub_temp_.size();
+  ev_used_ = 0;
+  ev_wave_.clear();
+  ev_filter_.clear();
+  S.ev_pool = &ev_pool_;
+  S.ev_wave = &ev_wave_;
+  S.ev_filter = &ev_filter_;
+  S.ev_used = &ev_used_;
 
   MergeParams P;
   P.W = W_;
@@ -240,22 +262,59 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   P.force_merge_weight = l1_ ? 0.002f : 0.001f;
   const float scale = 2048.0f / (1.0f + 1e-6f);
   P.inv_scale = (float)(1.0 / (double)scale);
+  // Largest float s whose correctly rounded sqrtf still satisfies the reference's comparison.
+  auto largest_s = [](double t, bool inclusive) {
+    auto ok = [&](float s) {
+      const double r = (double)std::sqrt(s);   // float sqrt, correctly rounded
+      return inclusive ? r <= t : r < t;
+    };
+    float s = (float)(t * t);
+    while (!ok(s)) s = std::nextafter(s, 0.0f);
+    while (ok(std::nextafter(s, 10.0f))) s = std::nextafter(s, 10.0f);
+    return s;
+  };
+  P.s_lt_005 = largest_s((double)0.05f, false);   // d < MergeDistanceThreshold (0.05f)
+  P.s_lt_02 = largest_s(0.2, false);              // dist < 0.2 (double literal)
+  P.s_le_015 = largest_s((double)0.15f, true);    // !(d > SplitDistanceThreshold (0.15f))
 
   const double t0 = NowMs();
-  const bool inert_enabled = !has_constraints_;
+  int inert_mode = has_constraints_ ? 2 : 1;
+  if (const char* e = getenv("VSG_INERT_MODE")) inert_mode = std::min(inert_mode, atoi(e));
   for (int b = 0; b < kNumBuckets; ++b) {
     const int n_b = bucket_base_host_[(size_t)b * (L + 1) + L];
     if (n_b == 0) continue;
     RunBucketStage(b, n_b, list_desc_dev_.get(), bucket_base_dev_.get(),
-                   list_slot_base_dev_.get(), kept_all_.get(), nodes(), P, inert_enabled, S,
+                   list_slot_base_dev_.get(), kept_all_.get(), nodes(), P, inert_mode, S,
                    stream_);
   }
+  timings_.optimistic_stages = optimistic_stages_;
+  timings_.rollbacks = rollbacks_;
   LaunchKeepVirtualBucket(list_desc_dev_.get(), L, stream_);
   if (force_constraints && has_constraints_) MergeConstrainedHostAssisted();
-  unsigned long long st[4] = {0, 0, 0, 0};
-  D2H(st, stats_.get(), 4, stream_);
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  D2H(st, stats_.get(), 8, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
+  if (getenv("VSG_DEBUG_STATS")) {
+    std::fprintf(stderr, "[vsg] wave: edges %llu batches %llu iters %llu hot-hits %llu internal %llu; "
+                 "optimistic stages %lld rollbacks %lld\n",
+                 st[3], st[7], st[4], st[5], st[6], (long long)optimistic_stages_,
+                 (long long)rollbacks_);
+  }
   timings_.merge_ms = (float)(NowMs() - t0);
+  for (auto& pr : ev_wave_) {
+    float ms = 0;
+    VSG_HIP(hipEventElapsedTime(&ms, ev_pool_[pr.first], ev_pool_[pr.second]));
+    timings_.wave_ms += ms;
+  }
+  for (auto& pr : ev_filter_) {
+    float ms = 0;
+    VSG_HIP(hipEventElapsedTime(&ms, ev_pool_[pr.first], ev_pool_[pr.second]));
+    timings_.filter_ms += ms;
+  }
+  timings_.wave_launches += (int64_t)ev_wave_.size();
+  timings_.filter_launches += (int64_t)ev_filter_.size();
+  timings_.wave_edges += (int64_t)st[3];
+  timings_.edges_active += (int64_t)st[3];
   timings_.edges_total = edges_total;
   timings_.merges[0] += (int64_t)st[0];
   timings_.merges[1] += (int64_t)st[1];

@@ -17,6 +17,9 @@ struct GraphTimings {
   float edges_ms = 0, sort_ms = 0, merge_ms = 0, readout_ms = 0, host_post_ms = 0;
   int64_t edges_total = 0, edges_active = 0;
   int64_t merges[3] = {0, 0, 0};   // forced, regular, small
+  float wave_ms = 0, filter_ms = 0;
+  int64_t wave_launches = 0, filter_launches = 0, wave_edges = 0;
+  int64_t optimistic_stages = 0, rollbacks = 0;
 };
 
 class DenseGraphHip {
@@ -109,6 +112,10 @@ class DenseGraphHip {
   // merge scratch
   DevBuf<int32_t> e_ra_, e_rb_, e_active_, e_apos_, a_ra_, a_rb_, seg_cnt_, seg_off_;
   DevBuf<uint32_t> e_gpos_, a_gpos_, a_comp_, a_idx_, s_comp_, s_idx_, seg_key_;
+  DevBuf<uint8_t> e_ti_, bk_flags_;
+  DevBuf<float4> bk_ds_;
+  DevBuf<int32_t> bk_cons_;
+  int64_t optimistic_stages_ = 0, rollbacks_ = 0;
   DevBuf<int32_t> scalars_;   // num_active, num_segs, misc
   DevBuf<unsigned long long> stats_;
   DevBuf<uint8_t> cub_temp_;
@@ -121,6 +128,9 @@ class DenseGraphHip {
   DevBuf<int32_t> small_i32_a_, small_i32_b_, small_i32_c_;
   DevBuf<float4> small_f4_;
   std::vector<int32_t> label_uf_host_;
+  std::vector<hipEvent_t> ev_pool_;
+  std::vector<std::pair<int, int>> ev_wave_, ev_filter_;
+  int ev_used_ = 0;
 
   std::vector<RegionInfo> regions_;
   std::unordered_map<int, int> key_to_region_;   // representative key -> index into regions_

@@ -22,6 +22,7 @@ namespace vsg {
 
 constexpr uint8_t kFlagFinalized = 1;
 constexpr uint8_t kFlagNoDesc = 2;
+constexpr uint8_t kFlagTentative = 4;   // region has tentatively settled edges in this stage
 
 struct NodeArrays {
   int32_t* parent;
@@ -48,6 +49,9 @@ struct MergeParams {
   int min_region_size;
   float force_merge_weight;   // 0.001 (L2) / 0.002 (L1), dense_segmentation.cpp:259-264
   float inv_scale;            // (float)(1.0 / scale_), segmentation_graph.h:348
+  // Squared-distance thresholds (see merge_kernels.hip): largest float s with
+  // sqrtf(s) < 0.05f, (double)sqrtf(s) < 0.2 and sqrtf(s) <= 0.15f respectively.
+  float s_lt_005, s_lt_02, s_le_015;
 };
 
 // ---- build_kernels.hip ----------------------------------------------------------------
@@ -111,12 +115,25 @@ struct MergeScratch {
   uint32_t* seg_key;     // run-length encoding of s_comp
   int32_t* seg_cnt;
   int32_t* seg_off;
-  int32_t* num_active;   // device scalar
-  int32_t* num_segs;     // device scalar
+  int32_t* num_active;   // device scalars: [0] num_active [1] num_segs [2] num_ti [3] violation
+  int32_t* num_segs;     // = num_active + 1
+  uint8_t* e_ti;         // per bucket edge: tentatively settled by the filter
+  float4* bk_ds;         // undo buffers of an optimistic stage (2 entries per active edge)
+  int32_t* bk_cons;
+  uint8_t* bk_flags;
+  int force_rollback;    // test hook: treat every optimistic stage as violated
+  int64_t* optimistic_stages;
+  int64_t* rollbacks;
   int32_t* cc;           // [N] component scratch (identity outside a stage)
-  unsigned long long* stats;   // [4] forced, regular, small, active-edge total
+  unsigned long long* stats;   // [16]: forced, regular, small, wave edges, debug x4; [8..15] undo copy
   void* cub_temp;
   size_t cub_temp_bytes;
+  // HIP event pairs recorded around k_filter / k_merge_wave launches (resolved by the caller
+  // after the stream has been synchronised).
+  std::vector<hipEvent_t>* ev_pool;
+  std::vector<std::pair<int, int>>* ev_wave;     // indices into ev_pool
+  std::vector<std::pair<int, int>>* ev_filter;
+  int* ev_used;
 };
 
 // bucket_base[b * (L+1) + l] = number of bucket-b edges in lists < l; [.. + L] = total.
@@ -126,7 +143,7 @@ void LaunchInitIdentity(int32_t* a, size_t n, hipStream_t s);
 // Runs one bucket stage (filter -> components -> exact workers).  n_b = edges in the bucket.
 void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* bucket_base,
                     const uint32_t* list_slot_base, uint8_t* kept_all, NodeArrays nodes,
-                    const MergeParams& P, bool inert_enabled, MergeScratch& S, hipStream_t s);
+                    const MergeParams& P, int inert_mode, MergeScratch& S, hipStream_t s);
 // Marks every edge of bucket 2048 (virtual edges) as kept.
 void LaunchKeepVirtualBucket(const ListDesc* lists, int num_lists, hipStream_t s);
 

@@ -148,51 +148,145 @@ void LaunchInitIdentity(int32_t* a, size_t n, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // Stage step 1: filter.
 // ------------------------------------------------------------------------------------------
+// inert_mode 0: every non-internal edge is active.
+// inert_mode 1 (graph without constraints): an edge between two finalized regions of at least
+//   min size is kept and changes no state whenever it is visited -- exact, because such a region
+//   stays finalized and large and there is no constraint that could force a merge.
+// inert_mode 2 (graph with constraints): the same edges, and edges between regions with different
+//   constraints, are *tentatively* settled as kept.  That is only valid while the constraint of
+//   the regions involved does not change during this stage, so both regions are marked
+//   (kFlagTentative in the region flags, which travel with the state into the workers); a worker
+//   that changes the constraint of a marked region raises the stage's violation flag and the host
+//   rolls the stage back and replays it with inert_mode 0 (see RunBucketStage).
 __global__ __launch_bounds__(256) void k_filter(int bucket, int n_b,
                                                  const ListDesc* __restrict__ lists,
                                                  const int32_t* __restrict__ base_row,
                                                  const uint32_t* __restrict__ list_slot_base,
                                                  uint8_t* __restrict__ kept_all, NodeArrays nodes,
-                                                 MergeParams P, int inert_enabled,
+                                                 MergeParams P, int inert_mode,
                                                  int32_t* __restrict__ cc,
                                                  int32_t* __restrict__ e_ra,
                                                  int32_t* __restrict__ e_rb,
                                                  uint32_t* __restrict__ e_gpos,
-                                                 int32_t* __restrict__ e_active) {
+                                                 int32_t* __restrict__ e_active,
+                                                 uint8_t* __restrict__ e_ti,
+                                                 int32_t* __restrict__ num_ti) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_b) return;
-  const int l = LocateList(base_row, P.num_lists, j);
-  const ListDesc L = lists[l];
-  const int pos = L.offsets[bucket] + (j - base_row[l]);
-  int a, b;
-  DecodeEdge(L, L.slots[pos], P.W, a, b);
-  const int ra = FindCompress(nodes.parent, a);
-  const int rb = FindCompress(nodes.parent, b);
-  const uint32_t gpos = list_slot_base[l] + (uint32_t)pos;
-  int active = 0;
-  if (ra != rb) {
-    bool inert = false;
-    if (inert_enabled) {
-      // Both regions finalized and >= min size in a graph without constraints: the edge is kept
-      // and changes no state, whenever it is visited (such a region stays finalized and large).
-      const int f1 = nodes.flags[ra], f2 = nodes.flags[rb];
-      if ((f1 & kFlagFinalized) && (f2 & kFlagFinalized)) {
-        const int s1 = __float_as_int(nodes.desc_sz[ra].w);
-        const int s2 = __float_as_int(nodes.desc_sz[rb].w);
-        inert = (s1 >= P.min_region_size) && (s2 >= P.min_region_size);
+  int ti = 0;
+  if (j < n_b) {
+    const int l = LocateList(base_row, P.num_lists, j);
+    const ListDesc L = lists[l];
+    const int pos = L.offsets[bucket] + (j - base_row[l]);
+    int a, b;
+    DecodeEdge(L, L.slots[pos], P.W, a, b);
+    const int ra = FindCompress(nodes.parent, a);
+    const int rb = FindCompress(nodes.parent, b);
+    const uint32_t gpos = list_slot_base[l] + (uint32_t)pos;
+    int active = 0;
+    if (ra != rb) {
+      bool inert = false;
+      if (inert_mode != 0) {
+        const int f1 = nodes.flags[ra], f2 = nodes.flags[rb];
+        bool both_final_large = false;
+        if ((f1 & kFlagFinalized) && (f2 & kFlagFinalized)) {
+          const int s1 = __float_as_int(nodes.desc_sz[ra].w);
+          const int s2 = __float_as_int(nodes.desc_sz[rb].w);
+          both_final_large = (s1 >= P.min_region_size) && (s2 >= P.min_region_size);
+        }
+        if (inert_mode == 1) {
+          inert = both_final_large;
+        } else {
+          const int c1 = nodes.cons[ra], c2 = nodes.cons[rb];
+          if (c1 >= 0 && c2 >= 0) {
+            inert = (c1 != c2);            // different constraints: never merged
+          } else {
+            inert = both_final_large;      // at least one unconstrained
+          }
+          if (inert) {
+            ti = 1;
+            if (!(f1 & kFlagTentative)) nodes.flags[ra] = (uint8_t)(f1 | kFlagTentative);
+            if (!(f2 & kFlagTentative)) nodes.flags[rb] = (uint8_t)(f2 | kFlagTentative);
+          }
+        }
+      }
+      if (inert) {
+        kept_all[gpos] = 1;
+      } else {
+        active = 1;
+        CcUnion(cc, ra, rb);
       }
     }
-    if (inert) {
-      kept_all[gpos] = 1;
-    } else {
-      active = 1;
-      CcUnion(cc, ra, rb);
+    e_ra[j] = ra;
+    e_rb[j] = rb;
+    e_gpos[j] = gpos;
+    e_active[j] = active;
+    e_ti[j] = (uint8_t)ti;
+  }
+  const unsigned long long m = __ballot(ti != 0);
+  if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(num_ti, (int)__popcll(m));
+}
+
+// Clears the tentative marks of a stage: on the regions marked by the filter and on whatever
+// region they have been merged into since.
+__global__ __launch_bounds__(256) void k_clear_tentative(int n_b, const uint8_t* __restrict__ e_ti,
+                                                          const int32_t* __restrict__ e_ra,
+                                                          const int32_t* __restrict__ e_rb,
+                                                          NodeArrays nodes) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_b || !e_ti[j]) return;
+  int r[2] = {e_ra[j], e_rb[j]};
+  for (int k = 0; k < 2; ++k) {
+    int x = r[k];
+    for (;;) {
+      const int f = nodes.flags[x];
+      if (f & kFlagTentative) nodes.flags[x] = (uint8_t)(f & ~kFlagTentative);
+      const int p = nodes.parent[x];
+      if (p == x) break;
+      x = p;
     }
   }
-  e_ra[j] = ra;
-  e_rb[j] = rb;
-  e_gpos[j] = gpos;
-  e_active[j] = active;
+}
+
+// Undo support for an optimistic stage: region states of every active edge's two regions.
+__global__ __launch_bounds__(256) void k_backup_roots(int n, const int32_t* __restrict__ a_ra,
+                                                       const int32_t* __restrict__ a_rb,
+                                                       NodeArrays nodes, float4* __restrict__ bk_ds,
+                                                       int32_t* __restrict__ bk_cons,
+                                                       uint8_t* __restrict__ bk_flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ra = a_ra[i], rb = a_rb[i];
+  bk_ds[2 * i] = nodes.desc_sz[ra];
+  bk_cons[2 * i] = nodes.cons[ra];
+  bk_flags[2 * i] = nodes.flags[ra];
+  bk_ds[2 * i + 1] = nodes.desc_sz[rb];
+  bk_cons[2 * i + 1] = nodes.cons[rb];
+  bk_flags[2 * i + 1] = nodes.flags[rb];
+}
+
+__global__ __launch_bounds__(256) void k_restore_roots(int n, const int32_t* __restrict__ a_ra,
+                                                        const int32_t* __restrict__ a_rb,
+                                                        NodeArrays nodes,
+                                                        const float4* __restrict__ bk_ds,
+                                                        const int32_t* __restrict__ bk_cons,
+                                                        const uint8_t* __restrict__ bk_flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ra = a_ra[i], rb = a_rb[i];
+  nodes.parent[ra] = ra;
+  nodes.desc_sz[ra] = bk_ds[2 * i];
+  nodes.cons[ra] = bk_cons[2 * i];
+  nodes.flags[ra] = bk_flags[2 * i];
+  nodes.parent[rb] = rb;
+  nodes.desc_sz[rb] = bk_ds[2 * i + 1];
+  nodes.cons[rb] = bk_cons[2 * i + 1];
+  nodes.flags[rb] = bk_flags[2 * i + 1];
+}
+
+__global__ __launch_bounds__(256) void k_clear_kept(int n_b, const uint32_t* __restrict__ e_gpos,
+                                                     uint8_t* __restrict__ kept_all) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n_b) kept_all[e_gpos[j]] = 0;
 }
 
 __global__ __launch_bounds__(256) void k_compact_active(int n_b, const int32_t* __restrict__ e_active,
@@ -248,13 +342,17 @@ struct RState {
 enum : int { kOutSkip = 0, kOutKeep = 1, kOutMerge1 = 2, kOutMerge2 = 3 };
 // kOutMerge1: region 1 survives (s1 holds the merged state); kOutMerge2: region 2 survives.
 
-// pixel_distance.h:479-493
-__device__ __forceinline__ float DescriptorDistance(const RState& a, const RState& b, float w,
-                                                    float force_w) {
+// ColorMeanDescriptorTraits::DescriptorDistance (pixel_distance.h:479-493) is
+//   dist = sqrt((dx^2+dy^2+dz^2) * (1/3));  return (w < force_w && dist < 0.2) ? 0 : dist
+// and is only ever compared with a threshold.  sqrtf is correctly rounded and monotone, so every
+// comparison is rewritten on s = (dx^2+dy^2+dz^2) * (1/3) against a float threshold that the host
+// derives with the same correctly rounded sqrtf (dense_graph.cpp: SquaredThresholds):
+//   regular merge test  d < 0.05f   <=>  s <= pass_s
+//   constrained split   d > 0.15f   <=>  s >  split_s
+// (with the force-merge rule of the stage's edge weight folded in).
+__device__ __forceinline__ float SquaredDistance(const RState& a, const RState& b) {
   const float x = a.d0 - b.d0, y = a.d1 - b.d1, z = a.d2 - b.d2;
-  const float dist = sqrtf((x * x + y * y + z * z) * (1.0f / 3.0f));
-  if (w < force_w && (double)dist < 0.2) return 0.0f;
-  return dist;
+  return (x * x + y * y + z * z) * (1.0f / 3.0f);
 }
 
 // MergeRegions (segmentation_graph.h:671-701) + MergeDescriptor (pixel_distance.h:495-505).
@@ -273,18 +371,23 @@ __device__ __forceinline__ int MergeStates(RState& s1, RState& s2) {
   }
   m.sz += o.sz;
   m.cons = max(s1.cons, s2.cons);
+  m.flags |= (o.flags & kFlagTentative);   // tentatively settled edges of `o` now hang on `m`
   return first_wins ? kOutMerge1 : kOutMerge2;
 }
 
 // One edge of SegmentGraph (segmentation_graph.h:374-440).  s1/s2 are updated in place (flags,
 // constraints, merged state).  stat: 0 none, 1 forced, 2 regular, 3 small.
-__device__ __forceinline__ int DecideEdge(RState& s1, RState& s2, float weight,
-                                          const MergeParams& P, int& stat) {
+struct StageThr {
+  float pass_s;    // regular test passes  <=> s <= pass_s
+  float split_s;   // constrained split    <=> s >  split_s
+  int min_size;
+};
+
+__device__ __forceinline__ int DecideEdge(RState& s1, RState& s2, const StageThr& T, int& stat) {
   stat = 0;
   if (s1.cons < 0 || s2.cons < 0) {
-    if (!(s1.flags & kFlagFinalized) && !(s2.flags & kFlagFinalized)) {
-      const float d = DescriptorDistance(s1, s2, weight, P.force_merge_weight);
-      if (d < 0.05f) {                       // MergeDistanceThreshold
+    if (!((s1.flags | s2.flags) & kFlagFinalized)) {
+      if (SquaredDistance(s1, s2) <= T.pass_s) {   // d < MergeDistanceThreshold
         stat = 2;
         return MergeStates(s1, s2);
       }
@@ -292,14 +395,13 @@ __device__ __forceinline__ int DecideEdge(RState& s1, RState& s2, float weight,
       s2.flags |= kFlagFinalized;
     }
     // at least one finalized here
-    if (s1.sz < P.min_region_size || s2.sz < P.min_region_size) {
+    if (s1.sz < T.min_size || s2.sz < T.min_size) {
       stat = 3;
       return MergeStates(s1, s2);
     }
     return kOutKeep;
   } else if (s1.cons == s2.cons) {
-    const float d = DescriptorDistance(s1, s2, weight, P.force_merge_weight);
-    if (d > 0.15f) {                         // SplitDistanceThreshold
+    if (SquaredDistance(s1, s2) > T.split_s) {     // d > SplitDistanceThreshold
       if ((double)s1.sz < (double)s2.sz * 0.3) {
         s1.cons = -1;
       } else if ((double)s2.sz < (double)s1.sz * 0.3) {
@@ -314,6 +416,15 @@ __device__ __forceinline__ int DecideEdge(RState& s1, RState& s2, float weight,
     return MergeStates(s1, s2);
   }
   return kOutKeep;
+}
+
+// A tentatively settled edge stays settled only while the constraints of its two regions do not
+// change.  o1/o2: states before the edge, n1/n2: states that replace them (for a merge both are
+// the survivor's state).
+__device__ __forceinline__ bool TentativeViolated(const RState& o1, const RState& o2,
+                                                  const RState& n1, const RState& n2) {
+  return ((o1.flags & kFlagTentative) && n1.cons != o1.cons) ||
+         ((o2.flags & kFlagTentative) && n2.cons != o2.cons);
 }
 
 __device__ __forceinline__ RState LoadState(const NodeArrays& nodes, int r) {
@@ -347,7 +458,8 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
                                                       const int32_t* __restrict__ a_rb,
                                                       const uint32_t* __restrict__ a_gpos,
                                                       NodeArrays nodes, uint8_t* __restrict__ kept_all,
-                                                      MergeParams P, float weight,
+                                                      StageThr T, int optimistic,
+                                                      int32_t* __restrict__ violation,
                                                       unsigned long long* __restrict__ stats) {
   const int seg = blockIdx.x * 256 + threadIdx.x;
   unsigned n_forced = 0, n_regular = 0, n_small = 0;
@@ -357,13 +469,24 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
       const int beg = seg_off[seg];
       for (int p = beg; p < beg + cnt; ++p) {
         const uint32_t i = s_idx[p];
-        const int r1 = FindCompress(nodes.parent, a_ra[i]);
-        const int r2 = FindCompress(nodes.parent, a_rb[i]);
+        // An optimistic stage must stay undoable from the backed-up region states alone, so it
+        // does not compress paths.
+        const int r1 = optimistic ? FindReadOnly(nodes.parent, a_ra[i])
+                                  : FindCompress(nodes.parent, a_ra[i]);
+        const int r2 = optimistic ? FindReadOnly(nodes.parent, a_rb[i])
+                                  : FindCompress(nodes.parent, a_rb[i]);
         if (r1 == r2) continue;
         RState s1 = LoadState(nodes, r1);
         RState s2 = LoadState(nodes, r2);
+        const RState o1 = s1, o2 = s2;
         int stat;
-        const int out = DecideEdge(s1, s2, weight, P, stat);
+        const int out = DecideEdge(s1, s2, T, stat);
+        if (optimistic) {
+          const bool v = (out == kOutKeep)     ? TentativeViolated(o1, o2, s1, s2)
+                         : (out == kOutMerge1) ? TentativeViolated(o1, o2, s1, s1)
+                                               : TentativeViolated(o1, o2, s2, s2);
+          if (v) *violation = 1;
+        }
         n_forced += (stat == 1);
         n_regular += (stat == 2);
         n_small += (stat == 3);
@@ -412,6 +535,16 @@ __device__ __forceinline__ RState ReadLaneState(const RState& s, int lane) {
   return r;
 }
 
+__device__ __forceinline__ bool SameState(const RState& a, const RState& b) {
+  return a.sz == b.sz && a.cons == b.cons && a.flags == b.flags;   // descriptor only changes with sz
+}
+
+// The common pattern inside a large component is a chain: one big region absorbs neighbour after
+// neighbour.  The winner of the last merge is therefore kept as the "hot" region: its state lives
+// in (wave-uniform) registers, is used instead of any lane's cached copy, and is written back
+// only when another region becomes hot or the component is finished.  Lane copies of a region are
+// refreshed (12 v_cndmask) only when it stops being hot or on the rare flag/constraint change, so
+// a chain step costs two id readlanes, six state readlanes, the decision and one parent store.
 __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ num_segs,
                                                     const int32_t* __restrict__ seg_off,
                                                     const int32_t* __restrict__ seg_cnt,
@@ -420,16 +553,21 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
                                                     const int32_t* __restrict__ a_rb,
                                                     const uint32_t* __restrict__ a_gpos,
                                                     NodeArrays nodes, uint8_t* __restrict__ kept_all,
-                                                    MergeParams P, float weight,
+                                                    StageThr T, int optimistic,
+                                                    int32_t* __restrict__ violation,
                                                     unsigned long long* __restrict__ stats) {
   const int lane = threadIdx.x;
   const int nseg = *num_segs;
-  unsigned n_forced = 0, n_regular = 0, n_small = 0;   // counted by the committing lane
+  unsigned n_forced = 0, n_regular = 0, n_small = 0;   // counted on lane 0 (uniform decisions)
+  unsigned dbg_iters = 0, dbg_hot = 0, dbg_internal = 0, dbg_batches = 0;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int cnt = seg_cnt[seg];
     if (cnt <= kSmallSegment) continue;
     const int beg = seg_off[seg];
     const int end = beg + cnt;
+    if (lane == 0) atomicAdd(&stats[3], (unsigned long long)cnt);
+    int hot = -1;          // wave-uniform
+    RState H = {};         // wave-uniform state of region `hot` (authoritative while hot >= 0)
     for (int base = beg; base < end; base += 64) {
       const int p = base + lane;
       const bool valid = p < end;
@@ -438,8 +576,8 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
       RState A = {}, B = {};
       if (valid) {
         const uint32_t i = s_idx[p];
-        ra = FindCompress(nodes.parent, a_ra[i]);
-        rb = FindCompress(nodes.parent, a_rb[i]);
+        ra = optimistic ? FindReadOnly(nodes.parent, a_ra[i]) : FindCompress(nodes.parent, a_ra[i]);
+        rb = optimistic ? FindReadOnly(nodes.parent, a_rb[i]) : FindCompress(nodes.parent, a_rb[i]);
         gpos = a_gpos[i];
         if (ra != rb) {
           A = LoadState(nodes, ra);
@@ -448,62 +586,80 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
       }
       bool my_kept = false;
       unsigned long long pending = __ballot(valid && ra != rb);
+      if (lane == 0) ++dbg_batches;
       while (pending) {
         const int j = __builtin_ctzll(pending);
         pending &= pending - 1;
         const int r1 = ReadLaneI(ra, j);
         const int r2 = ReadLaneI(rb, j);
-        if (r1 == r2) continue;   // became internal through an earlier merge of this batch
-        RState s1 = ReadLaneState(A, j);
-        RState s2 = ReadLaneState(B, j);
+        if (r1 == r2) { if (lane == 0) ++dbg_internal; continue; }   // became internal
+        if (lane == 0) { ++dbg_iters; dbg_hot += (r1 == hot || r2 == hot); }
+        RState s1, s2;
+        if (r1 == hot) s1 = H; else s1 = ReadLaneState(A, j);
+        if (r2 == hot) s2 = H; else s2 = ReadLaneState(B, j);
+        const RState o1 = s1, o2 = s2;
         int stat;
-        const int out = DecideEdge(s1, s2, weight, P, stat);
-        if (lane == j) {
-          n_forced += (stat == 1);
-          n_regular += (stat == 2);
-          n_small += (stat == 3);
+        const int out = DecideEdge(s1, s2, T, stat);
+        if (optimistic) {
+          const bool v = (out == kOutKeep)     ? TentativeViolated(o1, o2, s1, s2)
+                         : (out == kOutMerge1) ? TentativeViolated(o1, o2, s1, s1)
+                                               : TentativeViolated(o1, o2, s2, s2);
+          if (v && lane == 0) *violation = 1;
         }
+        n_forced += (stat == 1);
+        n_regular += (stat == 2);
+        n_small += (stat == 3);
         if (out == kOutKeep) {
-          if (lane == j) {
-            my_kept = true;
-            StoreState(nodes, r1, s1);
-            StoreState(nodes, r2, s2);
+          if (lane == j) my_kept = true;
+          // rare: finalisation or constraint reset changed one or both regions
+          if (!SameState(o1, s1)) {
+            if (r1 == hot) H = s1;
+            if (ra == r1) A = s1;
+            if (rb == r1) B = s1;
+            if (lane == j) StoreState(nodes, r1, s1);
           }
-          // flags / constraints may have changed: refresh every cached copy.
-          if (ra == r1) A = s1; else if (ra == r2) A = s2;
-          if (rb == r1) B = s1; else if (rb == r2) B = s2;
+          if (!SameState(o2, s2)) {
+            if (r2 == hot) H = s2;
+            if (ra == r2) A = s2;
+            if (rb == r2) B = s2;
+            if (lane == j) StoreState(nodes, r2, s2);
+          }
         } else {
           const int win = (out == kOutMerge1) ? r1 : r2;
           const int lose = (out == kOutMerge1) ? r2 : r1;
           const RState sw = (out == kOutMerge1) ? s1 : s2;
-          if (lane == j) {
-            StoreState(nodes, win, sw);
-            nodes.parent[lose] = win;
+          if (win != hot) {
+            if (hot >= 0 && hot != lose) {
+              // the previous hot region leaves the registers: refresh lane copies + memory
+              if (ra == hot) A = H;
+              if (rb == hot) B = H;
+              if (lane == 0) StoreState(nodes, hot, H);
+            }
+            hot = win;
           }
-          if (ra == win || ra == lose) {
-            ra = win;
-            A = sw;
-          }
-          if (rb == win || rb == lose) {
-            rb = win;
-            B = sw;
-          }
+          H = sw;
+          if (lane == j) nodes.parent[lose] = win;
+          if (ra == lose) ra = win;
+          if (rb == lose) rb = win;
         }
       }
       if (valid && my_kept) kept_all[gpos] = 1;
       // Make this batch's stores visible to the next batch's loads (same CU: L1 is shared).
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      // Next batch reloads region states from memory; the hot region's memory copy is stale, so
+      // write it back here once per batch (one 21-byte store) instead of once per merge.
+      if (hot >= 0 && lane == 0) StoreState(nodes, hot, H);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    n_forced += __shfl_down(n_forced, off);
-    n_regular += __shfl_down(n_regular, off);
-    n_small += __shfl_down(n_small, off);
   }
   if (lane == 0) {
     if (n_forced) atomicAdd(&stats[0], (unsigned long long)n_forced);
     if (n_regular) atomicAdd(&stats[1], (unsigned long long)n_regular);
     if (n_small) atomicAdd(&stats[2], (unsigned long long)n_small);
+    atomicAdd(&stats[4], (unsigned long long)dbg_iters);
+    atomicAdd(&stats[5], (unsigned long long)dbg_hot);
+    atomicAdd(&stats[6], (unsigned long long)dbg_internal);
+    atomicAdd(&stats[7], (unsigned long long)dbg_batches);
   }
 }
 
@@ -512,22 +668,53 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
 // ------------------------------------------------------------------------------------------
 static inline unsigned Blocks(int n) { return (unsigned)((n + 255) / 256); }
 
+static int NextEvent(MergeScratch& S) {
+  if (!S.ev_pool) return -1;
+  if (*S.ev_used >= (int)S.ev_pool->size()) {
+    hipEvent_t e;
+    VSG_HIP(hipEventCreate(&e));
+    S.ev_pool->push_back(e);
+  }
+  return (*S.ev_used)++;
+}
+
 void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* bucket_base,
                     const uint32_t* list_slot_base, uint8_t* kept_all, NodeArrays nodes,
-                    const MergeParams& P, bool inert_enabled, MergeScratch& S, hipStream_t s) {
+                    const MergeParams& P, int inert_mode, MergeScratch& S, hipStream_t s) {
   if (n_b <= 0) return;
   const int32_t* base_row = bucket_base + (size_t)bucket * (P.num_lists + 1);
+  int32_t* d_num_ti = S.num_active + 2;
+  int32_t* d_violation = S.num_active + 3;
+  VSG_HIP(hipMemsetAsync(d_num_ti, 0, 2 * sizeof(int32_t), s));
+  const int ef0 = NextEvent(S);
+  if (ef0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ef0], s));
   hipLaunchKernelGGL(k_filter, dim3(Blocks(n_b)), dim3(256), 0, s, bucket, n_b, lists, base_row,
-                     list_slot_base, kept_all, nodes, P, inert_enabled ? 1 : 0, S.cc, S.e_ra,
-                     S.e_rb, S.e_gpos, S.e_active);
+                     list_slot_base, kept_all, nodes, P, inert_mode, S.cc, S.e_ra, S.e_rb, S.e_gpos,
+                     S.e_active, S.e_ti, d_num_ti);
+  const int ef1 = NextEvent(S);
+  if (ef1 >= 0) {
+    VSG_HIP(hipEventRecord((*S.ev_pool)[ef1], s));
+    S.ev_filter->emplace_back(ef0, ef1);
+  }
   ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, S.e_active, S.e_apos, n_b, s);
   hipLaunchKernelGGL(k_compact_active, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_active,
                      S.e_apos, S.e_ra, S.e_rb, S.e_gpos, S.a_ra, S.a_rb, S.a_gpos, S.num_active);
   VSG_HIP(hipGetLastError());
-  int n_active = 0;
-  VSG_HIP(hipMemcpyAsync(&n_active, S.num_active, sizeof(int), hipMemcpyDeviceToHost, s));
+  int h[4] = {0, 0, 0, 0};   // num_active, num_segs (unused), num_ti, violation
+  VSG_HIP(hipMemcpyAsync(h, S.num_active, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   VSG_HIP(hipStreamSynchronize(s));
-  if (n_active == 0) return;
+  const int n_active = h[0];
+  const int n_ti = h[2];
+  auto clear_marks = [&]() {
+    if (n_ti > 0) {
+      hipLaunchKernelGGL(k_clear_tentative, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_ti, S.e_ra,
+                         S.e_rb, nodes);
+    }
+  };
+  if (n_active == 0) {
+    clear_marks();
+    return;
+  }
 
   hipLaunchKernelGGL(k_component_ids, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra,
                      S.cc, S.a_comp, S.a_idx);
@@ -536,24 +723,63 @@ void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* b
   RunLengthEncodeU32(S.cub_temp, S.cub_temp_bytes, S.s_comp, S.seg_key, S.seg_cnt, S.num_segs,
                      n_active, s);
   // Segment offsets: exclusive scan over n_active counts (only the first num_segs are defined;
-  // the rest is zeroed so the scan stays well defined).
+  // the prefix of an exclusive scan never depends on later elements).
   ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, S.seg_cnt, S.seg_off, n_active, s);
 
+  const bool optimistic = (inert_mode == 2) && n_ti > 0;
+  if (optimistic) {
+    hipLaunchKernelGGL(k_backup_roots, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra,
+                       S.a_rb, nodes, S.bk_ds, S.bk_cons, S.bk_flags);
+    VSG_HIP(hipMemcpyAsync(S.stats + 8, S.stats, 8 * sizeof(unsigned long long),
+                           hipMemcpyDeviceToDevice, s));
+  }
+
   const float weight = (float)bucket * P.inv_scale;
+  const bool force = weight < P.force_merge_weight;
+  StageThr T;
+  T.pass_s = force ? P.s_lt_02 : P.s_lt_005;
+  T.split_s = force ? P.s_lt_02 : P.s_le_015;
+  T.min_size = P.min_region_size;
   hipLaunchKernelGGL(k_merge_small, dim3(Blocks(n_active)), dim3(256), 0, s, S.num_segs, S.seg_off,
-                     S.seg_cnt, S.s_idx, S.a_ra, S.a_rb, S.a_gpos, nodes, kept_all, P, weight,
-                     S.stats);
+                     S.seg_cnt, S.s_idx, S.a_ra, S.a_rb, S.a_gpos, nodes, kept_all, T,
+                     optimistic ? 1 : 0, d_violation, S.stats);
   const int wave_grid = n_active / (kSmallSegment + 1) < 1 ? 1
                         : (n_active / (kSmallSegment + 1) > 8192 ? 8192
                                                                  : n_active / (kSmallSegment + 1));
+  const int ew0 = NextEvent(S);
+  if (ew0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ew0], s));
   hipLaunchKernelGGL(k_merge_wave, dim3(wave_grid), dim3(64), 0, s, S.num_segs, S.seg_off,
-                     S.seg_cnt, S.s_idx, S.a_ra, S.a_rb, S.a_gpos, nodes, kept_all, P, weight,
-                     S.stats);
+                     S.seg_cnt, S.s_idx, S.a_ra, S.a_rb, S.a_gpos, nodes, kept_all, T,
+                     optimistic ? 1 : 0, d_violation, S.stats);
+  const int ew1 = NextEvent(S);
+  if (ew1 >= 0) {
+    VSG_HIP(hipEventRecord((*S.ev_pool)[ew1], s));
+    S.ev_wave->emplace_back(ew0, ew1);
+  }
   hipLaunchKernelGGL(k_reset_cc, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra, S.a_rb,
                      S.cc);
   VSG_HIP(hipGetLastError());
-  unsigned long long add = (unsigned long long)n_active;
-  (void)add;
+  if (optimistic) {
+    int violated = 0;
+    VSG_HIP(hipMemcpyAsync(&violated, d_violation, sizeof(int), hipMemcpyDeviceToHost, s));
+    VSG_HIP(hipStreamSynchronize(s));
+    ++*S.optimistic_stages;
+    if (violated || S.force_rollback) {
+      // Undo the stage and replay it without any tentatively settled edge.
+      ++*S.rollbacks;
+      hipLaunchKernelGGL(k_restore_roots, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra,
+                         S.a_rb, nodes, S.bk_ds, S.bk_cons, S.bk_flags);
+      VSG_HIP(hipMemcpyAsync(S.stats, S.stats + 8, 8 * sizeof(unsigned long long),
+                             hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_gpos, kept_all);
+      clear_marks();
+      VSG_HIP(hipGetLastError());
+      RunBucketStage(bucket, n_b, lists, bucket_base, list_slot_base, kept_all, nodes, P, 0, S, s);
+      return;
+    }
+  }
+  clear_marks();
+  VSG_HIP(hipGetLastError());
 }
 
 __global__ __launch_bounds__(256) void k_keep_virtual_bucket(const ListDesc* __restrict__ lists,

@@ -354,6 +354,11 @@ void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
   last_timings_.edges_total = gt.edges_total;
   last_timings_.edges_active = gt.edges_active;
   last_timings_.merges = gt.merges[0] + gt.merges[1] + gt.merges[2];
+  last_timings_.wave_kernel_ms = gt.wave_ms;
+  last_timings_.wave_kernel_launches = gt.wave_launches;
+  last_timings_.wave_kernel_edges = gt.wave_edges;
+  last_timings_.filter_kernel_ms = gt.filter_ms;
+  last_timings_.filter_kernel_launches = gt.filter_launches;
   std::memset(&accum_, 0, sizeof(accum_));
 }
 
