@@ -1583,7 +1583,29 @@ class DenseSegmentation {
   // dense_segmentation.cpp:108-162.  features == nullptr <=> no new frame.
   int ProcessFrame(bool flush, const uint8_t* bgr, size_t stride, const float* flow,
                    bool has_flow_stream) {
-    if (seg_ == nullptr) NewSegmentation(options_.chunk_size);
+    if (seg_ == nullptr && !pending_import_) NewSegmentation(options_.chunk_size);
+    if (bgr && pending_import_) {
+      // First frame of a stream that continues another one: it is the constrained overlap frame;
+      // rebuild exactly the state ChunkBoundaryOutput leaves behind (cpp:291-315).
+      auto feat = std::make_shared<std::vector<float>>((size_t)W_ * H_ * 3);
+      PreprocessFeatures(bgr, stride, W_, H_, options_.presmoothing, feat->data());
+      feature_buffer_.push_back(nullptr);
+      feature_buffer_.push_back(feat);
+      if (has_flow_stream) {
+        VSO_CHECK(flow != nullptr);
+        flow_buffer_.push_back(nullptr);
+        flow_buffer_.push_back(std::make_shared<std::vector<float>>(flow, flow + (size_t)W_ * H_ * 2));
+      }
+      curr_chunk_start_ = 1;
+      NewSegmentation(curr_chunk_start_ + options_.chunk_size);
+      seg_->graph()->AddVirtualFrame(halo_[0].data());
+      seg_->graph()->AddFrame(feature_buffer_[1]->data(), halo_[1].data());
+      seg_->graph()->AddTemporal(nullptr, nullptr,
+                                 flow_buffer_.empty() ? nullptr : flow_buffer_[1]->data(), true);
+      pending_import_ = false;
+      ++input_frames_;
+      bgr = nullptr;   // consumed
+    }
     if (bgr) {
       auto feat = std::make_shared<std::vector<float>>((size_t)W_ * H_ * 3);
       PreprocessFeatures(bgr, stride, W_, H_, options_.presmoothing, feat->data());
@@ -1616,6 +1638,30 @@ class DenseSegmentation {
 
   const std::vector<std::unique_ptr<SegmentationDesc>>& results() const { return results_; }
   const int64_t* last_merge_stats() const { return last_merge_stats_; }
+
+  // Multi-GPU hand-off (not in the reference, where the state simply lives on in the object):
+  // everything the next chunk needs from this one -- the id images of the two overlap
+  // segmentations (dense_segmentation.cpp:300-308) and the running counters.
+  bool ExportHalo(int32_t* virt, int32_t* cons, int64_t scalars[4]) const {
+    if (halo_[0].empty()) return false;
+    std::memcpy(virt, halo_[0].data(), halo_[0].size() * sizeof(int32_t));
+    std::memcpy(cons, halo_[1].data(), halo_[1].size() * sizeof(int32_t));
+    scalars[0] = max_region_id_;
+    scalars[1] = chunk_id_;
+    scalars[2] = num_output_frames_;
+    scalars[3] = input_frames_;
+    return true;
+  }
+  void ImportHalo(const int32_t* virt, const int32_t* cons, const int64_t scalars[4]) {
+    VSO_CHECK(input_frames_ == 0 && seg_ == nullptr);
+    halo_[0].assign(virt, virt + (size_t)W_ * H_);
+    halo_[1].assign(cons, cons + (size_t)W_ * H_);
+    max_region_id_ = (int)scalars[0];
+    chunk_id_ = (int)scalars[1];
+    num_output_frames_ = (int)scalars[2];
+    input_frames_ = (int)scalars[3] - 1;   // the constrained overlap frame is fed again
+    pending_import_ = true;
+  }
   const float* last_smoothed() const {
     return (feature_buffer_.empty() || !feature_buffer_.back()) ? nullptr : feature_buffer_.back()->data();
   }
@@ -1643,15 +1689,14 @@ class DenseSegmentation {
     NewSegmentation(curr_chunk_start_ + options_.chunk_size);
     VSO_CHECK((int)overlap_segmentations_.size() == constraint_frames_ + 1);
     VSO_CHECK(overlap_segmentations_.size() >= 2);
-    std::vector<int32_t> ids((size_t)W_ * H_);
     // The id image is the graph's persistent region_ids_ buffer in the reference; every pixel is
     // covered by exactly one Region2D, so the previous contents never show through.
-    std::fill(ids.begin(), ids.end(), -1);
-    SegmentationDescToIdImage(*overlap_segmentations_[0], W_, ids.data());
-    seg_->graph()->AddVirtualFrame(ids.data());                                 // :305
-    std::fill(ids.begin(), ids.end(), -1);
-    SegmentationDescToIdImage(*overlap_segmentations_[1], W_, ids.data());
-    seg_->graph()->AddFrame(feature_buffer_[1]->data(), ids.data());            // :307-308
+    for (int k = 0; k < 2; ++k) {
+      halo_[k].assign((size_t)W_ * H_, -1);
+      SegmentationDescToIdImage(*overlap_segmentations_[k], W_, halo_[k].data());
+    }
+    seg_->graph()->AddVirtualFrame(halo_[0].data());                            // :305
+    seg_->graph()->AddFrame(feature_buffer_[1]->data(), halo_[1].data());       // :307-308
     if (!flow_buffer_.empty()) {                                                // :311-315
       seg_->graph()->AddTemporal(nullptr, nullptr, flow_buffer_[1]->data(), true);
     } else {
@@ -1738,6 +1783,8 @@ class DenseSegmentation {
   std::vector<std::unique_ptr<SegmentationDesc>> results_;
   std::unique_ptr<Segmentation> seg_;
   int64_t last_merge_stats_[3] = {0, 0, 0};
+  std::vector<int32_t> halo_[2];
+  bool pending_import_ = false;
 };
 
 }  // namespace vso
@@ -1829,6 +1876,14 @@ int vso_stream_last_smoothed(const vso_stream* s, float* out) {
   if (!p) return -1;
   std::memcpy(out, p, (size_t)s->ds->W() * s->ds->H() * 3 * sizeof(float));
   return 0;
+}
+
+int vso_stream_export_halo(const vso_stream* s, int32_t* virt, int32_t* cons, int64_t* scalars4) {
+  return s->ds->ExportHalo(virt, cons, scalars4) ? 0 : -1;
+}
+void vso_stream_import_halo(vso_stream* s, const int32_t* virt, const int32_t* cons,
+                            const int64_t* scalars4) {
+  s->ds->ImportHalo(virt, cons, scalars4);
 }
 
 void vso_preprocess(const uint8_t* bgr, size_t stride, int width, int height, int presmoothing,

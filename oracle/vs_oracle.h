@@ -67,6 +67,13 @@ void vso_stream_last_merge_stats(const vso_stream* s, int64_t* stats3);
 /* Smoothed feature frame of the most recently added frame (W*H*3 f32, BGR interleaved). */
 int vso_stream_last_smoothed(const vso_stream* s, float* out);
 
+/* Chunk hand-off for the multi-GPU chain (mirrors vsg_stream_export_halo / import_halo): id images
+ * of the two overlap frames (W*H int32 each, host) + {max_region_id, chunk_id, num_output_frames,
+ * input_frames}. */
+int vso_stream_export_halo(const vso_stream* s, int32_t* virt, int32_t* cons, int64_t* scalars4);
+void vso_stream_import_halo(vso_stream* s, const int32_t* virt, const int32_t* cons,
+                            const int64_t* scalars4);
+
 /* ---- stage level (kernel parity) ------------------------------------------------------- */
 /* PreprocessFeatures: u8*(1/255) then bilateral(3.0, 0.25) if presmoothing==2. out: W*H*3. */
 void vso_preprocess(const uint8_t* bgr, size_t stride, int width, int height, int presmoothing,

@@ -66,6 +66,9 @@ def lib():
     L.vso_stream_last_merge_stats.argtypes = [vp, vp]
     L.vso_stream_last_smoothed.restype = C.c_int
     L.vso_stream_last_smoothed.argtypes = [vp, vp]
+    L.vso_stream_export_halo.restype = C.c_int
+    L.vso_stream_export_halo.argtypes = [vp, vp, vp, vp]
+    L.vso_stream_import_halo.argtypes = [vp, vp, vp, vp]
     L.vso_preprocess.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp]
     L.vso_bilateral_tables.restype = C.c_float
     L.vso_bilateral_tables.argtypes = [C.c_float, C.c_float, vp, vp]
@@ -171,6 +174,19 @@ class OracleStream:
         out = np.empty((self.H, self.W, 3), np.float32)
         assert lib().vso_stream_last_smoothed(self.h, _ptr(out)) == 0
         return out
+
+    def export_halo(self):
+        a = np.empty((self.H, self.W), np.int32)
+        b = np.empty((self.H, self.W), np.int32)
+        s = np.zeros(4, np.int64)
+        assert lib().vso_stream_export_halo(self.h, _ptr(a), _ptr(b), _ptr(s)) == 0
+        return a, b, s
+
+    def import_halo(self, labels_virtual, labels_constrained, scalars):
+        a = np.ascontiguousarray(labels_virtual, np.int32)
+        b = np.ascontiguousarray(labels_constrained, np.int32)
+        s = np.ascontiguousarray(scalars, np.int64)
+        lib().vso_stream_import_halo(self.h, _ptr(a), _ptr(b), _ptr(s))
 
 
 def preprocess(bgr, presmoothing=2):

@@ -226,3 +226,24 @@ def test_optimistic_stage_rollback_is_exact(vsg, monkeypatch, W, H, N, kind, chu
     monkeypatch.delenv("VSG_FORCE_ROLLBACK")
     monkeypatch.setenv("VSG_INERT_MODE", "0")
     run_streams(vsg, W, H, N, kind, True, chunk)
+
+
+def test_chain_protocol_on_gpu(vsg):
+    """Fresh HIP engine per chunk + label-plane halo hand-off == one continuous oracle stream
+    (the multi-GPU chain mode, run on one device)."""
+    import torch
+    from video_segment_amd.multi_gpu import product_halo, run_chain
+    W, H, N, chunk = 64, 48, 40, 8
+    dev = torch.device("cuda", 0)
+    fl = synth.const_flow(W, H)
+    got = run_chain(
+        lambda: vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=True),
+        lambda k: synth.bench_frame(W, H, k), lambda k: fl, N, chunk, W, H, 0, 1, None,
+        from_engine_halo=lambda e: product_halo(e, W, H, dev))
+    o = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
+    want = []
+    for k in range(N):
+        n = o.process_frame(synth.bench_frame(W, H, k), fl if k > 0 else None, flush=(k == N - 1))
+        want += [o.result_bytes(i) for i in range(n)]
+    assert [k for k, _ in got] == list(range(N))
+    assert [b for _, b in got] == want

@@ -56,7 +56,7 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   keys_sorted_tmp_.alloc(9 * wh_);
   vals_tmp_.alloc(9 * wh_);
   scalars_.alloc(16);
-  stats_.alloc(16);
+  stats_.alloc(24);
   size_t temp = SortPairsU16TempBytes((int)(9 * wh_));
   temp = std::max(temp, ScanTempBytes((int)N));
   cub_temp_.alloc(temp);
@@ -203,7 +203,7 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   LaunchBuildBucketTable(list_desc_dev_.get(), L, bucket_base_dev_.get(), stream_);
   bucket_base_host_.resize((size_t)(kNumBuckets + 1) * (L + 1));
   D2H(bucket_base_host_.data(), bucket_base_dev_.get(), bucket_base_host_.size(), stream_);
-  VSG_HIP(hipMemsetAsync(stats_.get(), 0, 16 * sizeof(unsigned long long), stream_));
+  VSG_HIP(hipMemsetAsync(stats_.get(), 0, 24 * sizeof(unsigned long long), stream_));
   LaunchInitIdentity(cc_.get(), N, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
 
@@ -291,8 +291,8 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   timings_.rollbacks = rollbacks_;
   LaunchKeepVirtualBucket(list_desc_dev_.get(), L, stream_);
   if (force_constraints && has_constraints_) MergeConstrainedHostAssisted();
-  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  D2H(st, stats_.get(), 8, stream_);
+  unsigned long long st[24] = {0};
+  D2H(st, stats_.get(), 24, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
   if (getenv("VSG_DEBUG_STATS")) {
     std::fprintf(stderr, "[vsg] wave: edges %llu batches %llu iters %llu hot-hits %llu internal %llu; "

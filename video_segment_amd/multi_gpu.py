@@ -1,0 +1,218 @@
+"""Multi-GPU chunk chain: one video, chunks round-robin over the ranks.
+
+The reference is a single process: chunk c+1 is constrained by the labels chunk c produced for
+its two overlap frames, and region ids continue from `max_region_id_`.  Sharding one video over
+several GPUs therefore is a *pipeline*: rank r = c mod world segments chunk c and hands
+    * the region-id image of the virtual overlap frame      (W*H int32)
+    * the region-id image of the constrained overlap frame  (W*H int32)
+    * {max_region_id, chunk_id, num_output_frames, input_frames}
+to the rank that owns chunk c+1 (point-to-point send/recv: RCCL over xGMI on GPUs; gloo in the
+CPU tests).  Graph *construction* needs no exchange: every rank re-filters the raw frames of its
+own chunk, including the constrained overlap frame.
+
+The runner is engine agnostic: the engine factory returns an object with the DenseSegmentation
+interface (process_frame / result_bytes / export_halo / import_halo); the product engine is
+video_segment_amd.DenseSegmentation, the CPU tests use the oracle.
+"""
+import numpy as np
+
+
+def chunk_plan(num_frames, chunk):
+    """Frames fed to the engine of every chunk: list of (first_frame, last_frame) inclusive.
+
+    Chunk 0 is fed frames 0..chunk-1; chunk c >= 1 is fed its constrained overlap frame
+    s = c*(chunk-1) first and then s+1 .. s+chunk-1 (dense_segmentation.cpp:157, 281-331: the
+    steady state advances chunk-1 output frames per chunk).  The last chunk ends with the video.
+    """
+    plan = []
+    first = 0
+    stride = chunk - 1
+    while True:
+        last = min(first + chunk - 1, num_frames - 1)
+        plan.append((first, last))
+        if last >= num_frames - 1:
+            break
+        first += stride
+    return plan
+
+
+class DistTransport:
+    """torch.distributed point-to-point transport (backend nccl = RCCL on GPUs, gloo on CPU)."""
+
+    def __init__(self, device):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.device = torch, dist, device
+
+    def send(self, dst, tag, arrays):
+        for a in arrays:
+            t = a if self.torch.is_tensor(a) else self.torch.from_numpy(np.ascontiguousarray(a))
+            self.dist.send(t.to(self.device).contiguous(), dst=dst)
+
+    def recv(self, src, tag, shapes_dtypes):
+        out = []
+        for shape, dtype in shapes_dtypes:
+            t = self.torch.empty(shape, dtype=dtype, device=self.device)
+            self.dist.recv(t, src=src)
+            out.append(t)
+        return out
+
+
+def run_chain(engine_factory, get_frame, get_flow, num_frames, chunk, width, height, rank, world,
+              transport, to_engine_labels=None, from_engine_halo=None):
+    """Segments the chunks owned by `rank` and returns [(frame_index, SegmentationDesc bytes)].
+
+    engine_factory(): fresh engine (has_flow must match get_flow).
+    get_frame(k), get_flow(k): inputs of global frame k in the engine's memory kind (flow(0) unused).
+    to_engine_labels(x): converts a received label plane to what engine.import_halo accepts.
+    from_engine_halo(engine): returns (labels_virtual, labels_constrained, scalars) ready to send.
+    """
+    import torch
+    plan = chunk_plan(num_frames, chunk)
+    out = []
+    for c, (first, last) in enumerate(plan):
+        if c % world != rank:
+            continue
+        eng = engine_factory()
+        if c > 0:
+            src = (c - 1) % world
+            if src == rank:
+                virt, cons, scal = pending_local  # noqa: F821  (set below when world == 1)
+            else:
+                virt, cons, scal = transport.recv(
+                    src, c, [((height, width), torch.int32), ((height, width), torch.int32),
+                             ((4,), torch.int64)])
+            if to_engine_labels is not None:
+                virt, cons = to_engine_labels(virt), to_engine_labels(cons)
+            scal_np = scal.cpu().numpy() if torch.is_tensor(scal) else np.asarray(scal)
+            eng.import_halo(virt, cons, scal_np)
+        next_frame_out = None
+        for k in range(first, last + 1):
+            flush = (k == num_frames - 1)
+            flow = get_flow(k) if (get_flow is not None and k > 0) else None
+            n = eng.process_frame(get_frame(k), flow, flush=flush)
+            if n:
+                # the chunk's outputs start at frame `first` (chunk 0: frame 0)
+                base = first if next_frame_out is None else next_frame_out
+                for i in range(n):
+                    out.append((base + i, eng.result_bytes(i)))
+                next_frame_out = base + n
+        if c + 1 < len(plan):
+            halo = from_engine_halo(eng) if from_engine_halo is not None else eng.export_halo()
+            dst = (c + 1) % world
+            if dst == rank:
+                pending_local = halo  # noqa: F841
+            else:
+                transport.send(dst, c + 1, list(halo))
+        eng.close()
+    return out
+
+
+def run_chain_bench(args, rank, world, local_rank):
+    """bench.py --mode chain: one long video sharded chunk-wise over the ranks (RCCL hand-off)."""
+    import time
+    import torch
+    import torch.distributed as dist
+    import video_segment_amd as vsg
+    import synth
+
+    W, H, chunk = args.width, args.height, args.chunk
+    K, Wm = args.steps, args.warmup
+    dev = torch.device("cuda", local_rank)
+    # K timed chunks per rank (weak scaling: the video grows with the number of ranks), after Wm
+    # warm-up chunks per rank.
+    total_chunks = (Wm + K) * world
+    num_frames = chunk + (chunk - 1) * (total_chunks - 1)
+    plan = chunk_plan(num_frames, chunk)
+    mine = [c for c in range(len(plan)) if c % world == rank]
+    frames = {}
+    for c in mine:
+        for k in range(plan[c][0], plan[c][1] + 1):
+            if k not in frames:
+                frames[k] = torch.from_numpy(synth.bench_frame(W, H, k)).to(dev)
+    flow = torch.from_numpy(synth.const_flow(W, H)).to(dev)
+    transport = DistTransport(dev)
+    eng = None
+    torch.cuda.synchronize()
+    dist.barrier()
+    acc = {"wave_ms": 0.0, "wave_launches": 0, "wave_edges": 0, "merge_ms": 0.0, "pre_ms": 0.0,
+           "edges_ms": 0.0, "readout_ms": 0.0, "host_ms": 0.0, "filter_ms": 0.0,
+           "filter_launches": 0, "edges_total": 0, "merges": 0}
+    frames_out = 0
+    t0 = None
+    for idx, c in enumerate(mine):
+        if idx == Wm:
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+        first, last = plan[c]
+        eng = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=local_rank),
+                                    has_flow=True)
+        if c > 0:
+            virt, cons, scal = transport.recv((c - 1) % world, c,
+                                              [((H, W), torch.int32), ((H, W), torch.int32),
+                                               ((4,), torch.int64)])
+            eng.import_halo(virt, cons, scal.cpu().numpy())
+        for k in range(first, last + 1):
+            n = eng.process_frame(frames[k], flow if k > 0 else None, flush=(k == num_frames - 1))
+            if n and idx >= Wm:
+                frames_out += n
+                t = eng.last_timings()
+                acc["wave_ms"] += t.wave_kernel_ms
+                acc["wave_launches"] += t.wave_kernel_launches
+                acc["wave_edges"] += t.wave_kernel_edges
+                acc["filter_ms"] += t.filter_kernel_ms
+                acc["filter_launches"] += t.filter_kernel_launches
+                acc["merge_ms"] += t.merge_ms
+                acc["pre_ms"] += t.preprocess_ms
+                acc["edges_ms"] += t.edges_ms
+                acc["readout_ms"] += t.readout_ms
+                acc["host_ms"] += t.host_post_ms
+                acc["edges_total"] += t.edges_total
+                acc["merges"] += t.merges
+        if c + 1 < len(plan):
+            pa, pb, scal = eng.export_halo()
+            n_el = W * H
+            ta = torch.empty((H, W), dtype=torch.int32, device=dev)
+            tb = torch.empty((H, W), dtype=torch.int32, device=dev)
+            # device-to-device copies out of the library-owned planes
+            torch.cuda.synchronize()
+            ta.copy_(_wrap_device_int32(pa, n_el, dev).view(H, W))
+            tb.copy_(_wrap_device_int32(pb, n_el, dev).view(H, W))
+            transport.send((c + 1) % world, c + 1,
+                           [ta, tb, torch.from_numpy(scal).to(dev)])
+        eng.close()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    fo = torch.tensor([frames_out], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dist.all_reduce(fo, op=dist.ReduceOp.SUM)
+    return {"dt": float(tt.item()), "frames": float(fo.item()), "acc": acc,
+            "parallelism": "one video, chunks round-robin over %d GPUs, label-plane halo over "
+                           "RCCL send/recv" % world}
+
+
+def _wrap_device_int32(ptr, n, dev):
+    """Views library-owned device memory as a torch tensor (no copy) via __cuda_array_interface__."""
+    import torch
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (int(ptr), False),
+                                  "version": 2}
+    return torch.as_tensor(h, device=dev)
+
+
+def product_halo(engine, width, height, device):
+    """(labels_virtual, labels_constrained, scalars) of a product engine as torch device tensors
+    (copies of the library-owned planes), ready for transport.send / import_halo."""
+    import torch
+    pa, pb, scal = engine.export_halo()
+    n = width * height
+    ta = _wrap_device_int32(pa, n, device).view(height, width).clone()
+    tb = _wrap_device_int32(pb, n, device).view(height, width).clone()
+    return ta, tb, torch.from_numpy(scal)
