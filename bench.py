@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=20)
     ap.add_argument("--mode", choices=["streams", "chain"], default="streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=20)
     return ap.parse_args()
 
 

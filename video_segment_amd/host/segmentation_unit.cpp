@@ -1,0 +1,217 @@
+// segmentation_unit.cpp -- see segmentation_unit.h.  Behaviour restated from the reference's
+// DenseSegmentationUnit (segmentation/segmentation_unit.cpp:48-178): error conventions
+// (LOG(ERROR) + return false from OpenStreams, CHECK-abort on contract violations), frame-set
+// buffering until a chunk is segmented, the pts hand-over and the __STREAMING_SIZE__ marker.
+#include "segmentation_unit.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace segmentation {
+
+// ---- minimal proto2 reader for SegmentationDesc -------------------------------------------
+namespace {
+struct Cursor {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool ok = true;
+  uint64_t Varint() {
+    uint64_t v = 0;
+    int shift = 0;
+    while (p < end) {
+      const uint8_t b = *p++;
+      v |= (uint64_t)(b & 0x7f) << shift;
+      if (!(b & 0x80)) return v;
+      shift += 7;
+      if (shift > 63) break;
+    }
+    ok = false;
+    return 0;
+  }
+  // Returns the field number, sets wire type; length-delimited payload in [sub_p, sub_end).
+  bool Next(int* field, int* wt, Cursor* sub, uint64_t* value) {
+    if (p >= end || !ok) return false;
+    const uint64_t tag = Varint();
+    *field = (int)(tag >> 3);
+    *wt = (int)(tag & 7);
+    if (*wt == 0) {
+      *value = Varint();
+    } else if (*wt == 2) {
+      const uint64_t n = Varint();
+      if (!ok || n > (uint64_t)(end - p)) {
+        ok = false;
+        return false;
+      }
+      sub->p = p;
+      sub->end = p + n;
+      p += n;
+    } else if (*wt == 5) {
+      if (end - p < 4) { ok = false; return false; }
+      p += 4;
+    } else if (*wt == 1) {
+      if (end - p < 8) { ok = false; return false; }
+      p += 8;
+    } else {
+      ok = false;
+      return false;
+    }
+    return ok;
+  }
+};
+}  // namespace
+
+bool SegmentationDesc::ToIdImage(int width, int height, std::vector<int32_t>* out) const {
+  out->assign((size_t)width * height, -1);
+  Cursor top{reinterpret_cast<const uint8_t*>(wire.data()),
+             reinterpret_cast<const uint8_t*>(wire.data()) + wire.size()};
+  int f, wt;
+  uint64_t v;
+  Cursor region{nullptr, nullptr};
+  while (top.Next(&f, &wt, &region, &v)) {
+    if (f != 2 || wt != 2) continue;            // SegmentationDesc.region = 2
+    int id = -1;
+    Cursor raster{nullptr, nullptr}, sub{nullptr, nullptr};
+    bool has_raster = false;
+    while (region.Next(&f, &wt, &sub, &v)) {
+      if (f == 1 && wt == 0) id = (int)(int64_t)v;          // Region2D.id
+      if (f == 3 && wt == 2) { raster = sub; has_raster = true; }   // Region2D.raster
+    }
+    if (!region.ok) return false;
+    if (!has_raster) continue;
+    Cursor scan{nullptr, nullptr};
+    while (raster.Next(&f, &wt, &scan, &v)) {
+      if (f != 1 || wt != 2) continue;          // Rasterization.scan_inter = 1
+      int y = 0, lx = 0, rx = -1;
+      Cursor none{nullptr, nullptr};
+      while (scan.Next(&f, &wt, &none, &v)) {
+        if (wt != 0) continue;
+        if (f == 1) y = (int)(int64_t)v;
+        if (f == 2) lx = (int)(int64_t)v;
+        if (f == 3) rx = (int)(int64_t)v;
+      }
+      if (!scan.ok || y < 0 || y >= height || lx < 0 || rx >= width) return false;
+      for (int x = lx; x <= rx; ++x) (*out)[(size_t)y * width + x] = id;
+    }
+    if (!raster.ok) return false;
+  }
+  return top.ok;
+}
+
+int SegmentationDesc::NumRegions() const {
+  Cursor top{reinterpret_cast<const uint8_t*>(wire.data()),
+             reinterpret_cast<const uint8_t*>(wire.data()) + wire.size()};
+  int f, wt, n = 0;
+  uint64_t v;
+  Cursor sub{nullptr, nullptr};
+  while (top.Next(&f, &wt, &sub, &v)) n += (f == 2 && wt == 2);
+  return top.ok ? n : -1;
+}
+
+// ---- DenseSegmentationUnit ------------------------------------------------------------------
+DenseSegmentationUnit::DenseSegmentationUnit(const DenseSegmentationUnitOptions& options,
+                                             const DenseSegmentationOptions* dense_seg_options)
+    : options_(options) {
+  if (dense_seg_options) dense_seg_options_ = *dense_seg_options;
+}
+
+DenseSegmentationUnit::~DenseSegmentationUnit() {
+  if (dense_seg_) vsg_stream_destroy(dense_seg_);
+}
+
+bool DenseSegmentationUnit::OpenStreams(StreamSet* set) {
+  video_stream_idx_ = FindStreamIdx(options_.video_stream_name, set);
+  if (video_stream_idx_ < 0) {
+    std::fprintf(stderr, "ERROR: Could not find video stream!\n");
+    return false;
+  }
+  const VideoStream& vid_stream = set->at(video_stream_idx_)->As<VideoStream>();
+  frame_width_ = vid_stream.frame_width();
+  frame_height_ = vid_stream.frame_height();
+  if (vid_stream.pixel_format() != PIXEL_FORMAT_BGR24) {
+    std::fprintf(stderr, "ERROR: Expecting video format to be BGR24.\n");
+    return false;
+  }
+  if (!options_.flow_stream_name.empty()) {
+    flow_stream_idx_ = FindStreamIdx(options_.flow_stream_name, set);
+    if (flow_stream_idx_ < 0) {
+      std::fprintf(stderr, "ERROR: Flow stream specified but not present\n");
+      return false;
+    }
+  } else {
+    flow_stream_idx_ = -1;
+  }
+  set->push_back(std::shared_ptr<DataStream>(
+      new SegmentationStream(frame_width_, frame_height_, options_.segment_stream_name)));
+
+  // CreateDenseSegmentation(): the MI355X implementation behind the C ABI.
+  VF_CHECK(!dense_seg_options_.two_stage_oversegment && !dense_seg_options_.thin_structure_suppression &&
+               !dense_seg_options_.compute_vectorization,
+           "option not supported by the HIP over-segmentation path");
+  vsg_options o;
+  vsg_default_options(&o);
+  o.presmoothing = (int)dense_seg_options_.presmoothing;
+  o.frac_min_region_size = dense_seg_options_.frac_min_region_size;
+  o.chunk_size = dense_seg_options_.chunk_size;
+  o.chunk_overlap_ratio = dense_seg_options_.chunk_overlap_ratio;
+  o.num_constraint_frames = dense_seg_options_.num_constraint_frames;
+  o.enforce_n4_connectivity = dense_seg_options_.enforce_n4_connectivity ? 1 : 0;
+  o.enforce_spatial_connectedness = dense_seg_options_.enforce_spatial_connectedness ? 1 : 0;
+  o.color_distance = (int)dense_seg_options_.color_distance;
+  o.device = options_.device;
+  if (vsg_stream_create(&o, frame_width_, frame_height_, &dense_seg_) != VSG_OK) {
+    std::fprintf(stderr, "ERROR: could not create HIP dense segmentation: %s\n", vsg_last_error());
+    return false;
+  }
+  SetRateBufferSize(vsg_stream_chunk_size(dense_seg_) * 3);
+  return true;
+}
+
+void DenseSegmentationUnit::ProcessFrame(FrameSetPtr input, std::list<FrameSetPtr>* output) {
+  const VideoFrame& video_frame = input->at(video_stream_idx_)->As<VideoFrame>();
+  const float* flow = nullptr;
+  if (input_frames_ > 0 && flow_stream_idx_ >= 0) {
+    const DenseFlowFrame& flow_frame = input->at(flow_stream_idx_)->As<DenseFlowFrame>();
+    VF_CHECK(flow_frame.width() == frame_width_ && flow_frame.height() == frame_height_,
+             "flow dimensions differ from the video stream");
+    flow = flow_frame.flow();
+  }
+  frame_set_buffer_.push_back(input);
+  ++input_frames_;
+  int num_results = 0;
+  const int rc = vsg_stream_process_frame(dense_seg_, 0, video_frame.data(),
+                                          (size_t)video_frame.width_step(), flow,
+                                          flow_stream_idx_ >= 0 ? 1 : 0, VSG_MEM_HOST, &num_results);
+  VF_CHECK(rc == VSG_OK, vsg_last_error());
+  if (num_results > 0) OutputSegmentation(num_results, output);
+}
+
+bool DenseSegmentationUnit::PostProcess(std::list<FrameSetPtr>* append) {
+  if (!dense_seg_ || input_frames_ == 0) return false;
+  int num_results = 0;
+  const int rc = vsg_stream_process_frame(dense_seg_, 1, nullptr, 0, nullptr,
+                                          flow_stream_idx_ >= 0 ? 1 : 0, VSG_MEM_HOST, &num_results);
+  VF_CHECK(rc == VSG_OK, vsg_last_error());
+  if (num_results > 0) OutputSegmentation(num_results, append);
+  return false;
+}
+
+void DenseSegmentationUnit::OutputSegmentation(int num_results, std::list<FrameSetPtr>* output) {
+  for (int k = 0; k < num_results; ++k) {
+    VF_CHECK(!frame_set_buffer_.empty(), "more results than buffered frame sets");
+    FrameSetPtr frame_set = frame_set_buffer_.front();
+    frame_set_buffer_.pop_front();
+    const int64_t pts = frame_set->at(video_stream_idx_)->pts();
+    const uint8_t* data = nullptr;
+    size_t len = 0;
+    VF_CHECK(vsg_stream_result_bytes(dense_seg_, k, &data, &len) == VSG_OK, vsg_last_error());
+    std::unique_ptr<SegmentationDesc> desc(new SegmentationDesc);
+    desc->wire.assign(reinterpret_cast<const char*>(data), len);
+    frame_set->push_back(std::shared_ptr<Frame>(new PointerFrame<SegmentationDesc>(std::move(desc), pts)));
+    output->push_back(frame_set);
+    ++output_frames_;
+  }
+  // Progress marker parsed by the reference's web front end (segmentation_unit.cpp:177).
+  std::fprintf(stderr, "__STREAMING_SIZE__: %d\n", output_frames_);
+}
+
+}  // namespace segmentation
