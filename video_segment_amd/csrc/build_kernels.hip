@@ -401,7 +401,8 @@ __global__ __launch_bounds__(256) void k_first_of_label(const int32_t* __restric
   const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (pix >= n) return;
   const int l = labels[pix];
-  if (l >= 0 && l < num_labels) atomicMin(&first[l], (int)pix);
+  // most pixels of a region lose against an earlier pixel: test before issuing the atomic
+  if (l >= 0 && l < num_labels && first[l] > (int)pix) atomicMin(&first[l], (int)pix);
 }
 
 __global__ __launch_bounds__(256) void k_init_virtual_nodes(const int32_t* __restrict__ labels,
