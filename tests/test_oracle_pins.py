@@ -73,3 +73,17 @@ def test_oracle_matches_reference_probe_1080p():
     assert rid == 0 and m[0] == 48086.0
     assert m[1] == np.float32(666.239624) and m[2] == np.float32(35.610695)
     assert m[3] == np.float32(592062.9375)
+
+
+def test_oracle_matches_reference_config2_probe():
+    """SURVEY App. B, 'Config-2-shaped probe through seam (3)': DenseSegmentationGraph(640,480,32),
+    32 x {convertTo, BilateralFilter, AddNodesAndSpatialEdges}, SegmentFullGraph(983, false),
+    ObtainResults(nullptr, false, true, true), DetermineNeighborIds -> 288 regions, 1184 directed
+    neighbour links."""
+    W, H, F = 640, 480, 32
+    g = ol.OracleGraph(W, H, F)
+    for k in range(F):
+        g.add_frame(ol.preprocess(synth.probe_frame(W, H, k)))
+    g.segment(983, False)
+    g.obtain_results(None, True, True)
+    assert (g.num_regions(), g.num_neighbor_links()) == (288, 1184)
