@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--chunk", type=int, default=20)
     ap.add_argument("--mode", choices=["streams", "chain"], default="streams")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="concurrent independent 1080p streams per GPU (default 1 = the BASELINE "
+                         "workload; >1 only quantifies how idle one stream leaves the GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=20)
     return ap.parse_args()
@@ -112,8 +115,10 @@ def main():
         for k in range(n_frames):
             f = synth.bench_frame(W, H, k + seed_shift) if rank else synth.bench_frame(W, H, k)
             frames.append(torch.from_numpy(f).to(dev))
-        stream = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=local_rank),
-                                       has_flow=True)
+        import threading
+        S = max(1, args.streams)
+        streams = [vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=local_rank),
+                                         has_flow=True) for _ in range(S)]
         torch.cuda.synchronize()
 
         def barrier():
@@ -121,49 +126,65 @@ def main():
             if world > 1:
                 dist.barrier()
 
-        k = 0
-        steps_done = 0
-        # warm-up
-        while steps_done < Wm:
-            n = stream.process_frame(frames[k], flow if k > 0 else None)
-            k += 1
-            steps_done += 1 if n else 0
+        keys = ["wave_ms", "wave_launches", "wave_edges", "merge_ms", "pre_ms", "edges_ms",
+                "readout_ms", "host_ms", "filter_ms", "filter_launches", "edges_total", "merges"]
+        accs = [dict((k_, 0) for k_ in keys) for _ in range(S)]
+        outs = [0] * S
+        pos = [0] * S
+
+        def run(si, steps, record):
+            stream = streams[si]
+            done = 0
+            while done < steps:
+                k = pos[si]
+                n = stream.process_frame(frames[k], flow if k > 0 else None)
+                pos[si] = k + 1
+                if n:
+                    done += 1
+                    if record:
+                        outs[si] += n
+                        t = stream.last_timings()
+                        a = accs[si]
+                        a["wave_ms"] += t.wave_kernel_ms
+                        a["wave_launches"] += t.wave_kernel_launches
+                        a["wave_edges"] += t.wave_kernel_edges
+                        a["filter_ms"] += t.filter_kernel_ms
+                        a["filter_launches"] += t.filter_kernel_launches
+                        a["merge_ms"] += t.merge_ms
+                        a["pre_ms"] += t.preprocess_ms
+                        a["edges_ms"] += t.edges_ms
+                        a["readout_ms"] += t.readout_ms
+                        a["host_ms"] += t.host_post_ms
+                        a["edges_total"] += t.edges_total
+                        a["merges"] += t.merges
+
+        def run_all(steps, record):
+            if S == 1:
+                run(0, steps, record)
+                return
+            th = [threading.Thread(target=run, args=(si, steps, record)) for si in range(S)]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+
+        run_all(Wm, False)          # warm-up: includes the first (unconstrained) chunk
         barrier()
         t0 = time.perf_counter()
-        frames_out = 0
-        timed = 0
-        acc = {"wave_ms": 0.0, "wave_launches": 0, "wave_edges": 0, "merge_ms": 0.0,
-               "pre_ms": 0.0, "edges_ms": 0.0, "readout_ms": 0.0, "host_ms": 0.0,
-               "filter_ms": 0.0, "filter_launches": 0, "edges_total": 0, "merges": 0}
-        while timed < K:
-            n = stream.process_frame(frames[k], flow if k > 0 else None)
-            k += 1
-            if n:
-                timed += 1
-                frames_out += n
-                t = stream.last_timings()
-                acc["wave_ms"] += t.wave_kernel_ms
-                acc["wave_launches"] += t.wave_kernel_launches
-                acc["wave_edges"] += t.wave_kernel_edges
-                acc["filter_ms"] += t.filter_kernel_ms
-                acc["filter_launches"] += t.filter_kernel_launches
-                acc["merge_ms"] += t.merge_ms
-                acc["pre_ms"] += t.preprocess_ms
-                acc["edges_ms"] += t.edges_ms
-                acc["readout_ms"] += t.readout_ms
-                acc["host_ms"] += t.host_post_ms
-                acc["edges_total"] += t.edges_total
-                acc["merges"] += t.merges
+        run_all(K, True)            # K timed steps per stream
         barrier()
         dt = time.perf_counter() - t0
+        frames_out = sum(outs)
+        acc = dict((k_, sum(a[k_] for a in accs) / S) for k_ in keys)
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         fo = torch.tensor([frames_out], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.all_reduce(fo, op=dist.ReduceOp.SUM)
         result = {"dt": float(tt.item()), "frames": float(fo.item()), "acc": acc,
-                  "parallelism": "1 independent 1080p stream per GPU x %d" % world}
-        stream.close()
+                  "parallelism": "%d independent 1080p stream(s) per GPU x %d GPU(s)" % (S, world)}
+        for st_ in streams:
+            st_.close()
 
     if rank == 0:
         dt, frames_total, acc = result["dt"], result["frames"], result["acc"]

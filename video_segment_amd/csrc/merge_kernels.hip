@@ -586,69 +586,75 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
       }
       bool my_kept = false;
       unsigned long long pending = __ballot(valid && ra != rb);
-      // Lanes whose cached region is a plain partner for the fast path below: unconstrained,
-      // not finalized, has a descriptor, not tentatively marked.
-      unsigned long long ok_a = __ballot(A.cons < 0 && A.flags == 0);
-      unsigned long long ok_b = __ballot(B.cons < 0 && B.flags == 0);
+      // Per-lane flags: the cached region is a plain partner (unconstrained, not finalized, has a
+      // descriptor, not tentatively marked).
+      bool ok_a = (A.cons < 0 && A.flags == 0);
+      bool ok_b = (B.cons < 0 && B.flags == 0);
       if (lane == 0) ++dbg_batches;
       while (pending) {
+        // ---- tight chain loop: the hot region absorbs plain partners smaller than itself ------
+        // Every lane keeps a "partner view" relative to the hot region (which of its two regions
+        // is the partner, the partner's state), re-derived with a dozen VALU ops after each
+        // merge, so that one chain step is: 5 readlanes, the test, the mean update, one parent
+        // store and the id rename -- the same arithmetic as DecideEdge/MergeStates for this case
+        // (Case U; the hot region keeps its flags and constraint; the partner carries no mark).
+        if (hot >= 0 && !(H.flags & kFlagNoDesc)) {
+          for (;;) {
+            const bool e1 = (ra == hot), e2 = (rb == hot);
+            const unsigned long long internal = __ballot(ra == rb);
+            const unsigned long long chain = __ballot((e1 != e2) && (e1 ? ok_b : ok_a));
+            // drop leading pending lanes that became internal
+            while (pending && ((internal >> __builtin_ctzll(pending)) & 1ull)) {
+              pending &= pending - 1;
+              if (lane == 0) ++dbg_internal;
+            }
+            if (!pending) break;
+            const int j = __builtin_ctzll(pending);
+            if (!((chain >> j) & 1ull)) break;
+            const float px0 = e1 ? B.d0 : A.d0;
+            const float px1 = e1 ? B.d1 : A.d1;
+            const float px2 = e1 ? B.d2 : A.d2;
+            const int pszv = e1 ? B.sz : A.sz;
+            const int pidv = e1 ? rb : ra;
+            const int psz = ReadLaneI(pszv, j);
+            if (!(H.sz > psz)) break;
+            const float p0 = ReadLaneF(px0, j), p1 = ReadLaneF(px1, j), p2 = ReadLaneF(px2, j);
+            bool merge;
+            if (!(H.flags & kFlagFinalized)) {
+              const float x = H.d0 - p0, y = H.d1 - p1, z = H.d2 - p2;
+              if (!((x * x + y * y + z * z) * (1.0f / 3.0f) <= T.pass_s)) break;   // -> generic
+              merge = true;
+              ++n_regular;
+            } else {
+              merge = (psz < T.min_size || H.sz < T.min_size);
+              n_small += merge;
+            }
+            pending &= pending - 1;
+            if (lane == 0) { ++dbg_iters; ++dbg_hot; }
+            if (merge) {
+              const float denom = 1.0f / (float)(psz + H.sz);
+              const float ca = (float)psz * denom;
+              const float cb = (float)H.sz * denom;
+              H.d0 = ca * p0 + cb * H.d0;
+              H.d1 = ca * p1 + cb * H.d1;
+              H.d2 = ca * p2 + cb * H.d2;
+              H.sz += psz;
+              const int pid = ReadLaneI(pidv, j);
+              if (lane == j) nodes.parent[pid] = hot;
+              if (ra == pid) ra = hot;
+              if (rb == pid) rb = hot;
+            } else if (lane == j) {
+              my_kept = true;   // both regions finalized / large: kept, nothing changes
+            }
+          }
+          if (!pending) break;
+        }
         const int j = __builtin_ctzll(pending);
         pending &= pending - 1;
         const int r1 = ReadLaneI(ra, j);
         const int r2 = ReadLaneI(rb, j);
         if (r1 == r2) { if (lane == 0) ++dbg_internal; continue; }   // became internal
         if (lane == 0) { ++dbg_iters; dbg_hot += (r1 == hot || r2 == hot); }
-        // ---- fast path: the hot region meets a plain partner smaller than itself -------------
-        // Same arithmetic as DecideEdge/MergeStates for this case (Case U; the hot region keeps
-        // its flags and constraint; the partner carries no mark), without the generic
-        // bookkeeping: 4 state readlanes, one parent store, ids renamed in place.
-        {
-          const bool h1 = (r1 == hot), h2 = (r2 == hot);
-          if ((h1 != h2) && !(H.flags & kFlagNoDesc) && (((h1 ? ok_b : ok_a) >> j) & 1ull)) {
-            float p0, p1, p2;
-            int psz;
-            if (h1) {
-              p0 = ReadLaneF(B.d0, j); p1 = ReadLaneF(B.d1, j); p2 = ReadLaneF(B.d2, j);
-              psz = ReadLaneI(B.sz, j);
-            } else {
-              p0 = ReadLaneF(A.d0, j); p1 = ReadLaneF(A.d1, j); p2 = ReadLaneF(A.d2, j);
-              psz = ReadLaneI(A.sz, j);
-            }
-            if (H.sz > psz) {
-              int fast = 0;   // 1 merge, 2 keep
-              if (!(H.flags & kFlagFinalized)) {
-                const float x = H.d0 - p0, y = H.d1 - p1, z = H.d2 - p2;
-                if ((x * x + y * y + z * z) * (1.0f / 3.0f) <= T.pass_s) {
-                  fast = 1;
-                  ++n_regular;
-                }
-              } else if (psz < T.min_size || H.sz < T.min_size) {
-                fast = 1;
-                ++n_small;
-              } else {
-                fast = 2;
-              }
-              if (fast == 1) {
-                const float denom = 1.0f / (float)(psz + H.sz);
-                const float ca = (float)psz * denom;
-                const float cb = (float)H.sz * denom;
-                H.d0 = ca * p0 + cb * H.d0;
-                H.d1 = ca * p1 + cb * H.d1;
-                H.d2 = ca * p2 + cb * H.d2;
-                H.sz += psz;
-                const int pid = h1 ? r2 : r1;
-                if (lane == j) nodes.parent[pid] = hot;
-                if (ra == pid) ra = hot;
-                if (rb == pid) rb = hot;
-                continue;
-              }
-              if (fast == 2) {
-                if (lane == j) my_kept = true;
-                continue;
-              }
-            }
-          }
-        }
         RState s1, s2;
         if (r1 == hot) s1 = H; else s1 = ReadLaneState(A, j);
         if (r2 == hot) s2 = H; else s2 = ReadLaneState(B, j);
@@ -697,9 +703,9 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
           if (ra == lose) ra = win;
           if (rb == lose) rb = win;
         }
-        // the generic path may have refreshed lane copies: re-derive the partner masks
-        ok_a = __ballot(A.cons < 0 && A.flags == 0);
-        ok_b = __ballot(B.cons < 0 && B.flags == 0);
+        // the generic path may have refreshed lane copies: re-derive the partner flags
+        ok_a = (A.cons < 0 && A.flags == 0);
+        ok_b = (B.cons < 0 && B.flags == 0);
       }
       if (valid && my_kept) kept_all[gpos] = 1;
       // Make this batch's stores visible to the next batch's loads (same CU: L1 is shared).
