@@ -290,7 +290,14 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   timings_.optimistic_stages = optimistic_stages_;
   timings_.rollbacks = rollbacks_;
   LaunchKeepVirtualBucket(list_desc_dev_.get(), L, stream_);
+  VSG_HIP(hipStreamSynchronize(stream_));
+  const double t_buckets = NowMs();
   if (force_constraints && has_constraints_) MergeConstrainedHostAssisted();
+  const double t_mc = NowMs();
+  if (getenv("VSG_DEBUG_STATS")) {
+    std::fprintf(stderr, "[vsg] segment: buckets %.1f ms, merge-constrained %.1f ms\n",
+                 t_buckets - t0, t_mc - t_buckets);
+  }
   unsigned long long st[24] = {0};
   D2H(st, stats_.get(), 24, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
@@ -516,7 +523,7 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
     }
   }   // ids is sorted, so extra is sorted
   {
-    size_t ia = 0, ib = 0;
+    size_t ia = 0, ib = 0, ip = 0;   // ip: moving pointer into the sorted representative ids
     int noop_root = -1;   // representative whose plain member visits are currently no-ops
     while (ia < nv_nodes.size() || ib < extra.size()) {
       int node, r0;
@@ -529,9 +536,10 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
         r0 = node;
         ++ib;
       }
-      auto self = sim.find(node);
-      if (self != sim.end()) {
-        if (self->second.cons < 0) continue;   // region->constraint_id < 0
+      while (ip < ids.size() && ids[ip] < node) ++ip;
+      const bool is_rep = ip < ids.size() && ids[ip] == node;
+      if (is_rep) {
+        if (sim.at(node).cons < 0) continue;   // region->constraint_id < 0
       } else if (r0 == noop_root) {
         continue;   // same state, same input as the previous no-op visit
       }
@@ -601,8 +609,6 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* host_flows, b
 
   // 1. representative key per node (FlattenUnionFind).
   LaunchFlatten(nodes(), N, label_uf_.get(), stream_);
-  label_uf_host_.resize(N);
-  D2H(label_uf_host_.data(), label_uf_.get(), N, stream_);
   VSG_HIP(hipMemcpyAsync(label_img_.get(), label_uf_.get(), N * sizeof(int32_t),
                          hipMemcpyDeviceToDevice, stream_));
   VSG_HIP(hipMemsetAsync(adjust_.get(), 0, N * sizeof(int32_t), stream_));
@@ -744,15 +750,75 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* host_flows, b
     const bool have_flows = host_flows != nullptr;
     if (have_flows) flows = *host_flows;
     const int num_regions = (int)regions_.size();
-    TubeResult tr;
+    // Phase A (pure host, per region): split into tubes.  Only regions that really split need
+    // the representative of their tubes' first pixel, so those few node labels are gathered from
+    // the device afterwards instead of copying the whole label volume.
+    std::vector<std::pair<int, TubeResult>> split;
+    {
+      TubeResult tr;
+      for (int r = 0; r < num_regions; ++r) {
+        if (!regions_[r].has_raster) continue;
+        SplitRegionIntoTubes(regions_[r].raster, W_, H_, flows, have_flows, &tr);
+        if (tr.tubes.size() <= 1) continue;
+        split.emplace_back(r, TubeResult());
+        split.back().second.tubes.swap(tr.tubes);
+        split.back().second.areas.swap(tr.areas);
+        split.back().second.tube_to_keep = tr.tube_to_keep;
+      }
+    }
+    auto first_node_of = [&](const Raster3D& tube) {
+      const RasterSlice& s0 = tube[0];
+      return (int32_t)((size_t)s0.frame * wh_ + (size_t)s0.raster[0].y * W_ + s0.raster[0].lx);
+    };
+    auto fetch_labels = [&](const std::vector<int32_t>& node_ids, std::vector<int32_t>* keys) {
+      const int m = (int)node_ids.size();
+      keys->resize(m);
+      if (m == 0) return;
+      small_i32_a_.ensure((size_t)m);
+      small_i32_b_.ensure((size_t)m);
+      H2D(small_i32_a_.get(), node_ids.data(), (size_t)m, stream_);
+      LaunchGatherI32(label_uf_.get(), small_i32_a_.get(), m, small_i32_b_.get(), stream_);
+      D2H(keys->data(), small_i32_b_.get(), (size_t)m, stream_);
+      VSG_HIP(hipStreamSynchronize(stream_));
+    };
+    std::vector<int32_t> first_nodes, first_keys;
+    std::vector<size_t> key_offset(split.size());
+    for (size_t si = 0; si < split.size(); ++si) {
+      key_offset[si] = first_nodes.size();
+      for (auto& tube : split[si].second.tubes) first_nodes.push_back(first_node_of(tube));
+    }
+    fetch_labels(first_nodes, &first_keys);
+    // Phase B: bookkeeping in the reference's order (region, then tube).  The reference looks the
+    // tube's representative up through the union-find of its first pixel, which after an N4 swap
+    // can belong to ANOTHER region whose rasterization is then replaced (reference behaviour,
+    // kept); if that region is still to be visited its tube split is recomputed at its turn.
+    std::vector<char> dirty((size_t)num_regions, 0);
+    size_t si = 0;
     for (int r = 0; r < num_regions; ++r) {
-      if (!regions_[r].has_raster) continue;
-      SplitRegionIntoTubes(regions_[r].raster, W_, H_, flows, have_flows, &tr);
-      if (tr.tubes.size() <= 1) continue;
+      TubeResult local;
+      TubeResult* trp = nullptr;
+      std::vector<int32_t> keys;
+      const bool cached = si < split.size() && split[si].first == r;
+      if (dirty[r]) {
+        if (cached) ++si;
+        if (!regions_[r].has_raster) continue;
+        SplitRegionIntoTubes(regions_[r].raster, W_, H_, flows, have_flows, &local);
+        if (local.tubes.size() <= 1) continue;
+        std::vector<int32_t> nodes_needed;
+        for (auto& tube : local.tubes) nodes_needed.push_back(first_node_of(tube));
+        fetch_labels(nodes_needed, &keys);
+        trp = &local;
+      } else if (cached) {
+        trp = &split[si].second;
+        keys.assign(first_keys.begin() + key_offset[si],
+                    first_keys.begin() + key_offset[si] + trp->tubes.size());
+        ++si;
+      } else {
+        continue;
+      }
+      TubeResult& tr = *trp;
       for (int k = 0; k < (int)tr.tubes.size(); ++k) {
-        const RasterSlice& s0 = tr.tubes[k][0];
-        const size_t first_idx = (size_t)s0.frame * wh_ + (size_t)s0.raster[0].y * W_ + s0.raster[0].lx;
-        int rep_key = label_uf_host_[first_idx];
+        int rep_key = keys[k];
         if (k != tr.tube_to_keep) {
           int& adj = size_adjust[rep_key];
           adj = (int)((float)adj - tr.areas[k]);   // int -= float
@@ -787,6 +853,7 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* host_flows, b
         } else {
           idx = it->second;
         }
+        if (idx != r && idx > r && idx < num_regions) dirty[idx] = 1;
         regions_[idx].has_raster = true;
         regions_[idx].raster.swap(tr.tubes[k]);
       }
@@ -899,6 +966,11 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* host_flows, b
     ri.neighbors.erase(std::unique(ri.neighbors.begin(), ri.neighbors.end()), ri.neighbors.end());
   }
   const double t_end = NowMs();
+  if (getenv("VSG_DEBUG_STATS")) {
+    std::fprintf(stderr, "[vsg] readout: device1 %.1f host1 %.1f device2 %.1f host2 %.1f ms (intervals %d, pairs %d, unique %zu)\n",
+                 t_dev1 - t_start, t_host1 - t_dev1, t_dev2 - t_host1, t_end - t_dev2, num_iv, count,
+                 uniq.size());
+  }
   timings_.readout_ms = (float)((t_dev1 - t_start) + (t_dev2 - t_host1));
   timings_.host_post_ms = (float)((t_host1 - t_dev1) + (t_end - t_dev2));
 }

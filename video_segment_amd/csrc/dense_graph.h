@@ -127,7 +127,6 @@ class DenseGraphHip {
   DevBuf<unsigned long long> pairs_, order_keys_, pairs_sorted_, pairs_unique_;
   DevBuf<int32_t> small_i32_a_, small_i32_b_, small_i32_c_;
   DevBuf<float4> small_f4_;
-  std::vector<int32_t> label_uf_host_;
   std::vector<hipEvent_t> ev_pool_;
   std::vector<std::pair<int, int>> ev_wave_, ev_filter_;
   int ev_used_ = 0;

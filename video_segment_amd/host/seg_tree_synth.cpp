@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 
+#include "segmentation_io.h"
 #include "segmentation_unit.h"
 
 using namespace video_framework;
@@ -134,7 +135,7 @@ class HashSinkUnit : public VideoUnit {
 
 int main(int argc, char** argv) {
   int width = 64, height = 48, frames = 45, chunk = 20, flow = 1, device = -1;
-  std::string input = "probe";
+  std::string input = "probe", write_to_file;
   for (int i = 1; i + 1 < argc; i += 2) {
     const std::string k = argv[i];
     const char* v = argv[i + 1];
@@ -145,6 +146,7 @@ int main(int argc, char** argv) {
     else if (k == "--flow") flow = atoi(v);
     else if (k == "--input") input = v;
     else if (k == "--device") device = atoi(v);
+    else if (k == "--write_to_file") write_to_file = v;   // seg_tree.cpp:65
     else {
       std::fprintf(stderr, "unknown flag %s\n", k.c_str());
       return 2;
@@ -160,6 +162,13 @@ int main(int argc, char** argv) {
   HashSinkUnit sink;
   dense_unit.AttachTo(&source);
   sink.AttachTo(&dense_unit);
+  std::unique_ptr<SegmentationWriterUnit> writer;
+  if (!write_to_file.empty()) {   // seg_tree.cpp:296-312
+    SegmentationWriterUnitOptions wo;
+    wo.filename = write_to_file;
+    writer.reset(new SegmentationWriterUnit(wo));
+    writer->AttachTo(&sink);
+  }
 
   if (!source.PrepareProcessing()) {
     std::fprintf(stderr, "ERROR: setup failed\n");

@@ -1,0 +1,66 @@
+// segmentation_io.h -- writer for the reference's chunked segmentation container
+// (segment_util/segmentation_io.h:31-66, segmentation_io.cpp:46-154) and the unit that feeds it
+// (SegmentationWriterUnit, segmentation/segmentation_unit.cpp:333-415), so that the HIP path's
+// output is a file-level drop-in for segment_converter / segment_renderer / segment_viewer.
+//
+//   HEAD  int32 M, int32 flags[M]            flags = {use_vectorization = 1, shape_moments = 0}
+//   CHNK  int32 id, int32 N, int64 offs[N], int64 pts[N], int64 next_header_offset
+//   N x   SEGD  int32 size, bytes[size]      serialized SegmentationDesc
+//   TERM  int32 number_of_chunks
+#ifndef VSG_HOST_SEGMENTATION_IO_H_
+#define VSG_HOST_SEGMENTATION_IO_H_
+
+#include <cstdint>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "segmentation_unit.h"
+
+namespace segmentation {
+
+class SegmentationWriter {
+ public:
+  explicit SegmentationWriter(const std::string& filename) : filename_(filename) {}
+  bool OpenFile(const std::vector<int>& header_entries = std::vector<int>());
+  void AddSegmentationDataToChunk(const std::string& data, int64_t pts = 0);
+  void WriteChunk();
+  void WriteTermHeaderAndClose();
+
+ private:
+  std::string filename_;
+  std::ofstream ofs_;
+  std::vector<int> header_entries_;
+  int32_t num_chunks_ = 0;
+  int64_t curr_offset_ = 0;
+  int total_frames_ = 0;
+  std::vector<int64_t> file_offsets_, time_stamps_;
+  std::vector<std::string> chunk_buffer_;
+};
+
+struct SegmentationWriterUnitOptions {
+  std::string video_stream_name = "VideoStream";
+  std::string segment_stream_name = "SegmentationStream";
+  std::string filename;
+};
+
+// Like the reference's unit, frames are only buffered while streaming and the whole video is
+// written as ONE chunk when the stream ends.
+class SegmentationWriterUnit : public VideoUnit {
+ public:
+  explicit SegmentationWriterUnit(const SegmentationWriterUnitOptions& options)
+      : options_(options), writer_(options.filename) {}
+  bool OpenStreams(StreamSet* set) override;
+  void ProcessFrame(FrameSetPtr input, std::list<FrameSetPtr>* output) override;
+  bool PostProcess(std::list<FrameSetPtr>* append) override;
+
+ private:
+  SegmentationWriterUnitOptions options_;
+  SegmentationWriter writer_;
+  int seg_stream_idx_ = -1;
+  int frame_number_ = 0;
+};
+
+}  // namespace segmentation
+
+#endif  // VSG_HOST_SEGMENTATION_IO_H_
