@@ -56,7 +56,7 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   keys_sorted_tmp_.alloc(9 * wh_);
   vals_tmp_.alloc(9 * wh_);
   scalars_.alloc(16);
-  stats_.alloc(24);
+  stats_.alloc(32);
   size_t temp = SortPairsU16TempBytes((int)(9 * wh_));
   temp = std::max(temp, ScanTempBytes((int)N));
   cub_temp_.alloc(temp);
@@ -203,7 +203,7 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   LaunchBuildBucketTable(list_desc_dev_.get(), L, bucket_base_dev_.get(), stream_);
   bucket_base_host_.resize((size_t)(kNumBuckets + 1) * (L + 1));
   D2H(bucket_base_host_.data(), bucket_base_dev_.get(), bucket_base_host_.size(), stream_);
-  VSG_HIP(hipMemsetAsync(stats_.get(), 0, 24 * sizeof(unsigned long long), stream_));
+  VSG_HIP(hipMemsetAsync(stats_.get(), 0, 32 * sizeof(unsigned long long), stream_));
   LaunchInitIdentity(cc_.get(), N, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
 
@@ -238,6 +238,8 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   S.bk_cons = bk_cons_.get();
   S.bk_flags = bk_flags_.get();
   S.force_rollback = getenv("VSG_FORCE_ROLLBACK") ? 1 : 0;
+  S.wave_v1 = getenv("VSG_WAVE_V1") ? 1 : 0;
+  S.wave_dbg = getenv("VSG_WAVE_DBG") ? atoi(getenv("VSG_WAVE_DBG")) : 0;
   optimistic_stages_ = 0;
   rollbacks_ = 0;
   S.optimistic_stages = &optimistic_stages_;
@@ -280,12 +282,42 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   const double t0 = NowMs();
   int inert_mode = has_constraints_ ? 2 : 1;
   if (const char* e = getenv("VSG_INERT_MODE")) inert_mode = std::min(inert_mode, atoi(e));
+  const bool debug_stages = getenv("VSG_DEBUG_STAGES") != nullptr;
   for (int b = 0; b < kNumBuckets; ++b) {
     const int n_b = bucket_base_host_[(size_t)b * (L + 1) + L];
     if (n_b == 0) continue;
+    unsigned long long s0[32] = {0}, s1[32] = {0};
+    double ts = 0;
+    size_t ev0 = 0;
+    if (debug_stages) {
+      VSG_HIP(hipMemsetAsync(stats_.get() + 16, 0, 2 * sizeof(unsigned long long), stream_));
+      D2H(s0, stats_.get(), 32, stream_);
+      VSG_HIP(hipStreamSynchronize(stream_));
+      ts = NowMs();
+      ev0 = ev_wave_.size();
+    }
     RunBucketStage(b, n_b, list_desc_dev_.get(), bucket_base_dev_.get(),
                    list_slot_base_dev_.get(), kept_all_.get(), nodes(), P, inert_mode, S,
                    stream_);
+    if (debug_stages) {
+      D2H(s1, stats_.get(), 32, stream_);
+      VSG_HIP(hipStreamSynchronize(stream_));
+      const double te = NowMs();
+      float wave_ms = 0;
+      for (size_t k = ev0; k < ev_wave_.size(); ++k) {
+        float ms = 0;
+        VSG_HIP(hipEventElapsedTime(&ms, ev_pool_[ev_wave_[k].first], ev_pool_[ev_wave_[k].second]));
+        wave_ms += ms;
+      }
+      if (te - ts > 1.0) {
+        std::fprintf(stderr, "[vsg] stage b=%d n_b=%d wall %.2f ms wave %.2f ms | wave edges %llu batches %llu "
+                     "rounds %llu nwin %llu (solo %llu) chain %llu cuts %llu | max_seg %llu slowest %.2f Mcyc | "
+                     "cyc load %.1f M loop %.1f M\n",
+                     b, n_b, te - ts, wave_ms, s1[3] - s0[3], s1[7] - s0[7], s1[5] - s0[5],
+                     s1[4] - s0[4], s1[6] - s0[6], s1[20] - s0[20], s1[21] - s0[21], s1[17],
+                     s1[16] / 1e6, (s1[18] - s0[18]) / 1e6, (s1[19] - s0[19]) / 1e6);
+      }
+    }
   }
   timings_.optimistic_stages = optimistic_stages_;
   timings_.rollbacks = rollbacks_;
@@ -301,10 +333,12 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   unsigned long long st[24] = {0};
   D2H(st, stats_.get(), 24, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
+  if (st[23] != 0) std::fprintf(stderr, "[vsg] chain self check: %llu mismatches\n", st[23]);
+  if (st[22] != 0) throw Error(-4 /* VSG_ERR_INTERNAL */, "merge worker: a batch did not converge");
   if (getenv("VSG_DEBUG_STATS")) {
-    std::fprintf(stderr, "[vsg] wave: edges %llu batches %llu iters %llu hot-hits %llu internal %llu; "
-                 "optimistic stages %lld rollbacks %lld\n",
-                 st[3], st[7], st[4], st[5], st[6], (long long)optimistic_stages_,
+    std::fprintf(stderr, "[vsg] wave: edges %llu batches %llu rounds %llu generic %llu (solo %llu) chain %llu "
+                 "cuts %llu; optimistic stages %lld rollbacks %lld\n",
+                 st[3], st[7], st[5], st[4], st[6], st[20], st[21], (long long)optimistic_stages_,
                  (long long)rollbacks_);
   }
   timings_.merge_ms = (float)(NowMs() - t0);

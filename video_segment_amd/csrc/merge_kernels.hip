@@ -329,6 +329,22 @@ __global__ __launch_bounds__(256) void k_reset_cc(int n, const int32_t* __restri
   cc[rb] = rb;
 }
 
+// Active edges in component order (contiguous input of the workers).
+__global__ __launch_bounds__(256) void k_gather_sorted(int n, const uint32_t* __restrict__ s_idx,
+                                                        const int32_t* __restrict__ a_ra,
+                                                        const int32_t* __restrict__ a_rb,
+                                                        const uint32_t* __restrict__ a_gpos,
+                                                        int32_t* __restrict__ s_ra,
+                                                        int32_t* __restrict__ s_rb,
+                                                        uint32_t* __restrict__ s_gpos) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t i = s_idx[p];
+  s_ra[p] = a_ra[i];
+  s_rb[p] = a_rb[i];
+  s_gpos[p] = a_gpos[i];
+}
+
 // ------------------------------------------------------------------------------------------
 // Exact edge semantics on plain values (shared by the lane and the wave worker).
 // ------------------------------------------------------------------------------------------
@@ -453,10 +469,9 @@ constexpr int kSmallSegment = 24;   // components with more active edges go to a
 __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__ num_segs,
                                                       const int32_t* __restrict__ seg_off,
                                                       const int32_t* __restrict__ seg_cnt,
-                                                      const uint32_t* __restrict__ s_idx,
-                                                      const int32_t* __restrict__ a_ra,
-                                                      const int32_t* __restrict__ a_rb,
-                                                      const uint32_t* __restrict__ a_gpos,
+                                                      const int32_t* __restrict__ s_ra,
+                                                      const int32_t* __restrict__ s_rb,
+                                                      const uint32_t* __restrict__ s_gpos,
                                                       NodeArrays nodes, uint8_t* __restrict__ kept_all,
                                                       StageThr T, int optimistic,
                                                       int32_t* __restrict__ violation,
@@ -468,13 +483,12 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
     if (cnt <= kSmallSegment) {
       const int beg = seg_off[seg];
       for (int p = beg; p < beg + cnt; ++p) {
-        const uint32_t i = s_idx[p];
         // An optimistic stage must stay undoable from the backed-up region states alone, so it
         // does not compress paths.
-        const int r1 = optimistic ? FindReadOnly(nodes.parent, a_ra[i])
-                                  : FindCompress(nodes.parent, a_ra[i]);
-        const int r2 = optimistic ? FindReadOnly(nodes.parent, a_rb[i])
-                                  : FindCompress(nodes.parent, a_rb[i]);
+        const int r1 = optimistic ? FindReadOnly(nodes.parent, s_ra[p])
+                                  : FindCompress(nodes.parent, s_ra[p]);
+        const int r2 = optimistic ? FindReadOnly(nodes.parent, s_rb[p])
+                                  : FindCompress(nodes.parent, s_rb[p]);
         if (r1 == r2) continue;
         RState s1 = LoadState(nodes, r1);
         RState s2 = LoadState(nodes, r2);
@@ -491,7 +505,7 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
         n_regular += (stat == 2);
         n_small += (stat == 3);
         if (out == kOutKeep) {
-          kept_all[a_gpos[i]] = 1;
+          kept_all[s_gpos[p]] = 1;
           StoreState(nodes, r1, s1);
           StoreState(nodes, r2, s2);
         } else if (out == kOutMerge1) {
@@ -545,13 +559,12 @@ __device__ __forceinline__ bool SameState(const RState& a, const RState& b) {
 // only when another region becomes hot or the component is finished.  Lane copies of a region are
 // refreshed (12 v_cndmask) only when it stops being hot or on the rare flag/constraint change, so
 // a chain step costs two id readlanes, six state readlanes, the decision and one parent store.
-__global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ num_segs,
-                                                    const int32_t* __restrict__ seg_off,
-                                                    const int32_t* __restrict__ seg_cnt,
-                                                    const uint32_t* __restrict__ s_idx,
-                                                    const int32_t* __restrict__ a_ra,
-                                                    const int32_t* __restrict__ a_rb,
-                                                    const uint32_t* __restrict__ a_gpos,
+__global__ __launch_bounds__(64) void k_merge_wave_v1(const int32_t* __restrict__ num_segs,
+                                                       const int32_t* __restrict__ seg_off,
+                                                       const int32_t* __restrict__ seg_cnt,
+                                                       const int32_t* __restrict__ s_ra,
+                                                       const int32_t* __restrict__ s_rb,
+                                                       const uint32_t* __restrict__ s_gpos,
                                                     NodeArrays nodes, uint8_t* __restrict__ kept_all,
                                                     StageThr T, int optimistic,
                                                     int32_t* __restrict__ violation,
@@ -559,13 +572,16 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
   const int lane = threadIdx.x;
   const int nseg = *num_segs;
   unsigned n_forced = 0, n_regular = 0, n_small = 0;   // counted on lane 0 (uniform decisions)
-  unsigned dbg_iters = 0, dbg_hot = 0, dbg_internal = 0, dbg_batches = 0;
+  unsigned dbg_iters = 0, dbg_hot = 0, dbg_internal = 0, dbg_batches = 0, dbg_chain = 0;
+  unsigned long long cyc_load = 0, cyc_loop = 0;
+  unsigned dbg_g[6] = {0, 0, 0, 0, 0, 0};
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int cnt = seg_cnt[seg];
     if (cnt <= kSmallSegment) continue;
     const int beg = seg_off[seg];
     const int end = beg + cnt;
     if (lane == 0) atomicAdd(&stats[3], (unsigned long long)cnt);
+    const unsigned long long seg_t0 = __builtin_readcyclecounter();
     int hot = -1;          // wave-uniform
     RState H = {};         // wave-uniform state of region `hot` (authoritative while hot >= 0)
     for (int base = beg; base < end; base += 64) {
@@ -574,11 +590,11 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
       int ra = -1, rb = -2;
       uint32_t gpos = 0;
       RState A = {}, B = {};
+      const unsigned long long bt0 = __builtin_readcyclecounter();
       if (valid) {
-        const uint32_t i = s_idx[p];
-        ra = optimistic ? FindReadOnly(nodes.parent, a_ra[i]) : FindCompress(nodes.parent, a_ra[i]);
-        rb = optimistic ? FindReadOnly(nodes.parent, a_rb[i]) : FindCompress(nodes.parent, a_rb[i]);
-        gpos = a_gpos[i];
+        ra = optimistic ? FindReadOnly(nodes.parent, s_ra[p]) : FindCompress(nodes.parent, s_ra[p]);
+        rb = optimistic ? FindReadOnly(nodes.parent, s_rb[p]) : FindCompress(nodes.parent, s_rb[p]);
+        gpos = s_gpos[p];
         if (ra != rb) {
           A = LoadState(nodes, ra);
           B = LoadState(nodes, rb);
@@ -591,6 +607,8 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
       bool ok_a = (A.cons < 0 && A.flags == 0);
       bool ok_b = (B.cons < 0 && B.flags == 0);
       if (lane == 0) ++dbg_batches;
+      const unsigned long long bt1 = __builtin_readcyclecounter();
+      cyc_load += bt1 - bt0;
       while (pending) {
         // ---- tight chain loop: the hot region absorbs plain partners smaller than itself ------
         // Every lane keeps a "partner view" relative to the hot region (which of its two regions
@@ -630,7 +648,7 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
               n_small += merge;
             }
             pending &= pending - 1;
-            if (lane == 0) { ++dbg_iters; ++dbg_hot; }
+            if (lane == 0) { ++dbg_iters; ++dbg_hot; ++dbg_chain; }
             if (merge) {
               const float denom = 1.0f / (float)(psz + H.sz);
               const float ca = (float)psz * denom;
@@ -658,6 +676,21 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
         RState s1, s2;
         if (r1 == hot) s1 = H; else s1 = ReadLaneState(A, j);
         if (r2 == hot) s2 = H; else s2 = ReadLaneState(B, j);
+        if (lane == 0) {   // debug classification of the generic iterations
+          const bool h1 = (r1 == hot), h2 = (r2 == hot);
+          const bool pl1 = (s1.cons < 0 && s1.flags == 0), pl2 = (s2.cons < 0 && s2.flags == 0);
+          if (!h1 && !h2) {
+            ++dbg_g[0];
+            if (pl1 && pl2) ++dbg_g[4];
+            if (s1.sz == 1 && s2.sz == 1) ++dbg_g[5];
+          } else {
+            const bool ppl = h1 ? pl2 : pl1;
+            const int psz = h1 ? s2.sz : s1.sz;
+            if (!ppl) ++dbg_g[1];
+            else if (!(H.sz > psz)) ++dbg_g[2];
+            else ++dbg_g[3];
+          }
+        }
         const RState o1 = s1, o2 = s2;
         int stat;
         const int out = DecideEdge(s1, s2, T, stat);
@@ -714,6 +747,11 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
       // write it back here once per batch (one 21-byte store) instead of once per merge.
       if (hot >= 0 && lane == 0) StoreState(nodes, hot, H);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      cyc_loop += __builtin_readcyclecounter() - bt1;
+    }
+    if (lane == 0) {
+      atomicMax(&stats[16], __builtin_readcyclecounter() - seg_t0);   // slowest component
+      atomicMax(&stats[17], (unsigned long long)cnt);                 // largest component
     }
   }
   if (lane == 0) {
@@ -724,6 +762,483 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
     atomicAdd(&stats[5], (unsigned long long)dbg_hot);
     atomicAdd(&stats[6], (unsigned long long)dbg_internal);
     atomicAdd(&stats[7], (unsigned long long)dbg_batches);
+    atomicAdd(&stats[18], cyc_load);
+    atomicAdd(&stats[19], cyc_loop);
+    atomicAdd(&stats[20], (unsigned long long)dbg_chain);
+    for (int k = 0; k < 6; ++k) atomicAdd(&stats[24 + k], (unsigned long long)dbg_g[k]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Worker B: one wavefront replays one large component, 64 edges per batch, in *rounds*.
+// ------------------------------------------------------------------------------------------
+// A lone wavefront issues roughly one instruction every 4-8 cycles, so replaying the 64 edges of
+// a batch one after the other (k_merge_wave_v1, ~130 instructions per edge) leaves the stage bound
+// by its largest component.  This worker keeps the regions of the batch in an LDS table and
+// commits as many edges per round as the sequential semantics allow:
+//
+//   * every pending lane reserves its two regions with its lane number (ds_min); a lane that
+//     holds both reservations is the earliest pending edge on both regions, so executing it now
+//     is what the sequential replay would do (deterministic reservations).  All such lanes run
+//     DecideEdge at once, each on its own pair of regions;
+//   * the region most edges of the batch touch is the batch's *hot* region and is not reserved.
+//     The leading run of pending hot edges whose partner is a plain region (unconstrained,
+//     unflagged) smaller than the hot region is committed as one *chain*: under the speculation
+//     that every merge test passes, the sizes are a prefix sum and the weights ca/cb and the
+//     products ca*p are lane-parallel; only  h = ca*p + cb*h  (two flops per channel) is replayed
+//     in order, recording the pre-merge mean per lane, and the merge tests are then verified by
+//     all lanes at once.  The chain is cut at the first failed test and that lane is replayed
+//     by the generic code in the next round, so the result is exactly the sequential one;
+//   * the first pending hot edge that does not qualify for the chain runs alone (generic code).
+//
+// The earliest pending lane always commits, so a batch takes at most 64 rounds.
+constexpr int kTabSize = 256;     // >= 2 * 128 distinct regions of a batch at load factor 1/2
+constexpr int kTabDirty = 0x100;
+
+struct WaveTable {
+  int32_t key[kTabSize];     // region id, -1: empty
+  int32_t link[kTabSize];    // in-batch union-find over slots
+  uint32_t res[kTabSize];    // reservation: (0xfffff - round) << 6 | lane, smaller wins
+  int32_t cnt[kTabSize];     // number of pending endpoints on the slot at batch start
+  float4 ds[kTabSize];
+  int32_t cons[kTabSize];
+  int32_t flags[kTabSize];   // region flags | kTabDirty
+};
+
+__device__ __forceinline__ int TabInsert(WaveTable& t, int r, bool& inserted) {
+  unsigned h = ((unsigned)r * 2654435761u) >> 24;
+  for (;;) {
+    const int old = atomicCAS(&t.key[h], -1, r);
+    if (old == -1) { inserted = true; return (int)h; }
+    if (old == r) { inserted = false; return (int)h; }
+    h = (h + 1) & (kTabSize - 1);
+  }
+}
+
+__device__ __forceinline__ int SlotRoot(const WaveTable& t, int s) {
+  int p;
+  while ((p = t.link[s]) != s) s = p;
+  return s;
+}
+
+__device__ __forceinline__ RState TabLoad(const WaveTable& t, int s) {
+  const float4 ds = t.ds[s];
+  RState r;
+  r.d0 = ds.x;
+  r.d1 = ds.y;
+  r.d2 = ds.z;
+  r.sz = __float_as_int(ds.w);
+  r.cons = t.cons[s];
+  r.flags = t.flags[s] & 0xff;
+  return r;
+}
+
+__device__ __forceinline__ void TabStore(WaveTable& t, int s, const RState& r, int dirty) {
+  t.ds[s] = make_float4(r.d0, r.d1, r.d2, __int_as_float(r.sz));
+  t.cons[s] = r.cons;
+  t.flags[s] = r.flags | dirty;
+}
+
+constexpr int kFill = 4;        // 64-edge chunks read per fill
+constexpr int kQueue = 512;     // ring capacity >= 63 + kFill * 64, power of two
+
+struct WaveQueue {
+  int32_t ra[kQueue];
+  int32_t rb[kQueue];
+  uint32_t gpos[kQueue];
+};
+
+__global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ num_segs,
+                                                    const int32_t* __restrict__ seg_off,
+                                                    const int32_t* __restrict__ seg_cnt,
+                                                    const int32_t* __restrict__ s_ra,
+                                                    const int32_t* __restrict__ s_rb,
+                                                    const uint32_t* __restrict__ s_gpos,
+                                                    NodeArrays nodes, uint8_t* __restrict__ kept_all,
+                                                    StageThr T, int optimistic,
+                                                    int32_t* __restrict__ violation,
+                                                    unsigned long long* __restrict__ stats,
+                                                    int dbg_flags) {
+  __shared__ WaveTable tab;
+  __shared__ WaveQueue queue;
+  const int lane = threadIdx.x;
+  for (int s = lane; s < kTabSize; s += 64) {
+    tab.key[s] = -1;
+    tab.res[s] = 0xffffffffu;
+    tab.cnt[s] = 0;
+  }
+  __syncthreads();
+  const int nseg = *num_segs;
+  unsigned n_forced = 0, n_regular = 0, n_small = 0;   // per lane, reduced at the end
+  unsigned dbg_rounds = 0, dbg_nwin = 0, dbg_chain = 0, dbg_solo = 0, dbg_batches = 0, dbg_cut = 0;
+  unsigned long long cyc_load = 0, cyc_loop = 0;
+  for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const int cnt = seg_cnt[seg];
+    if (cnt <= kSmallSegment) continue;
+    const int beg = seg_off[seg];
+    const int end = beg + cnt;
+    if (lane == 0) atomicAdd(&stats[3], (unsigned long long)cnt);
+    const unsigned long long seg_t0 = __builtin_readcyclecounter();
+    // Edges whose two ends already share a region are dropped when they are read (a large share
+    // of a component's edges once its regions have grown), 256 edges per fill with all root
+    // searches in flight together; the surviving edges wait in an LDS ring and are replayed 64 at
+    // a time, so the fixed cost of a batch is spent on pending edges only.
+    int qn = 0, qhead = 0, next = beg;   // wave-uniform
+    while (next < end || qn > 0) {
+      const unsigned long long bt0 = __builtin_readcyclecounter();
+      if (qn < 64 && next < end) {
+        int xa[kFill], xb[kFill], ca[kFill], cb[kFill];
+        uint32_t gp[kFill];
+        bool vd[kFill];
+#pragma unroll
+        for (int k = 0; k < kFill; ++k) {
+          const int p = next + k * 64 + lane;
+          vd[k] = p < end;
+          xa[k] = vd[k] ? s_ra[p] : 0;
+          xb[k] = vd[k] ? s_rb[p] : 0;
+          gp[k] = vd[k] ? s_gpos[p] : 0u;
+          ca[k] = xa[k];
+          cb[k] = xb[k];
+        }
+        for (bool any = true; any;) {   // all root searches of the fill advance together
+          int pa[kFill], pb[kFill];
+#pragma unroll
+          for (int k = 0; k < kFill; ++k) {
+            pa[k] = nodes.parent[ca[k]];
+            pb[k] = nodes.parent[cb[k]];
+          }
+          any = false;
+#pragma unroll
+          for (int k = 0; k < kFill; ++k) {
+            if (pa[k] != ca[k]) { ca[k] = pa[k]; any = true; }
+            if (pb[k] != cb[k]) { cb[k] = pb[k]; any = true; }
+          }
+        }
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int k = 0; k < kFill; ++k) {
+          if (!optimistic) {   // an optimistic stage must stay undoable: no path compression
+            if (vd[k] && ca[k] != xa[k]) nodes.parent[xa[k]] = ca[k];
+            if (vd[k] && cb[k] != xb[k]) nodes.parent[xb[k]] = cb[k];
+          }
+          const bool pend = vd[k] && ca[k] != cb[k];
+          const unsigned long long m = __ballot(pend);
+          if (pend) {
+            const int slot = (qhead + qn + (int)__popcll(m & lt)) & (kQueue - 1);
+            queue.ra[slot] = ca[k];
+            queue.rb[slot] = cb[k];
+            queue.gpos[slot] = gp[k];
+          }
+          qn += (int)__popcll(m);
+        }
+        next += kFill * 64;
+        __syncthreads();
+        cyc_load += __builtin_readcyclecounter() - bt0;
+        if (qn < 64 && next < end) continue;
+      }
+      if (qn == 0) break;
+      const unsigned long long bt0b = __builtin_readcyclecounter();
+      // ---- take up to 64 pending edges: current roots, region table --------------------------------
+      const int take = qn < 64 ? qn : 64;
+      const bool valid = lane < take;
+      int ra = -1, rb = -1;
+      uint32_t gpos = 0;
+      if (valid) {
+        const int slot = (qhead + lane) & (kQueue - 1);
+        ra = FindReadOnly(nodes.parent, queue.ra[slot]);
+        rb = FindReadOnly(nodes.parent, queue.rb[slot]);
+        gpos = queue.gpos[slot];
+      }
+      qhead = (qhead + take) & (kQueue - 1);
+      qn -= take;
+      bool pending = valid && ra != rb;
+      int sa = 0, sb = 0;     // table slots of the current roots of the two end regions
+      if (pending) {
+        bool ins;
+        sa = TabInsert(tab, ra, ins);
+        if (ins) {
+          tab.link[sa] = sa;
+          TabStore(tab, sa, LoadState(nodes, ra), 0);
+        }
+        sb = TabInsert(tab, rb, ins);
+        if (ins) {
+          tab.link[sb] = sb;
+          TabStore(tab, sb, LoadState(nodes, rb), 0);
+        }
+        atomicAdd(&tab.cnt[sa], 1);
+        atomicAdd(&tab.cnt[sb], 1);
+      }
+      __syncthreads();
+      int hot = -1;   // wave-uniform slot of the hot region
+      {
+        int best = 0;
+        if (pending) best = max((tab.cnt[sa] << 8) | sa, (tab.cnt[sb] << 8) | sb);
+        for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off));
+        if ((best >> 8) >= 3 && !(dbg_flags & 4)) hot = best & (kTabSize - 1);
+      }
+      if (lane == 0) ++dbg_batches;
+      const unsigned long long bt1 = __builtin_readcyclecounter();
+      cyc_load += bt1 - bt0b;
+
+      bool my_kept = false;
+      bool failed = false;    // this lane's chain test failed: replay it with the generic code
+      for (unsigned round = 0;; ++round) {
+        if (pending) {
+          sa = SlotRoot(tab, sa);
+          sb = SlotRoot(tab, sb);
+          if (sa == sb) pending = false;   // became internal
+        }
+        if (!__ballot(pending)) break;
+        if (round > 70u) {   // cannot happen (the earliest pending lane always commits): report
+          if (lane == 0) atomicAdd(&stats[22], 1ull);
+          break;
+        }
+        if (hot >= 0) hot = SlotRoot(tab, hot);
+        const bool a_hot = (sa == hot), b_hot = (sb == hot);
+        const bool hot_lane = pending && (a_hot || b_hot);
+        const uint32_t key = ((0xfffffu - round) << 6) | (uint32_t)lane;
+        if (pending) {
+          if (!a_hot) atomicMin(&tab.res[sa], key);
+          if (!b_hot) atomicMin(&tab.res[sb], key);
+        }
+        __syncthreads();
+        const uint32_t res_a = pending ? tab.res[sa] : 0u;
+        const uint32_t res_b = pending ? tab.res[sb] : 0u;
+        const bool own = pending && (a_hot || res_a == key) && (b_hot || res_b == key);
+        const unsigned long long hot_mask = __ballot(hot_lane);
+        RState Hs = {}, P = {};
+        int ps = 0;           // partner slot of a hot lane
+        bool elig = false;    // chain lane
+        bool dup = false;     // hot lane whose partner is reserved by an earlier hot lane
+        int owner = 0;
+        if (hot_mask) {
+          Hs = TabLoad(tab, hot);   // uniform
+          ps = a_hot ? sb : sa;
+          const bool mode_ok = !(Hs.flags & kFlagNoDesc) &&
+                               (!(Hs.flags & kFlagFinalized) || Hs.sz >= T.min_size);
+          if (hot_lane && mode_ok) {
+            if (own) {
+              P = TabLoad(tab, ps);
+              elig = !failed && P.cons < 0 && P.flags == 0 && P.sz < Hs.sz && !(dbg_flags & 1);
+            } else if (!(dbg_flags & 2)) {
+              const uint32_t r = a_hot ? res_b : res_a;
+              owner = (int)(r & 63u);
+              dup = true;   // confirmed below: the owner must be a chain lane
+            }
+          }
+          // chain lanes that will merge (a finalized hot region only absorbs small partners)
+          const unsigned long long merge0 =
+              __ballot(elig && (!(Hs.flags & kFlagFinalized) || P.sz < T.min_size));
+          // the owner of a partner slot touches that slot; if it is a hot lane its partner is ps
+          dup = dup && ((hot_mask >> owner) & 1ull) && ((merge0 >> owner) & 1ull);
+        }
+        const unsigned long long elig_mask = __ballot(elig);
+        const unsigned long long dup_mask = __ballot(dup);
+        // A pending edge that shares a region with the partner of a chain lane turns into a hot
+        // edge as soon as that partner is absorbed, so nothing behind it may join the chain.
+        const bool future_hot =
+            pending && !hot_lane &&
+            ((res_a != key && ((elig_mask >> (res_a & 63u)) & 1ull)) ||
+             (res_b != key && ((elig_mask >> (res_b & 63u)) & 1ull)));
+        const unsigned long long blocked =
+            (hot_mask & ~(elig_mask | dup_mask)) | __ballot(future_hot);
+        const unsigned long long prefix =
+            blocked ? ((1ull << __builtin_ctzll(blocked)) - 1ull) : ~0ull;
+        unsigned long long chain_mask = elig_mask & prefix;
+        if (dbg_flags & 32) {   // no jumping over earlier pending lanes
+          const unsigned long long others = __ballot(pending) & ~chain_mask;
+          if (others) chain_mask &= (1ull << __builtin_ctzll(others)) - 1ull;
+        }
+        if ((dbg_flags & 64) && chain_mask) chain_mask = 1ull << __builtin_ctzll(chain_mask);
+        const bool solo = hot_lane && own && !elig && lane == (int)__builtin_ctzll(hot_mask | (1ull << 63));
+        bool n_win = pending && own && (!hot_lane || solo);
+        if (dbg_flags & 8) n_win = n_win && lane == (int)__builtin_ctzll(__ballot(pending));
+        {
+          const unsigned long long nwin_mask = __ballot(n_win), solo_mask = __ballot(solo);
+          if (lane == 0) {
+            ++dbg_rounds;
+            dbg_nwin += (unsigned)__popcll(nwin_mask);
+            dbg_solo += (unsigned)__popcll(solo_mask);
+          }
+        }
+
+        // ---- lanes that own both regions: generic edge ------------------------------------------
+        if (n_win) {
+          RState s1 = TabLoad(tab, sa);
+          RState s2 = TabLoad(tab, sb);
+          const RState o1 = s1, o2 = s2;
+          int stat;
+          const int out = DecideEdge(s1, s2, T, stat);
+          if (optimistic) {
+            const bool v = (out == kOutKeep)     ? TentativeViolated(o1, o2, s1, s2)
+                           : (out == kOutMerge1) ? TentativeViolated(o1, o2, s1, s1)
+                                                 : TentativeViolated(o1, o2, s2, s2);
+            if (v) *violation = 1;
+          }
+          n_forced += (stat == 1);
+          n_regular += (stat == 2);
+          n_small += (stat == 3);
+          if (out == kOutKeep) {
+            my_kept = true;
+            if (!SameState(o1, s1)) TabStore(tab, sa, s1, kTabDirty);
+            if (!SameState(o2, s2)) TabStore(tab, sb, s2, kTabDirty);
+          } else if (out == kOutMerge1) {
+            TabStore(tab, sa, s1, kTabDirty);
+            tab.link[sb] = sa;
+            nodes.parent[tab.key[sb]] = tab.key[sa];
+          } else {
+            TabStore(tab, sb, s2, kTabDirty);
+            tab.link[sa] = sb;
+            nodes.parent[tab.key[sa]] = tab.key[sb];
+          }
+          pending = false;
+        }
+
+        // ---- the chain on the hot region -----------------------------------------------------
+        if (chain_mask) {
+          const bool in_chain = (chain_mask >> lane) & 1ull;
+          const bool fin = (Hs.flags & kFlagFinalized) != 0;
+          // finalized hot region (>= min size): a plain partner merges iff it is small
+          const bool merging = in_chain && (!fin || P.sz < T.min_size);
+          const int v = merging ? P.sz : 0;
+          int incl = v;
+          for (int off = 1; off < 64; off <<= 1) {
+            const int n = __shfl_up(incl, off);
+            if (lane >= off) incl += n;
+          }
+          const int S = Hs.sz + incl - v;     // size of the hot region before this lane's merge
+          // MergeStates with o = partner, m = hot region
+          const float denom = 1.0f / (float)(P.sz + S);
+          const float ca = (float)P.sz * denom;
+          const float cb = (float)S * denom;
+          const float t0 = ca * P.d0, t1 = ca * P.d1, t2 = ca * P.d2;
+          float h0 = Hs.d0, h1 = Hs.d1, h2 = Hs.d2;
+          float r0 = 0.f, r1 = 0.f, r2 = 0.f;   // hot mean before this lane's merge
+          const unsigned long long merging_mask = __ballot(merging);
+          for (unsigned long long mm = merging_mask; mm; mm &= mm - 1) {
+            const int k = (int)__builtin_ctzll(mm);
+            if (lane == k) {
+              r0 = h0;
+              r1 = h1;
+              r2 = h2;
+            }
+            const float cbk = ReadLaneF(cb, k);
+            h0 = ReadLaneF(t0, k) + cbk * h0;
+            h1 = ReadLaneF(t1, k) + cbk * h1;
+            h2 = ReadLaneF(t2, k) + cbk * h2;
+          }
+          unsigned long long fail = 0;
+          if (!fin) {
+            const float x = r0 - P.d0, y = r1 - P.d1, z = r2 - P.d2;
+            const bool pass = (x * x + y * y + z * z) * (1.0f / 3.0f) <= T.pass_s;
+            fail = __ballot(merging && !pass);
+          }
+          int fcut = 64;
+          RState Hn = Hs;
+          if (fail) {
+            fcut = (int)__builtin_ctzll(fail);
+            if (lane == fcut) failed = true;
+            Hn.d0 = ReadLaneF(r0, fcut);
+            Hn.d1 = ReadLaneF(r1, fcut);
+            Hn.d2 = ReadLaneF(r2, fcut);
+            Hn.sz = ReadLaneI(S, fcut);
+            if (lane == 0) ++dbg_cut;
+          } else {
+            Hn.d0 = h0;
+            Hn.d1 = h1;
+            Hn.d2 = h2;
+            Hn.sz = Hs.sz + ReadLaneI(incl, 63);
+          }
+          const unsigned long long below = (fcut < 64) ? ((1ull << fcut) - 1ull) : ~0ull;
+          const bool do_commit = in_chain && lane < fcut;
+          if (dbg_flags & 16) {   // self check: replay the committed chain with DecideEdge
+            RState Hc = Hs;
+            unsigned bad = 0;
+            for (unsigned long long mm = chain_mask & below; mm; mm &= mm - 1) {
+              const int k = (int)__builtin_ctzll(mm);
+              RState a = Hc, b = ReadLaneState(P, k);
+              const RState b0 = b;
+              int st;
+              const int out = DecideEdge(a, b, T, st);
+              const bool km = (merging_mask >> k) & 1ull;
+              if (km) {
+                if (out != kOutMerge1 || st != (fin ? 3 : 2)) ++bad;
+                Hc = a;
+              } else {
+                if (out != kOutKeep || !SameState(a, Hc) || !SameState(b, b0)) ++bad;
+              }
+            }
+            if (__float_as_int(Hc.d0) != __float_as_int(Hn.d0) || __float_as_int(Hc.d1) != __float_as_int(Hn.d1) ||
+                __float_as_int(Hc.d2) != __float_as_int(Hn.d2) || !SameState(Hc, Hn)) ++bad;
+            if (fail) {
+              RState a = Hc, b = ReadLaneState(P, fcut);
+              int st;
+              DecideEdge(a, b, T, st);
+              if (st == 2) ++bad;
+            }
+            if (lane == 0 && bad) atomicAdd(&stats[23], (unsigned long long)bad);
+          }
+          if (do_commit) {
+            if (merging) {
+              tab.link[ps] = hot;
+              nodes.parent[tab.key[ps]] = tab.key[hot];
+              if (fin) ++n_small; else ++n_regular;
+            } else {
+              my_kept = true;   // both regions large, the hot one finalized: nothing changes
+            }
+            pending = false;
+          }
+          // later parallel edges of a committed chain merge
+          const int own_commit = __shfl((int)do_commit, owner);
+          const int own_merging = __shfl((int)merging, owner);
+          // (only of a merge: the edge is internal from then on whatever happens in between)
+          if (dup && ((prefix >> lane) & 1ull) && own_commit && own_merging) pending = false;
+          if (lane == 0) {
+            dbg_chain += (unsigned)__popcll(merging_mask & below);
+            if (merging_mask & below) TabStore(tab, hot, Hn, kTabDirty);
+          }
+        }
+        __syncthreads();
+      }
+
+      if (valid && my_kept) kept_all[gpos] = 1;
+      // ---- write the changed regions back, reset the table ---------------------------------------
+      for (int s = lane; s < kTabSize; s += 64) {
+        const int k = tab.key[s];
+        if (k >= 0) {
+          if (tab.link[s] == s && (tab.flags[s] & kTabDirty)) StoreState(nodes, k, TabLoad(tab, s));
+          tab.key[s] = -1;
+        }
+        tab.res[s] = 0xffffffffu;
+        tab.cnt[s] = 0;
+      }
+      // Make this batch's stores visible to the next batch's loads (same CU: L1 is shared).
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __syncthreads();
+      cyc_loop += __builtin_readcyclecounter() - bt1;
+    }
+    if (lane == 0) {
+      atomicMax(&stats[16], __builtin_readcyclecounter() - seg_t0);   // slowest component
+      atomicMax(&stats[17], (unsigned long long)cnt);                 // largest component
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    n_forced += __shfl_down(n_forced, off);
+    n_regular += __shfl_down(n_regular, off);
+    n_small += __shfl_down(n_small, off);
+  }
+  if (lane == 0) {
+    if (n_forced) atomicAdd(&stats[0], (unsigned long long)n_forced);
+    if (n_regular) atomicAdd(&stats[1], (unsigned long long)n_regular);
+    if (n_small) atomicAdd(&stats[2], (unsigned long long)n_small);
+    atomicAdd(&stats[4], (unsigned long long)dbg_nwin);
+    atomicAdd(&stats[5], (unsigned long long)dbg_rounds);
+    atomicAdd(&stats[6], (unsigned long long)dbg_solo);
+    atomicAdd(&stats[7], (unsigned long long)dbg_batches);
+    atomicAdd(&stats[18], cyc_load);
+    atomicAdd(&stats[19], cyc_loop);
+    atomicAdd(&stats[20], (unsigned long long)dbg_chain);
+    atomicAdd(&stats[21], (unsigned long long)dbg_cut);
   }
 }
 
@@ -804,17 +1319,29 @@ void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* b
   T.pass_s = force ? P.s_lt_02 : P.s_lt_005;
   T.split_s = force ? P.s_lt_02 : P.s_le_015;
   T.min_size = P.min_region_size;
+  // Active edges in component order; the scratch arrays of the earlier steps are free by now.
+  int32_t* s_ra = reinterpret_cast<int32_t*>(S.a_comp);
+  int32_t* s_rb = reinterpret_cast<int32_t*>(S.a_idx);
+  uint32_t* s_gpos = reinterpret_cast<uint32_t*>(S.e_apos);
+  hipLaunchKernelGGL(k_gather_sorted, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.s_idx,
+                     S.a_ra, S.a_rb, S.a_gpos, s_ra, s_rb, s_gpos);
   hipLaunchKernelGGL(k_merge_small, dim3(Blocks(n_active)), dim3(256), 0, s, S.num_segs, S.seg_off,
-                     S.seg_cnt, S.s_idx, S.a_ra, S.a_rb, S.a_gpos, nodes, kept_all, T,
+                     S.seg_cnt, s_ra, s_rb, s_gpos, nodes, kept_all, T,
                      optimistic ? 1 : 0, d_violation, S.stats);
   const int wave_grid = n_active / (kSmallSegment + 1) < 1 ? 1
                         : (n_active / (kSmallSegment + 1) > 8192 ? 8192
                                                                  : n_active / (kSmallSegment + 1));
   const int ew0 = NextEvent(S);
   if (ew0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ew0], s));
-  hipLaunchKernelGGL(k_merge_wave, dim3(wave_grid), dim3(64), 0, s, S.num_segs, S.seg_off,
-                     S.seg_cnt, S.s_idx, S.a_ra, S.a_rb, S.a_gpos, nodes, kept_all, T,
-                     optimistic ? 1 : 0, d_violation, S.stats);
+  if (S.wave_v1) {
+    hipLaunchKernelGGL(k_merge_wave_v1, dim3(wave_grid), dim3(64), 0, s, S.num_segs, S.seg_off,
+                       S.seg_cnt, s_ra, s_rb, s_gpos, nodes, kept_all, T, optimistic ? 1 : 0,
+                       d_violation, S.stats);
+  } else {
+    hipLaunchKernelGGL(k_merge_wave, dim3(wave_grid), dim3(64), 0, s, S.num_segs, S.seg_off,
+                       S.seg_cnt, s_ra, s_rb, s_gpos, nodes, kept_all, T, optimistic ? 1 : 0,
+                       d_violation, S.stats, S.wave_dbg);
+  }
   const int ew1 = NextEvent(S);
   if (ew1 >= 0) {
     VSG_HIP(hipEventRecord((*S.ev_pool)[ew1], s));

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 
+#include "flow_reader.h"
 #include "segmentation_io.h"
 #include "segmentation_unit.h"
 
@@ -29,8 +30,10 @@ uint32_t PcgHash(uint32_t v) {
 // Same generators as tests/synth.py (probe_frame / bench_frame / const_flow).
 class SyntheticVideoUnit : public VideoUnit {
  public:
-  SyntheticVideoUnit(int width, int height, int frames, bool flow, bool bench)
-      : width_(width), height_(height), frames_(frames), flow_(flow), bench_(bench) {}
+  SyntheticVideoUnit(int width, int height, int frames, bool flow, bool bench,
+                     const std::string& save_flow = std::string())
+      : width_(width), height_(height), frames_(frames), flow_(flow), bench_(bench),
+        save_flow_(save_flow) {}
 
   bool OpenStreams(StreamSet* set) override {
     width_step_ = (width_ * 3 + 3) / 4 * 4;   // padded like video_reader_unit.cpp:200-206
@@ -40,11 +43,18 @@ class SyntheticVideoUnit : public VideoUnit {
       set->push_back(std::shared_ptr<DataStream>(
           new DenseFlowStream(width_, height_, "BackwardFlowStream")));
     }
+    if (!save_flow_.empty()) {   // what DenseFlowUnit does with --save_flow (flow_reader.cpp:240-248)
+      flow_writer_.reset(new DenseFlowWriter(save_flow_));
+      if (!flow_writer_->OpenAndWriteHeader(width_, height_, FLOW_BACKWARD)) return false;
+    }
     return true;
   }
 
   bool PostProcess(std::list<FrameSetPtr>* append) override {
-    if (k_ >= frames_) return false;
+    if (k_ >= frames_) {
+      if (flow_writer_) flow_writer_->Close();
+      return false;
+    }
     FrameSetPtr fs(new FrameSet);
     std::shared_ptr<VideoFrame> vf(new VideoFrame(width_, height_, 3, width_step_, (int64_t)k_ * 40000));
     uint8_t* d = vf->mutable_data();
@@ -69,14 +79,15 @@ class SyntheticVideoUnit : public VideoUnit {
       }
     }
     fs->push_back(vf);
-    if (flow_) {
+    if (flow_ || flow_writer_) {
       std::shared_ptr<DenseFlowFrame> ff(new DenseFlowFrame(width_, height_, true, vf->pts()));
       float* f = ff->mutable_flow();
       for (size_t i = 0; i < (size_t)width_ * height_; ++i) {
         f[2 * i] = -2.0f;
         f[2 * i + 1] = 0.0f;
       }
-      fs->push_back(ff);
+      if (flow_writer_ && k_ > 0) flow_writer_->AddFlowFrame(f);   // no field for frame 0
+      if (flow_) fs->push_back(ff);
     }
     append->push_back(fs);
     ++k_;
@@ -86,6 +97,8 @@ class SyntheticVideoUnit : public VideoUnit {
  private:
   int width_, height_, frames_;
   bool flow_, bench_;
+  std::string save_flow_;
+  std::unique_ptr<DenseFlowWriter> flow_writer_;
   int width_step_ = 0;
   int k_ = 0;
 };
@@ -135,7 +148,7 @@ class HashSinkUnit : public VideoUnit {
 
 int main(int argc, char** argv) {
   int width = 64, height = 48, frames = 45, chunk = 20, flow = 1, device = -1;
-  std::string input = "probe", write_to_file;
+  std::string input = "probe", write_to_file, flow_file, save_flow;
   for (int i = 1; i + 1 < argc; i += 2) {
     const std::string k = argv[i];
     const char* v = argv[i + 1];
@@ -147,12 +160,25 @@ int main(int argc, char** argv) {
     else if (k == "--input") input = v;
     else if (k == "--device") device = atoi(v);
     else if (k == "--write_to_file") write_to_file = v;   // seg_tree.cpp:65
+    else if (k == "--flow_file") flow_file = v;           // <input>.flow, seg_tree.cpp:121-125
+    else if (k == "--save_flow") save_flow = v;           // seg_tree.cpp:67, 177-179
     else {
       std::fprintf(stderr, "unknown flag %s\n", k.c_str());
       return 2;
     }
   }
-  SyntheticVideoUnit source(width, height, frames, flow != 0, input == "bench");
+  // With --flow_file the flow comes from DenseFlowReaderUnit instead of the source
+  // (seg_tree.cpp:164-169).
+  const bool flow_from_file = flow != 0 && !flow_file.empty();
+  SyntheticVideoUnit source(width, height, frames, flow != 0 && !flow_from_file, input == "bench",
+                            save_flow);
+  std::unique_ptr<DenseFlowReaderUnit> flow_reader;
+  VideoUnit* input_unit = &source;
+  if (flow_from_file) {
+    flow_reader.reset(new DenseFlowReaderUnit(DenseFlowReaderOptions(), flow_file));
+    flow_reader->AttachTo(input_unit);
+    input_unit = flow_reader.get();
+  }
   DenseSegmentationUnitOptions unit_options;
   if (!flow) unit_options.flow_stream_name.clear();   // seg_tree.cpp:195-198
   unit_options.device = device;
@@ -160,7 +186,7 @@ int main(int argc, char** argv) {
   seg_options.chunk_size = chunk;
   DenseSegmentationUnit dense_unit(unit_options, &seg_options);
   HashSinkUnit sink;
-  dense_unit.AttachTo(&source);
+  dense_unit.AttachTo(input_unit);
   sink.AttachTo(&dense_unit);
   std::unique_ptr<SegmentationWriterUnit> writer;
   if (!write_to_file.empty()) {   // seg_tree.cpp:296-312
