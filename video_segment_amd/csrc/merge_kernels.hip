@@ -983,17 +983,28 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
       bool my_kept = false;
       bool failed = false;    // this lane's chain test failed: replay it with the generic code
       for (unsigned round = 0;; ++round) {
-        if (pending) {
-          sa = SlotRoot(tab, sa);
-          sb = SlotRoot(tab, sb);
-          if (sa == sb) pending = false;   // became internal
+        {   // current root slots (both ends and the hot region advance together)
+          int h = hot;
+          for (bool more = true; more;) {
+            int pa = sa, pb = sb, ph = h;
+            if (pending) {
+              pa = tab.link[sa];
+              pb = tab.link[sb];
+            }
+            if (h >= 0) ph = tab.link[h];
+            more = (pa != sa) || (pb != sb) || (ph != h);
+            sa = pa;
+            sb = pb;
+            h = ph;
+          }
+          hot = h;
+          if (pending && sa == sb) pending = false;   // became internal
         }
         if (!__ballot(pending)) break;
-        if (round > 70u) {   // cannot happen (the earliest pending lane always commits): report
+        if (round > 140u) {   // cannot happen (the earliest pending lane commits, after at most one failed chain test): report
           if (lane == 0) atomicAdd(&stats[22], 1ull);
           break;
         }
-        if (hot >= 0) hot = SlotRoot(tab, hot);
         const bool a_hot = (sa == hot), b_hot = (sb == hot);
         const bool hot_lane = pending && (a_hot || b_hot);
         const uint32_t key = ((0xfffffu - round) << 6) | (uint32_t)lane;
@@ -1019,7 +1030,9 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
           if (hot_lane && mode_ok) {
             if (own) {
               P = TabLoad(tab, ps);
-              elig = !failed && P.cons < 0 && P.flags == 0 && P.sz < Hs.sz && !(dbg_flags & 1);
+              // unconstrained partner (Case U), or partner with the hot region's constraint (Case S)
+              elig = !failed && (P.cons < 0 || P.cons == Hs.cons) && P.flags == 0 && P.sz < Hs.sz &&
+                     !(dbg_flags & 1);
             } else if (!(dbg_flags & 2)) {
               const uint32_t r = a_hot ? res_b : res_a;
               owner = (int)(r & 63u);
@@ -1027,8 +1040,8 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
             }
           }
           // chain lanes that will merge (a finalized hot region only absorbs small partners)
-          const unsigned long long merge0 =
-              __ballot(elig && (!(Hs.flags & kFlagFinalized) || P.sz < T.min_size));
+          const unsigned long long merge0 = __ballot(
+              elig && (P.cons >= 0 || !(Hs.flags & kFlagFinalized) || P.sz < T.min_size));
           // the owner of a partner slot touches that slot; if it is a hot lane its partner is ps
           dup = dup && ((hot_mask >> owner) & 1ull) && ((merge0 >> owner) & 1ull);
         }
@@ -1098,8 +1111,12 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
         if (chain_mask) {
           const bool in_chain = (chain_mask >> lane) & 1ull;
           const bool fin = (Hs.flags & kFlagFinalized) != 0;
-          // finalized hot region (>= min size): a plain partner merges iff it is small
-          const bool merging = in_chain && (!fin || P.sz < T.min_size);
+          // Case S (same constraint): merge unless the descriptors are further apart than the
+          // split threshold, whatever the sizes and flags.  Case U: regular test while the hot
+          // region is not finalized; a finalized hot region (>= min size) absorbs small partners.
+          const bool case_s = in_chain && P.cons >= 0;
+          const bool merging = in_chain && (case_s || !fin || P.sz < T.min_size);
+          const bool tested = case_s || (in_chain && !fin);
           const int v = merging ? P.sz : 0;
           int incl = v;
           for (int off = 1; off < 64; off <<= 1) {
@@ -1128,10 +1145,11 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
             h2 = ReadLaneF(t2, k) + cbk * h2;
           }
           unsigned long long fail = 0;
-          if (!fin) {
+          {
             const float x = r0 - P.d0, y = r1 - P.d1, z = r2 - P.d2;
-            const bool pass = (x * x + y * y + z * z) * (1.0f / 3.0f) <= T.pass_s;
-            fail = __ballot(merging && !pass);
+            const float sd = (x * x + y * y + z * z) * (1.0f / 3.0f);
+            const bool pass = case_s ? !(sd > T.split_s) : (sd <= T.pass_s);
+            fail = __ballot(tested && !pass);
           }
           int fcut = 64;
           RState Hn = Hs;
@@ -1162,7 +1180,7 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
               const int out = DecideEdge(a, b, T, st);
               const bool km = (merging_mask >> k) & 1ull;
               if (km) {
-                if (out != kOutMerge1 || st != (fin ? 3 : 2)) ++bad;
+                if (out != kOutMerge1 || st != (b0.cons >= 0 ? 1 : (fin ? 3 : 2))) ++bad;
                 Hc = a;
               } else {
                 if (out != kOutKeep || !SameState(a, Hc) || !SameState(b, b0)) ++bad;
@@ -1174,7 +1192,7 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
               RState a = Hc, b = ReadLaneState(P, fcut);
               int st;
               DecideEdge(a, b, T, st);
-              if (st == 2) ++bad;
+              if (st == 2 || st == 1) ++bad;
             }
             if (lane == 0 && bad) atomicAdd(&stats[23], (unsigned long long)bad);
           }
@@ -1182,7 +1200,7 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
             if (merging) {
               tab.link[ps] = hot;
               nodes.parent[tab.key[ps]] = tab.key[hot];
-              if (fin) ++n_small; else ++n_regular;
+              if (case_s) ++n_forced; else if (fin) ++n_small; else ++n_regular;
             } else {
               my_kept = true;   // both regions large, the hot one finalized: nothing changes
             }
