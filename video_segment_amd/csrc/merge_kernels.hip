@@ -846,9 +846,20 @@ struct WaveQueue {
   int32_t ra[kQueue];
   int32_t rb[kQueue];
   uint32_t gpos[kQueue];
+  int produced;   // entries pushed by the producer wave (monotonic)
+  int consumed;   // entries taken by the consumer wave (monotonic)
+  int done;       // the producer has read the whole component
 };
 
-__global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ num_segs,
+// Orders the LDS accesses of the lanes of ONE wavefront (they execute in order in hardware; this
+// only keeps the compiler from moving them across the phase boundary).
+__device__ __forceinline__ void WaveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
+__global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ num_segs,
                                                     const int32_t* __restrict__ seg_off,
                                                     const int32_t* __restrict__ seg_cnt,
                                                     const int32_t* __restrict__ s_ra,
@@ -861,8 +872,9 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
                                                     int dbg_flags) {
   __shared__ WaveTable tab;
   __shared__ WaveQueue queue;
-  const int lane = threadIdx.x;
-  for (int s = lane; s < kTabSize; s += 64) {
+  const int lane = threadIdx.x & 63;
+  const bool producer = threadIdx.x >= 64;   // wave 1 reads ahead, wave 0 replays
+  for (int s = threadIdx.x; s < kTabSize; s += 128) {
     tab.key[s] = -1;
     tab.res[s] = 0xffffffffu;
     tab.cnt[s] = 0;
@@ -871,22 +883,33 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
   const int nseg = *num_segs;
   unsigned n_forced = 0, n_regular = 0, n_small = 0;   // per lane, reduced at the end
   unsigned dbg_rounds = 0, dbg_nwin = 0, dbg_chain = 0, dbg_solo = 0, dbg_batches = 0, dbg_cut = 0;
-  unsigned long long cyc_load = 0, cyc_loop = 0;
+  unsigned long long cyc_load = 0, cyc_loop = 0, cyc_wait = 0;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int cnt = seg_cnt[seg];
     if (cnt <= kSmallSegment) continue;
     const int beg = seg_off[seg];
     const int end = beg + cnt;
-    if (lane == 0) atomicAdd(&stats[3], (unsigned long long)cnt);
-    const unsigned long long seg_t0 = __builtin_readcyclecounter();
     // Edges whose two ends already share a region are dropped when they are read (a large share
-    // of a component's edges once its regions have grown), 256 edges per fill with all root
-    // searches in flight together; the surviving edges wait in an LDS ring and are replayed 64 at
-    // a time, so the fixed cost of a batch is spent on pending edges only.
-    int qn = 0, qhead = 0, next = beg;   // wave-uniform
-    while (next < end || qn > 0) {
-      const unsigned long long bt0 = __builtin_readcyclecounter();
-      if (qn < 64 && next < end) {
+    // of a component's edges once its regions have grown): the producer wave reads 256 edges per
+    // fill with all root searches in flight together and pushes the surviving edges into an LDS
+    // ring; the consumer wave replays them 64 at a time, so the fixed cost of a batch is spent on
+    // pending edges only and the global-memory latency of the reads is off the replay's path.
+    if (threadIdx.x == 0) {
+      queue.produced = 0;
+      queue.consumed = 0;
+      queue.done = 0;
+    }
+    __syncthreads();
+    if (producer) {
+      int produced = 0;
+      for (int next = beg; next < end; next += kFill * 64) {
+        const unsigned long long pt0 = __builtin_readcyclecounter();
+        while (produced - __hip_atomic_load(&queue.consumed, __ATOMIC_ACQUIRE,
+                                            __HIP_MEMORY_SCOPE_WORKGROUP) > kQueue - kFill * 64) {
+          __builtin_amdgcn_s_sleep(2);
+        }
+        const unsigned long long pt1 = __builtin_readcyclecounter();
+        cyc_wait += pt1 - pt0;
         int xa[kFill], xb[kFill], ca[kFill], cb[kFill];
         uint32_t gp[kFill];
         bool vd[kFill];
@@ -917,40 +940,68 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
         const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
         for (int k = 0; k < kFill; ++k) {
-          if (!optimistic) {   // an optimistic stage must stay undoable: no path compression
+          // Path compression of the start node only (it is not a root, so the consumer never
+          // writes it); an optimistic stage must stay undoable and does not compress.
+          if (!optimistic) {
             if (vd[k] && ca[k] != xa[k]) nodes.parent[xa[k]] = ca[k];
             if (vd[k] && cb[k] != xb[k]) nodes.parent[xb[k]] = cb[k];
           }
           const bool pend = vd[k] && ca[k] != cb[k];
           const unsigned long long m = __ballot(pend);
           if (pend) {
-            const int slot = (qhead + qn + (int)__popcll(m & lt)) & (kQueue - 1);
+            const int slot = (produced + (int)__popcll(m & lt)) & (kQueue - 1);
             queue.ra[slot] = ca[k];
             queue.rb[slot] = cb[k];
             queue.gpos[slot] = gp[k];
           }
-          qn += (int)__popcll(m);
+          produced += (int)__popcll(m);
         }
-        next += kFill * 64;
-        __syncthreads();
-        cyc_load += __builtin_readcyclecounter() - bt0;
-        if (qn < 64 && next < end) continue;
+        WaveSync();
+        if (lane == 0) {
+          __hip_atomic_store(&queue.produced, produced, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        cyc_load += __builtin_readcyclecounter() - pt1;
       }
-      if (qn == 0) break;
+      if (lane == 0) {
+        __hip_atomic_store(&queue.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      __syncthreads();   // end of the segment (matches the consumer's)
+      continue;
+    }
+
+    // ---- consumer --------------------------------------------------------------------------------
+    if (lane == 0) atomicAdd(&stats[3], (unsigned long long)cnt);
+    const unsigned long long seg_t0 = __builtin_readcyclecounter();
+    int consumed = 0;   // wave-uniform
+    for (;;) {
+      const unsigned long long bt0 = __builtin_readcyclecounter();
+      int avail;
+      for (;;) {   // `done` is read before `produced`: once done is set, produced is final
+        const int done = __hip_atomic_load(&queue.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        avail = __hip_atomic_load(&queue.produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) -
+                consumed;
+        if (avail >= 64 || done) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (avail == 0) break;
       const unsigned long long bt0b = __builtin_readcyclecounter();
+      cyc_wait += bt0b - bt0;
       // ---- take up to 64 pending edges: current roots, region table --------------------------------
-      const int take = qn < 64 ? qn : 64;
+      const int take = avail < 64 ? avail : 64;
       const bool valid = lane < take;
       int ra = -1, rb = -1;
       uint32_t gpos = 0;
       if (valid) {
-        const int slot = (qhead + lane) & (kQueue - 1);
+        const int slot = (consumed + lane) & (kQueue - 1);
         ra = FindReadOnly(nodes.parent, queue.ra[slot]);
         rb = FindReadOnly(nodes.parent, queue.rb[slot]);
         gpos = queue.gpos[slot];
       }
-      qhead = (qhead + take) & (kQueue - 1);
-      qn -= take;
+      consumed += take;
+      WaveSync();
+      if (lane == 0) {
+        __hip_atomic_store(&queue.consumed, consumed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       bool pending = valid && ra != rb;
       int sa = 0, sb = 0;     // table slots of the current roots of the two end regions
       if (pending) {
@@ -968,7 +1019,7 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
         atomicAdd(&tab.cnt[sa], 1);
         atomicAdd(&tab.cnt[sb], 1);
       }
-      __syncthreads();
+      WaveSync();
       int hot = -1;   // wave-uniform slot of the hot region
       {
         int best = 0;
@@ -1012,7 +1063,7 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
           if (!a_hot) atomicMin(&tab.res[sa], key);
           if (!b_hot) atomicMin(&tab.res[sb], key);
         }
-        __syncthreads();
+        WaveSync();
         const uint32_t res_a = pending ? tab.res[sa] : 0u;
         const uint32_t res_b = pending ? tab.res[sb] : 0u;
         const bool own = pending && (a_hot || res_a == key) && (b_hot || res_b == key);
@@ -1216,7 +1267,7 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
             if (merging_mask & below) TabStore(tab, hot, Hn, kTabDirty);
           }
         }
-        __syncthreads();
+        WaveSync();
       }
 
       if (valid && my_kept) kept_all[gpos] = 1;
@@ -1232,13 +1283,21 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
       }
       // Make this batch's stores visible to the next batch's loads (same CU: L1 is shared).
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      __syncthreads();
+      WaveSync();
       cyc_loop += __builtin_readcyclecounter() - bt1;
     }
     if (lane == 0) {
       atomicMax(&stats[16], __builtin_readcyclecounter() - seg_t0);   // slowest component
       atomicMax(&stats[17], (unsigned long long)cnt);                 // largest component
     }
+    __syncthreads();   // end of the segment (matches the producer's)
+  }
+  if (producer) {
+    if (lane == 0) {
+      atomicAdd(&stats[27], cyc_load);   // producer: reading + root searches
+      atomicAdd(&stats[28], cyc_wait);   // producer: ring full
+    }
+    return;
   }
   for (int off = 32; off > 0; off >>= 1) {
     n_forced += __shfl_down(n_forced, off);
@@ -1254,6 +1313,7 @@ __global__ __launch_bounds__(64) void k_merge_wave(const int32_t* __restrict__ n
     atomicAdd(&stats[6], (unsigned long long)dbg_solo);
     atomicAdd(&stats[7], (unsigned long long)dbg_batches);
     atomicAdd(&stats[18], cyc_load);
+    atomicAdd(&stats[26], cyc_wait);   // consumer: ring empty
     atomicAdd(&stats[19], cyc_loop);
     atomicAdd(&stats[20], (unsigned long long)dbg_chain);
     atomicAdd(&stats[21], (unsigned long long)dbg_cut);
@@ -1356,7 +1416,7 @@ void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* b
                        S.seg_cnt, s_ra, s_rb, s_gpos, nodes, kept_all, T, optimistic ? 1 : 0,
                        d_violation, S.stats);
   } else {
-    hipLaunchKernelGGL(k_merge_wave, dim3(wave_grid), dim3(64), 0, s, S.num_segs, S.seg_off,
+    hipLaunchKernelGGL(k_merge_wave, dim3(wave_grid), dim3(128), 0, s, S.num_segs, S.seg_off,
                        S.seg_cnt, s_ra, s_rb, s_gpos, nodes, kept_all, T, optimistic ? 1 : 0,
                        d_violation, S.stats, S.wave_dbg);
   }
