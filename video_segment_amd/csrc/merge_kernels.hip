@@ -839,6 +839,36 @@ __device__ __forceinline__ void TabStore(WaveTable& t, int s, const RState& r, i
   t.flags[s] = r.flags | dirty;
 }
 
+// Wave-wide inclusive prefix sum / maximum with DPP row shifts and row broadcasts (no LDS round
+// trips).  Lanes without a source keep the identity 0 (`old` operand, bound_ctrl off).
+template <int kCtrl, int kRowMask, int kBankMask>
+__device__ __forceinline__ int Dpp0(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, kCtrl, kRowMask, kBankMask, false);
+}
+
+__device__ __forceinline__ int WaveInclusiveSum(int v) {
+  int t = v + Dpp0<0x111, 0xf, 0xf>(v);     // row_shr:1
+  t += Dpp0<0x112, 0xf, 0xf>(v);            // row_shr:2
+  int o = t + Dpp0<0x113, 0xf, 0xf>(v);     // row_shr:3
+  o += Dpp0<0x114, 0xf, 0xe>(o);            // row_shr:4, banks 1-3
+  o += Dpp0<0x118, 0xf, 0xc>(o);            // row_shr:8, banks 2-3
+  o += Dpp0<0x142, 0xa, 0xf>(o);            // row_bcast:15 into rows 1 and 3
+  o += Dpp0<0x143, 0xc, 0xf>(o);            // row_bcast:31 into rows 2 and 3
+  return o;
+}
+
+// Maximum of non-negative values, returned to every lane.
+__device__ __forceinline__ int WaveMax(int v) {
+  int t = max(v, Dpp0<0x111, 0xf, 0xf>(v));
+  t = max(t, Dpp0<0x112, 0xf, 0xf>(v));
+  int o = max(t, Dpp0<0x113, 0xf, 0xf>(v));
+  o = max(o, Dpp0<0x114, 0xf, 0xe>(o));
+  o = max(o, Dpp0<0x118, 0xf, 0xc>(o));
+  o = max(o, Dpp0<0x142, 0xa, 0xf>(o));
+  o = max(o, Dpp0<0x143, 0xc, 0xf>(o));
+  return __builtin_amdgcn_readlane(o, 63);
+}
+
 constexpr int kFill = 4;        // 64-edge chunks read per fill
 constexpr int kQueue = 512;     // ring capacity >= 63 + kFill * 64, power of two
 
@@ -859,6 +889,7 @@ __device__ __forceinline__ void WaveSync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
+template <bool kDbg>
 __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ num_segs,
                                                     const int32_t* __restrict__ seg_off,
                                                     const int32_t* __restrict__ seg_cnt,
@@ -871,6 +902,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
                                                     unsigned long long* __restrict__ stats,
                                                     int dbg_flags) {
   __shared__ WaveTable tab;
+  auto Clock = []() -> unsigned long long { return kDbg ? __builtin_readcyclecounter() : 0ull; };
   __shared__ WaveQueue queue;
   const int lane = threadIdx.x & 63;
   const bool producer = threadIdx.x >= 64;   // wave 1 reads ahead, wave 0 replays
@@ -903,12 +935,12 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
     if (producer) {
       int produced = 0;
       for (int next = beg; next < end; next += kFill * 64) {
-        const unsigned long long pt0 = __builtin_readcyclecounter();
+        const unsigned long long pt0 = Clock();
         while (produced - __hip_atomic_load(&queue.consumed, __ATOMIC_ACQUIRE,
                                             __HIP_MEMORY_SCOPE_WORKGROUP) > kQueue - kFill * 64) {
           __builtin_amdgcn_s_sleep(2);
         }
-        const unsigned long long pt1 = __builtin_readcyclecounter();
+        const unsigned long long pt1 = Clock();
         cyc_wait += pt1 - pt0;
         int xa[kFill], xb[kFill], ca[kFill], cb[kFill];
         uint32_t gp[kFill];
@@ -960,7 +992,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
         if (lane == 0) {
           __hip_atomic_store(&queue.produced, produced, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        cyc_load += __builtin_readcyclecounter() - pt1;
+        cyc_load += Clock() - pt1;
       }
       if (lane == 0) {
         __hip_atomic_store(&queue.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -971,10 +1003,10 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
 
     // ---- consumer --------------------------------------------------------------------------------
     if (lane == 0) atomicAdd(&stats[3], (unsigned long long)cnt);
-    const unsigned long long seg_t0 = __builtin_readcyclecounter();
+    const unsigned long long seg_t0 = Clock();
     int consumed = 0;   // wave-uniform
     for (;;) {
-      const unsigned long long bt0 = __builtin_readcyclecounter();
+      const unsigned long long bt0 = Clock();
       int avail;
       for (;;) {   // `done` is read before `produced`: once done is set, produced is final
         const int done = __hip_atomic_load(&queue.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -984,7 +1016,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
         __builtin_amdgcn_s_sleep(2);
       }
       if (avail == 0) break;
-      const unsigned long long bt0b = __builtin_readcyclecounter();
+      const unsigned long long bt0b = Clock();
       cyc_wait += bt0b - bt0;
       // ---- take up to 64 pending edges: current roots, region table --------------------------------
       const int take = avail < 64 ? avail : 64;
@@ -993,9 +1025,15 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
       uint32_t gpos = 0;
       if (valid) {
         const int slot = (consumed + lane) & (kQueue - 1);
-        ra = FindReadOnly(nodes.parent, queue.ra[slot]);
-        rb = FindReadOnly(nodes.parent, queue.rb[slot]);
+        ra = queue.ra[slot];
+        rb = queue.rb[slot];
         gpos = queue.gpos[slot];
+        for (bool more = true; more;) {   // the producer's roots may be stale by now
+          const int pa = nodes.parent[ra], pb = nodes.parent[rb];
+          more = (pa != ra) || (pb != rb);
+          ra = pa;
+          rb = pb;
+        }
       }
       consumed += take;
       WaveSync();
@@ -1005,16 +1043,17 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
       bool pending = valid && ra != rb;
       int sa = 0, sb = 0;     // table slots of the current roots of the two end regions
       if (pending) {
-        bool ins;
-        sa = TabInsert(tab, ra, ins);
-        if (ins) {
+        const RState A = LoadState(nodes, ra), B = LoadState(nodes, rb);   // both in flight
+        bool ins_a, ins_b;
+        sa = TabInsert(tab, ra, ins_a);
+        sb = TabInsert(tab, rb, ins_b);
+        if (ins_a) {
           tab.link[sa] = sa;
-          TabStore(tab, sa, LoadState(nodes, ra), 0);
+          TabStore(tab, sa, A, 0);
         }
-        sb = TabInsert(tab, rb, ins);
-        if (ins) {
+        if (ins_b) {
           tab.link[sb] = sb;
-          TabStore(tab, sb, LoadState(nodes, rb), 0);
+          TabStore(tab, sb, B, 0);
         }
         atomicAdd(&tab.cnt[sa], 1);
         atomicAdd(&tab.cnt[sb], 1);
@@ -1024,11 +1063,11 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
       {
         int best = 0;
         if (pending) best = max((tab.cnt[sa] << 8) | sa, (tab.cnt[sb] << 8) | sb);
-        for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off));
-        if ((best >> 8) >= 3 && !(dbg_flags & 4)) hot = best & (kTabSize - 1);
+        best = WaveMax(best);
+        if ((best >> 8) >= 3 && !(kDbg && (dbg_flags & 4))) hot = best & (kTabSize - 1);
       }
-      if (lane == 0) ++dbg_batches;
-      const unsigned long long bt1 = __builtin_readcyclecounter();
+      if (kDbg && lane == 0) ++dbg_batches;
+      const unsigned long long bt1 = Clock();
       cyc_load += bt1 - bt0b;
 
       bool my_kept = false;
@@ -1083,8 +1122,8 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
               P = TabLoad(tab, ps);
               // unconstrained partner (Case U), or partner with the hot region's constraint (Case S)
               elig = !failed && (P.cons < 0 || P.cons == Hs.cons) && P.flags == 0 && P.sz < Hs.sz &&
-                     !(dbg_flags & 1);
-            } else if (!(dbg_flags & 2)) {
+                     !(kDbg && (dbg_flags & 1));
+            } else if (!(kDbg && (dbg_flags & 2))) {
               const uint32_t r = a_hot ? res_b : res_a;
               owner = (int)(r & 63u);
               dup = true;   // confirmed below: the owner must be a chain lane
@@ -1109,15 +1148,15 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
         const unsigned long long prefix =
             blocked ? ((1ull << __builtin_ctzll(blocked)) - 1ull) : ~0ull;
         unsigned long long chain_mask = elig_mask & prefix;
-        if (dbg_flags & 32) {   // no jumping over earlier pending lanes
+        if (kDbg && (dbg_flags & 32)) {   // no jumping over earlier pending lanes
           const unsigned long long others = __ballot(pending) & ~chain_mask;
           if (others) chain_mask &= (1ull << __builtin_ctzll(others)) - 1ull;
         }
-        if ((dbg_flags & 64) && chain_mask) chain_mask = 1ull << __builtin_ctzll(chain_mask);
+        if ((kDbg && (dbg_flags & 64)) && chain_mask) chain_mask = 1ull << __builtin_ctzll(chain_mask);
         const bool solo = hot_lane && own && !elig && lane == (int)__builtin_ctzll(hot_mask | (1ull << 63));
         bool n_win = pending && own && (!hot_lane || solo);
-        if (dbg_flags & 8) n_win = n_win && lane == (int)__builtin_ctzll(__ballot(pending));
-        {
+        if (kDbg && (dbg_flags & 8)) n_win = n_win && lane == (int)__builtin_ctzll(__ballot(pending));
+        if constexpr (kDbg) {
           const unsigned long long nwin_mask = __ballot(n_win), solo_mask = __ballot(solo);
           if (lane == 0) {
             ++dbg_rounds;
@@ -1127,6 +1166,42 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
         }
 
         // ---- lanes that own both regions: generic edge ------------------------------------------
+        if (n_win) {
+          const RState s1 = TabLoad(tab, sa);
+          const RState s2 = TabLoad(tab, sb);
+          // Fast path, by far the most common generic edge: two plain regions (unconstrained,
+          // not finalized, unmarked) that pass the regular test.  Same arithmetic as
+          // DecideEdge / MergeStates for this case.
+          if (s1.cons < 0 && s2.cons < 0 && (s1.flags | s2.flags) == 0 &&
+              SquaredDistance(s1, s2) <= T.pass_s) {
+            const bool first = s1.sz > s2.sz;   // ties keep region 2
+            const int ws = first ? sa : sb, ls = first ? sb : sa;
+            RState m, o;
+            m.d0 = first ? s1.d0 : s2.d0;
+            m.d1 = first ? s1.d1 : s2.d1;
+            m.d2 = first ? s1.d2 : s2.d2;
+            m.sz = first ? s1.sz : s2.sz;
+            o.d0 = first ? s2.d0 : s1.d0;
+            o.d1 = first ? s2.d1 : s1.d1;
+            o.d2 = first ? s2.d2 : s1.d2;
+            o.sz = first ? s2.sz : s1.sz;
+            const float denom = 1.0f / (float)(o.sz + m.sz);
+            const float ca = (float)o.sz * denom;
+            const float cb = (float)m.sz * denom;
+            m.d0 = ca * o.d0 + cb * m.d0;
+            m.d1 = ca * o.d1 + cb * m.d1;
+            m.d2 = ca * o.d2 + cb * m.d2;
+            m.sz += o.sz;
+            m.cons = max(s1.cons, s2.cons);
+            m.flags = 0;
+            TabStore(tab, ws, m, kTabDirty);
+            tab.link[ls] = ws;
+            nodes.parent[tab.key[ls]] = tab.key[ws];
+            ++n_regular;
+            pending = false;
+            n_win = false;
+          }
+        }
         if (n_win) {
           RState s1 = TabLoad(tab, sa);
           RState s2 = TabLoad(tab, sb);
@@ -1169,11 +1244,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           const bool merging = in_chain && (case_s || !fin || P.sz < T.min_size);
           const bool tested = case_s || (in_chain && !fin);
           const int v = merging ? P.sz : 0;
-          int incl = v;
-          for (int off = 1; off < 64; off <<= 1) {
-            const int n = __shfl_up(incl, off);
-            if (lane >= off) incl += n;
-          }
+          const int incl = WaveInclusiveSum(v);
           const int S = Hs.sz + incl - v;     // size of the hot region before this lane's merge
           // MergeStates with o = partner, m = hot region
           const float denom = 1.0f / (float)(P.sz + S);
@@ -1211,7 +1282,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
             Hn.d1 = ReadLaneF(r1, fcut);
             Hn.d2 = ReadLaneF(r2, fcut);
             Hn.sz = ReadLaneI(S, fcut);
-            if (lane == 0) ++dbg_cut;
+            if (kDbg && lane == 0) ++dbg_cut;
           } else {
             Hn.d0 = h0;
             Hn.d1 = h1;
@@ -1220,7 +1291,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           }
           const unsigned long long below = (fcut < 64) ? ((1ull << fcut) - 1ull) : ~0ull;
           const bool do_commit = in_chain && lane < fcut;
-          if (dbg_flags & 16) {   // self check: replay the committed chain with DecideEdge
+          if constexpr (kDbg) if (dbg_flags & 16) {   // self check: replay the committed chain with DecideEdge
             RState Hc = Hs;
             unsigned bad = 0;
             for (unsigned long long mm = chain_mask & below; mm; mm &= mm - 1) {
@@ -1263,7 +1334,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           // (only of a merge: the edge is internal from then on whatever happens in between)
           if (dup && ((prefix >> lane) & 1ull) && own_commit && own_merging) pending = false;
           if (lane == 0) {
-            dbg_chain += (unsigned)__popcll(merging_mask & below);
+            if (kDbg) dbg_chain += (unsigned)__popcll(merging_mask & below);
             if (merging_mask & below) TabStore(tab, hot, Hn, kTabDirty);
           }
         }
@@ -1284,16 +1355,16 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
       // Make this batch's stores visible to the next batch's loads (same CU: L1 is shared).
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       WaveSync();
-      cyc_loop += __builtin_readcyclecounter() - bt1;
+      cyc_loop += Clock() - bt1;
     }
-    if (lane == 0) {
-      atomicMax(&stats[16], __builtin_readcyclecounter() - seg_t0);   // slowest component
-      atomicMax(&stats[17], (unsigned long long)cnt);                 // largest component
+    if (kDbg && lane == 0) {
+      atomicMax(&stats[16], Clock() - seg_t0);            // slowest component
+      atomicMax(&stats[17], (unsigned long long)cnt);     // largest component
     }
     __syncthreads();   // end of the segment (matches the producer's)
   }
   if (producer) {
-    if (lane == 0) {
+    if (kDbg && lane == 0) {
       atomicAdd(&stats[27], cyc_load);   // producer: reading + root searches
       atomicAdd(&stats[28], cyc_wait);   // producer: ring full
     }
@@ -1308,6 +1379,8 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
     if (n_forced) atomicAdd(&stats[0], (unsigned long long)n_forced);
     if (n_regular) atomicAdd(&stats[1], (unsigned long long)n_regular);
     if (n_small) atomicAdd(&stats[2], (unsigned long long)n_small);
+  }
+  if (kDbg && lane == 0) {
     atomicAdd(&stats[4], (unsigned long long)dbg_nwin);
     atomicAdd(&stats[5], (unsigned long long)dbg_rounds);
     atomicAdd(&stats[6], (unsigned long long)dbg_solo);
@@ -1415,10 +1488,14 @@ void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* b
     hipLaunchKernelGGL(k_merge_wave_v1, dim3(wave_grid), dim3(64), 0, s, S.num_segs, S.seg_off,
                        S.seg_cnt, s_ra, s_rb, s_gpos, nodes, kept_all, T, optimistic ? 1 : 0,
                        d_violation, S.stats);
-  } else {
-    hipLaunchKernelGGL(k_merge_wave, dim3(wave_grid), dim3(128), 0, s, S.num_segs, S.seg_off,
+  } else if (S.wave_debug) {
+    hipLaunchKernelGGL(k_merge_wave<true>, dim3(wave_grid), dim3(128), 0, s, S.num_segs, S.seg_off,
                        S.seg_cnt, s_ra, s_rb, s_gpos, nodes, kept_all, T, optimistic ? 1 : 0,
                        d_violation, S.stats, S.wave_dbg);
+  } else {
+    hipLaunchKernelGGL(k_merge_wave<false>, dim3(wave_grid), dim3(128), 0, s, S.num_segs, S.seg_off,
+                       S.seg_cnt, s_ra, s_rb, s_gpos, nodes, kept_all, T, optimistic ? 1 : 0,
+                       d_violation, S.stats, 0);
   }
   const int ew1 = NextEvent(S);
   if (ew1 >= 0) {
