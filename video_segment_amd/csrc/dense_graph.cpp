@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <unordered_set>
 
 namespace vsg {
 
@@ -424,17 +425,26 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
     for (size_t i = old; i < old + (size_t)k; ++i) (*node_ids)[i] += begin;
   };
 
+  const double tm0 = NowMs();
   std::vector<int32_t> nv_nodes, nv_roots, v_nodes, v_roots;
   for (auto& r : nvranges) collect(r.first, r.second, &nv_nodes, &nv_roots);
   for (auto& r : vranges) collect(r.first, r.second, &v_nodes, &v_roots);
+  const double tm1 = NowMs();
 
   // Distinct representatives and their states.
   std::vector<int32_t> ids;
   {
-    ids = nv_roots;
-    ids.insert(ids.end(), v_roots.begin(), v_roots.end());
+    // Millions of flagged nodes, a few dozen representatives, long runs of equal values.
+    std::unordered_set<int32_t> seen;
+    int32_t last = -1;
+    for (const std::vector<int32_t>* v : {&nv_roots, &v_roots}) {
+      for (int32_t r : *v) {
+        if (r == last) continue;
+        last = r;
+        if (seen.insert(r).second) ids.push_back(r);
+      }
+    }
     std::sort(ids.begin(), ids.end());
-    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
   }
   const int m = (int)ids.size();
   if (m == 0) return;
@@ -452,6 +462,7 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
   D2H(h_flags.data(), small_i32_c_.get(), (size_t)m, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
 
+  const double tm2 = NowMs();
   std::unordered_map<int, SimRegion> sim;
   sim.reserve((size_t)m * 2);
   for (int i = 0; i < m; ++i) {
@@ -608,6 +619,12 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
   }
 
   // Write back.
+  const double tm3 = NowMs();
+  if (getenv("VSG_DEBUG_STATS")) {
+    std::fprintf(stderr, "[vsg] merge-constrained: collect %.1f ms (%zu + %zu flagged nodes), states %.1f ms "
+                 "(%d representatives), replay %.1f ms\n", tm1 - tm0, nv_nodes.size(), v_nodes.size(),
+                 tm2 - tm1, m, tm3 - tm2);
+  }
   std::vector<int32_t> u_ids, u_parent, u_cons, u_flags;
   std::vector<float4> u_ds;
   for (auto& kv : sim) {
