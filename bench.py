@@ -194,6 +194,14 @@ def main():
         wave_avg_s = acc["wave_ms"] / 1e3 / wave_launches
         wave_bytes_per_launch = WAVE_BYTES_PER_EDGE * acc["wave_edges"] / wave_launches
         achieved = wave_bytes_per_launch / wave_avg_s / 1e9 if wave_avg_s > 0 else 0.0
+        # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes cannot run inside the
+        # timed process, so the committed summary of the same workload is quoted (null if absent).
+        traffic, traffic_note = None, "no PMC summary under profiles/"
+        pmc_path = os.path.join(ROOT, "profiles", "r1_b_pmc_wave.json")
+        if os.path.exists(pmc_path) and (W, H, chunk) == (1920, 1080, 20):
+            pmc = json.load(open(pmc_path))
+            traffic = pmc["fetch_bytes_per_launch_raw"] + pmc["write_bytes_per_launch_raw"]
+            traffic_note = ("FETCH_SIZE + WRITE_SIZE per launch, raw counters, from " + pmc["source"])
         out = {
             "metric": "over-segmented frames/sec at 1080p",
             "value": fps,
@@ -218,12 +226,14 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "vsg::k_merge_wave (ordered per-component union-find replay)",
+                "kernel": "vsg::k_merge_wave (ordered per-component union-find replay, round based)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "B/launch",
+                "traffic_note": traffic_note,
                 "launches": acc["wave_launches"],
                 "avg_launch_ms": wave_avg_s * 1e3,
                 "bytes_per_launch": wave_bytes_per_launch,
