@@ -1,5 +1,5 @@
 """Debug helper: runs a few graph parity cases under the VSG_WAVE_DBG toggles of the wave worker
-(1 no chain, 2 no parallel-edge shortcut, 4 no hot region, 8 one lane per round) and reports merge
+(1 no chain, 4 no hot region, 8 one generic lane per round, 16 chain self check, 32 no jumping, 64 one chain lane per round) and reports merge
 statistics / partition equality against the oracle."""
 import os
 import subprocess
@@ -23,7 +23,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                                                            og.merge_stats(), same))
     sys.exit(0)
 
-for dbg in (sys.argv[1:] or ["0", "1", "2", "3", "4", "8", "15"]):
+for dbg in (sys.argv[1:] or ["0", "1", "4", "8", "16", "32", "64"]):
     env = dict(os.environ, VSG_WAVE_DBG=dbg)
     print("VSG_WAVE_DBG=%s" % dbg, flush=True)
     subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, timeout=300)

@@ -124,7 +124,8 @@ struct MergeScratch {
   int force_rollback;    // test hook: treat every optimistic stage as violated
   int wave_v1;           // debug hook: use the sequential wave worker (k_merge_wave_v1)
   int wave_debug;        // use the instrumented build of the wave worker (counters, self checks)
-  int wave_dbg;          // debug hook: 1 no chain, 2 no parallel-edge shortcut, 4 no hot region, 8 one lane per round
+  int wave_dbg;          // debug hook (bit mask): 1 no chain, 4 no hot region, 8 one generic lane per round,
+                         // 16 chain self check, 32 no jumping over pending lanes, 64 one chain lane per round
   int64_t* optimistic_stages;
   int64_t* rollbacks;
   int32_t* cc;           // [N] component scratch (identity outside a stage)

@@ -1096,55 +1096,74 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           break;
         }
         const bool a_hot = (sa == hot), b_hot = (sb == hot);
-        const bool hot_lane = pending && (a_hot || b_hot);
         const uint32_t key = ((0xfffffu - round) << 6) | (uint32_t)lane;
         if (pending) {
           if (!a_hot) atomicMin(&tab.res[sa], key);
           if (!b_hot) atomicMin(&tab.res[sb], key);
         }
         WaveSync();
-        const uint32_t res_a = pending ? tab.res[sa] : 0u;
-        const uint32_t res_b = pending ? tab.res[sb] : 0u;
-        const bool own = pending && (a_hot || res_a == key) && (b_hot || res_b == key);
-        const unsigned long long hot_mask = __ballot(hot_lane);
-        RState Hs = {}, P = {};
-        int ps = 0;           // partner slot of a hot lane
-        bool elig = false;    // chain lane
-        bool dup = false;     // hot lane whose partner is reserved by an earlier hot lane
-        int owner = 0;
-        if (hot_mask) {
-          Hs = TabLoad(tab, hot);   // uniform
-          ps = a_hot ? sb : sa;
-          const bool mode_ok = !(Hs.flags & kFlagNoDesc) &&
-                               (!(Hs.flags & kFlagFinalized) || Hs.sz >= T.min_size);
-          if (hot_lane && mode_ok) {
-            if (own) {
-              P = TabLoad(tab, ps);
-              // unconstrained partner (Case U), or partner with the hot region's constraint (Case S)
-              elig = !failed && (P.cons < 0 || P.cons == Hs.cons) && P.flags == 0 && P.sz < Hs.sz &&
-                     !(kDbg && (dbg_flags & 1));
-            } else if (!(kDbg && (dbg_flags & 2))) {
-              const uint32_t r = a_hot ? res_b : res_a;
-              owner = (int)(r & 63u);
-              dup = true;   // confirmed below: the owner must be a chain lane
-            }
-          }
-          // chain lanes that will merge (a finalized hot region only absorbs small partners)
-          const unsigned long long merge0 = __ballot(
-              elig && (P.cons >= 0 || !(Hs.flags & kFlagFinalized) || P.sz < T.min_size));
-          // the owner of a partner slot touches that slot; if it is a hot lane its partner is ps
-          dup = dup && ((hot_mask >> owner) & 1ull) && ((merge0 >> owner) & 1ull);
+        uint32_t res_a = 0, res_b = 0;
+        RState A = {}, B = {};
+        if (pending) {
+          res_a = tab.res[sa];
+          res_b = tab.res[sb];
+          A = TabLoad(tab, sa);
+          B = TabLoad(tab, sb);
         }
+        // own_x: this lane is the earliest pending edge on region x (the hot region is not reserved)
+        const bool own_a = pending && !a_hot && res_a == key;
+        const bool own_b = pending && !b_hot && res_b == key;
+        const int oa = (int)(res_a & 63u), ob = (int)(res_b & 63u);   // owners (earlier lanes)
+        RState Hs = {}, P = {};
+        int ps = 0;            // partner slot of a chain lane
+        bool hot_lane = pending && (a_hot || b_hot);
+        bool elig = false;     // chain lane
+        bool both = false;     // both ends (will) belong to the hot region: internal once committed
+        bool merging = false;
+        bool case_s = false;
+        bool fin = false;
+        if (__ballot(hot_lane)) {
+          Hs = TabLoad(tab, hot);   // uniform
+          fin = (Hs.flags & kFlagFinalized) != 0;
+          const bool mode_ok = !(Hs.flags & kFlagNoDesc) && (!fin || Hs.sz >= T.min_size) &&
+                               !(kDbg && (dbg_flags & 1));
+          // A region is *effectively hot* for a lane when it is the hot region or when its owner
+          // (an earlier lane) is a chain lane that absorbs it into the hot region: by the time this
+          // lane is replayed the region is part of the hot one.  So a run of edges p1-p2, p2-p3, ...
+          // hanging off the hot region joins the chain in one round.  The set of absorbing lanes
+          // only grows, so the loop ends (no memory access inside).
+          unsigned long long em = 0;   // chain lanes that merge
+          for (;;) {
+            const bool ea = a_hot || (pending && !own_a && ((em >> oa) & 1ull));
+            const bool eb = b_hot || (pending && !own_b && ((em >> ob) & 1ull));
+            hot_lane = pending && (ea || eb);
+            both = hot_lane && ea && eb;
+            const bool part_b = ea;   // the partner is the end that is not effectively hot
+            P.d0 = part_b ? B.d0 : A.d0;
+            P.d1 = part_b ? B.d1 : A.d1;
+            P.d2 = part_b ? B.d2 : A.d2;
+            P.sz = part_b ? B.sz : A.sz;
+            P.cons = part_b ? B.cons : A.cons;
+            P.flags = part_b ? B.flags : A.flags;
+            ps = part_b ? sb : sa;
+            const bool own_p = part_b ? own_b : own_a;
+            // unconstrained partner (Case U), or partner with the hot region's constraint (Case S)
+            elig = hot_lane && !both && mode_ok && own_p && !failed && P.flags == 0 &&
+                   (P.cons < 0 || P.cons == Hs.cons) && P.sz < Hs.sz;
+            case_s = P.cons >= 0;
+            // Case S merges unless the descriptors are further apart than the split threshold,
+            // whatever the sizes and flags; Case U: regular test while the hot region is not
+            // finalized, a finalized hot region (>= min size) absorbs small partners only.
+            merging = elig && (case_s || !fin || P.sz < T.min_size);
+            const unsigned long long em2 = __ballot(merging);
+            if (em2 == em) break;
+            em = em2;
+          }
+        }
+        const unsigned long long hot_mask = __ballot(hot_lane);
         const unsigned long long elig_mask = __ballot(elig);
-        const unsigned long long dup_mask = __ballot(dup);
-        // A pending edge that shares a region with the partner of a chain lane turns into a hot
-        // edge as soon as that partner is absorbed, so nothing behind it may join the chain.
-        const bool future_hot =
-            pending && !hot_lane &&
-            ((res_a != key && ((elig_mask >> (res_a & 63u)) & 1ull)) ||
-             (res_b != key && ((elig_mask >> (res_b & 63u)) & 1ull)));
-        const unsigned long long blocked =
-            (hot_mask & ~(elig_mask | dup_mask)) | __ballot(future_hot);
+        // hot lanes that are neither chain lanes nor internal end the chain
+        const unsigned long long blocked = hot_mask & ~(elig_mask | __ballot(both));
         const unsigned long long prefix =
             blocked ? ((1ull << __builtin_ctzll(blocked)) - 1ull) : ~0ull;
         unsigned long long chain_mask = elig_mask & prefix;
@@ -1153,7 +1172,11 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           if (others) chain_mask &= (1ull << __builtin_ctzll(others)) - 1ull;
         }
         if ((kDbg && (dbg_flags & 64)) && chain_mask) chain_mask = 1ull << __builtin_ctzll(chain_mask);
-        const bool solo = hot_lane && own && !elig && lane == (int)__builtin_ctzll(hot_mask | (1ull << 63));
+        // The first hot lane, when it is no chain lane, is replayed alone by the generic code (it
+        // touches the hot region itself: nothing earlier can have absorbed one of its ends).
+        const bool own = pending && (a_hot || own_a) && (b_hot || own_b);
+        const bool solo = hot_lane && own && !elig && !both &&
+                          lane == (int)__builtin_ctzll(hot_mask | (1ull << 63));
         bool n_win = pending && own && (!hot_lane || solo);
         if (kDbg && (dbg_flags & 8)) n_win = n_win && lane == (int)__builtin_ctzll(__ballot(pending));
         if constexpr (kDbg) {
@@ -1167,8 +1190,8 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
 
         // ---- lanes that own both regions: generic edge ------------------------------------------
         if (n_win) {
-          const RState s1 = TabLoad(tab, sa);
-          const RState s2 = TabLoad(tab, sb);
+          const RState& s1 = A;
+          const RState& s2 = B;
           // Fast path, by far the most common generic edge: two plain regions (unconstrained,
           // not finalized, unmarked) that pass the regular test.  Same arithmetic as
           // DecideEdge / MergeStates for this case.
@@ -1203,8 +1226,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           }
         }
         if (n_win) {
-          RState s1 = TabLoad(tab, sa);
-          RState s2 = TabLoad(tab, sb);
+          RState s1 = A, s2 = B;
           const RState o1 = s1, o2 = s2;
           int stat;
           const int out = DecideEdge(s1, s2, T, stat);
@@ -1236,12 +1258,8 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
         // ---- the chain on the hot region -----------------------------------------------------
         if (chain_mask) {
           const bool in_chain = (chain_mask >> lane) & 1ull;
-          const bool fin = (Hs.flags & kFlagFinalized) != 0;
-          // Case S (same constraint): merge unless the descriptors are further apart than the
-          // split threshold, whatever the sizes and flags.  Case U: regular test while the hot
-          // region is not finalized; a finalized hot region (>= min size) absorbs small partners.
-          const bool case_s = in_chain && P.cons >= 0;
-          const bool merging = in_chain && (case_s || !fin || P.sz < T.min_size);
+          merging = in_chain && merging;
+          case_s = in_chain && case_s;
           const bool tested = case_s || (in_chain && !fin);
           const int v = merging ? P.sz : 0;
           const int incl = WaveInclusiveSum(v);
@@ -1328,11 +1346,10 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
             }
             pending = false;
           }
-          // later parallel edges of a committed chain merge
-          const int own_commit = __shfl((int)do_commit, owner);
-          const int own_merging = __shfl((int)merging, owner);
-          // (only of a merge: the edge is internal from then on whatever happens in between)
-          if (dup && ((prefix >> lane) & 1ull) && own_commit && own_merging) pending = false;
+          // An edge with both ends (by then) inside the hot region is internal: every lane that
+          // absorbs one of its ends is an earlier chain lane, committed if this lane is below the
+          // cut.
+          if (both && lane < fcut && ((prefix >> lane) & 1ull)) pending = false;
           if (lane == 0) {
             if (kDbg) dbg_chain += (unsigned)__popcll(merging_mask & below);
             if (merging_mask & below) TabStore(tab, hot, Hn, kTabDirty);
