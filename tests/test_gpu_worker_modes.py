@@ -1,0 +1,93 @@
+"""GPU parity of the merge worker's mechanisms and of awkward stream shapes.
+
+The round-based wave worker has debug switches that disable its mechanisms
+one by one (VSG_WAVE_DBG bit mask), a self check that replays every committed chain with the
+generic edge code, and the edge-by-edge worker of round 1a (VSG_WAVE_V1).  Every mode must give the
+oracle's bytes.  Shapes: odd sizes, padded rows, tiny frames, random (out of range) flow."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import synth
+from test_gpu_parity import rand_frame, run_streams, vsg  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(96, 64, 26, "smooth", 10), (128, 96, 44, "bench", 20), (64, 48, 30, "noise", 8)]
+
+
+@pytest.mark.parametrize("mode", ["1", "4", "8", "32", "64", "9"])
+def test_worker_mechanisms_off_one_by_one(vsg, monkeypatch, mode):
+    monkeypatch.setenv("VSG_WAVE_DBG", mode)
+    for (W, H, N, kind, chunk) in CASES:
+        run_streams(vsg, W, H, N, kind, True, chunk)
+
+
+def test_chain_self_check_is_silent(vsg, monkeypatch, capfd):
+    """Bit 16: every committed chain is replayed with DecideEdge inside the kernel and compared
+    (means bit for bit, sizes, flags, constraints, merge statistics class)."""
+    monkeypatch.setenv("VSG_WAVE_DBG", "16")
+    for (W, H, N, kind, chunk) in CASES + [(256, 144, 44, "bench", 20)]:
+        run_streams(vsg, W, H, N, kind, True, chunk)
+    err = capfd.readouterr().err
+    assert "self check" not in err, err
+
+
+def test_edge_by_edge_worker(vsg, monkeypatch):
+    monkeypatch.setenv("VSG_WAVE_V1", "1")
+    for (W, H, N, kind, chunk) in CASES:
+        run_streams(vsg, W, H, N, kind, True, chunk)
+
+
+@pytest.mark.parametrize("W,H,N,kind,flow,chunk", [
+    (67, 45, 20, "noise", True, 8),       # odd sizes
+    (33, 31, 19, "smooth", True, 8),
+    (17, 9, 12, "noise", True, 8),        # tiny
+    (9, 17, 9, "smooth", False, 8),
+    (131, 71, 23, "bench", True, 10),
+    (256, 144, 44, "bench", True, 20),    # large components: wave worker with constraints
+])
+def test_stream_shapes(vsg, W, H, N, kind, flow, chunk):
+    run_streams(vsg, W, H, N, kind, flow, chunk)
+
+
+def test_padded_rows_and_random_flow(vsg):
+    """Frames handed over as views of wider buffers (width_step > 3 W, like the reference's padded
+    VideoFrames) and a different random flow field per frame, including far out-of-range and
+    non-finite vectors (x86 float->int semantics of the displaced pixel)."""
+    W, H, N, chunk = 70, 50, 21, 8
+    rng = np.random.default_rng(11)
+    gs = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=True)
+    os_ = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
+    for k in range(N):
+        wide = np.zeros((H, W + 6, 3), np.uint8)
+        wide[:] = rng.integers(0, 256, wide.shape, dtype=np.uint8)   # garbage in the padding
+        wide[:, :W] = rand_frame(rng, W, H, "smooth")
+        view = wide[:, :W]
+        assert not view.flags["C_CONTIGUOUS"]
+        fl = rng.normal(0, 6.0, (H, W, 2)).astype(np.float32)
+        fl[0, 0] = (1e9, -1e9)
+        fl[1, 2] = (np.nan, 3.0)
+        fl[2, 1] = (np.inf, -np.inf)
+        f = fl if k > 0 else None
+        last = k == N - 1
+        ng = gs.process_frame(view, f, flush=last)
+        no = os_.process_frame(np.ascontiguousarray(view), f, flush=last)
+        assert ng == no
+        for i in range(no):
+            assert gs.result_bytes(i) == os_.result_bytes(i), (k, i)
+    gs.close()
+    os_.close()
+
+
+def test_invalid_arguments_are_rejected(vsg):
+    from video_segment_amd._lib import VsgError
+    with pytest.raises(VsgError):
+        vsg.DenseSegmentation(0, 48, vsg.default_options(), has_flow=True)
+    with pytest.raises(VsgError):
+        vsg.DenseSegmentation(64, 48, vsg.default_options(chunk_size=5), has_flow=True)   # overlap needs >= 8
+    s = vsg.DenseSegmentation(64, 48, vsg.default_options(), has_flow=True)
+    s.process_frame(synth.probe_frame(64, 48, 0), None)
+    with pytest.raises(VsgError):      # a stream created with flow needs a flow field from frame 1 on
+        s.process_frame(synth.probe_frame(64, 48, 1), None)
+    s.close()

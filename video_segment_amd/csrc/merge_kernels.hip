@@ -1349,7 +1349,10 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           // An edge with both ends (by then) inside the hot region is internal: every lane that
           // absorbs one of its ends is an earlier chain lane, committed if this lane is below the
           // cut.
-          if (both && lane < fcut && ((prefix >> lane) & 1ull)) pending = false;
+          // (the debug modes that shorten the chain leave these lanes to the next round's internal test)
+          if (both && lane < fcut && ((prefix >> lane) & 1ull) && !(kDbg && (dbg_flags & (32 | 64)))) {
+            pending = false;
+          }
           if (lane == 0) {
             if (kDbg) dbg_chain += (unsigned)__popcll(merging_mask & below);
             if (merging_mask & below) TabStore(tab, hot, Hn, kTabDirty);
