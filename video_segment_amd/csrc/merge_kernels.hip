@@ -1042,6 +1042,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
       }
       bool pending = valid && ra != rb;
       int sa = 0, sb = 0;     // table slots of the current roots of the two end regions
+      int mine_a = -1, mine_b = -1;   // slots this lane inserted (it writes them back and frees them)
       if (pending) {
         const RState A = LoadState(nodes, ra), B = LoadState(nodes, rb);   // both in flight
         bool ins_a, ins_b;
@@ -1057,6 +1058,8 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
         }
         atomicAdd(&tab.cnt[sa], 1);
         atomicAdd(&tab.cnt[sb], 1);
+        if (ins_a) mine_a = sa;
+        if (ins_b) mine_b = sb;
       }
       WaveSync();
       int hot = -1;   // wave-uniform slot of the hot region
@@ -1363,14 +1366,17 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
 
       if (valid && my_kept) kept_all[gpos] = 1;
       // ---- write the changed regions back, reset the table ---------------------------------------
-      for (int s = lane; s < kTabSize; s += 64) {
-        const int k = tab.key[s];
-        if (k >= 0) {
-          if (tab.link[s] == s && (tab.flags[s] & kTabDirty)) StoreState(nodes, k, TabLoad(tab, s));
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int s = e ? mine_b : mine_a;
+        if (s >= 0) {
+          if (tab.link[s] == s && (tab.flags[s] & kTabDirty)) {
+            StoreState(nodes, tab.key[s], TabLoad(tab, s));
+          }
           tab.key[s] = -1;
+          tab.res[s] = 0xffffffffu;
+          tab.cnt[s] = 0;
         }
-        tab.res[s] = 0xffffffffu;
-        tab.cnt[s] = 0;
       }
       // Make this batch's stores visible to the next batch's loads (same CU: L1 is shared).
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
