@@ -1361,8 +1361,10 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
             if (merging_mask & below) TabStore(tab, hot, Hn, kTabDirty);
           }
         }
+        if (!__ballot(pending)) break;   // nothing left: skip the next round's root resolution
         WaveSync();
       }
+      WaveSync();
 
       if (valid && my_kept) kept_all[gpos] = 1;
       // ---- write the changed regions back, reset the table ---------------------------------------
