@@ -116,3 +116,35 @@ def test_host_flow_reader_unit_feeds_the_hip_path():
         c = subprocess.run([exe, "--width", "32", "--height", "48", "--frames", "4", "--flow", "1",
                             "--flow_file", p], capture_output=True, text=True, timeout=300)
         assert c.returncode == 1 and "different dimension" in c.stderr
+
+
+@pytest.mark.gpu
+def test_raw_video_file_with_flow_file_next_to_it():
+    """seg_tree_sample's wiring on files: <video> + <video base>.flow (seg_tree.cpp:120-169) through
+    RawVideoReaderUnit -> DenseFlowReaderUnit -> DenseSegmentationUnit reproduces the App. B pin."""
+    from video_segment_amd.raw_video import read_raw_video, write_raw_video
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "video_segment_amd", "csrc"), "-j8", "-s"])
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    W, H, N = 64, 48, 45
+    exe = os.path.join(HOST, "seg_tree_synth")
+    with tempfile.TemporaryDirectory() as d:
+        video = os.path.join(d, "clip.rawv")
+        write_raw_video(video, [synth.probe_frame(W, H, k) for k in range(N)])
+        back, fps = read_raw_video(video)
+        assert back.shape == (N, H, W, 3) and fps == 25.0
+        w = flow_io.DenseFlowWriter(os.path.join(d, "clip.flow"))
+        w.open_and_write_header(W, H, flow_io.FLOW_BACKWARD)
+        for k in range(1, N):
+            w.add_flow_frame(synth.const_flow(W, H))
+        w.close()
+        a = subprocess.run([exe, "--input_file", video, "--flow", "1"], capture_output=True, text=True,
+                           timeout=300)
+        assert a.returncode == 0, a.stderr
+        assert "frames=45 first_frame_regions=240 total_regions=12385 label_fnv1a32=5ef008e2" in a.stdout
+        # without the .flow file the same clip is segmented without flow (different pin: no-flow run)
+        os.remove(os.path.join(d, "clip.flow"))
+        b = subprocess.run([exe, "--input_file", video, "--flow", "1"], capture_output=True, text=True,
+                           timeout=300)
+        assert b.returncode == 0, b.stderr
+        assert "frames=45" in b.stdout and "label_fnv1a32=5ef008e2" not in b.stdout
+

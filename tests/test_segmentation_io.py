@@ -49,6 +49,31 @@ def test_container_round_trip():
         assert chunks == 3 and [b for _, b in got] == frames
 
 
+def test_cpp_reader_reads_python_written_container():
+    """SegmentationReader of the host mirror (no GPU involved): frames, time stamps, resolution
+    and the label hash of the App. B pin come back from a file written by the Python writer."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "video_segment_amd", "csrc"), "-j8", "-s"])
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    W, H, N = 64, 48, 45
+    frames = oracle_frames(W, H, N)
+    with tempfile.TemporaryDirectory() as d:
+        for chunk_every in (None, 7):
+            p = os.path.join(d, "o.pb")
+            write_py(p, frames, chunk_every=chunk_every)
+            r = subprocess.run([os.path.join(HOST, "seg_tree_synth"), "--read_pb", p],
+                               capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stderr
+            assert "frames=45 first_frame_regions=240 total_regions=12385 label_fnv1a32=5ef008e2" in r.stdout
+            assert "width=64 height=48 header_flags=2 last_pts=%d" % (44 * 40000) in r.stdout
+            assert "bytes=%d " % sum(len(f) for f in frames) in r.stdout
+        # truncated file: no TERM header
+        q = os.path.join(d, "t.pb")
+        open(q, "wb").write(open(p, "rb").read()[:-8])
+        r = subprocess.run([os.path.join(HOST, "seg_tree_synth"), "--read_pb", q],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1
+
+
 @pytest.mark.gpu
 def test_host_writer_unit_matches_python_writer():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "video_segment_amd", "csrc"), "-j8", "-s"])

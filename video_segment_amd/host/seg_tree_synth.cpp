@@ -10,9 +10,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <string>
 
 #include "flow_reader.h"
+#include "raw_video_reader.h"
 #include "segmentation_io.h"
 #include "segmentation_unit.h"
 
@@ -146,9 +148,42 @@ class HashSinkUnit : public VideoUnit {
 
 }  // namespace
 
+// --read_pb FILE: reads a segmentation container back with SegmentationReader and prints what the
+// sink prints for a live run (frames, regions, label hash), without touching the GPU.
+int ReadBack(const std::string& file) {
+  SegmentationReader reader(file);
+  if (!reader.OpenFileAndReadHeaders()) return 1;
+  int width = 0, height = 0;
+  if (reader.NumFrames() > 0 && !reader.SegmentationResolution(&width, &height)) return 1;
+  uint32_t hash = 2166136261u;
+  long total_regions = 0;
+  int first_regions = 0;
+  size_t bytes = 0;
+  std::vector<int32_t> ids;
+  for (int k = 0; reader.RemainingFrames() > 0; ++k) {
+    SegmentationDesc desc;
+    if (!reader.ReadNextFrame(&desc) || !desc.ToIdImage(width, height, &ids)) return 1;
+    for (int32_t v : ids) {
+      for (int b = 0; b < 4; ++b) {
+        hash ^= (uint32_t)((uint32_t)v >> (8 * b)) & 0xffu;
+        hash *= 16777619u;
+      }
+    }
+    if (k == 0) first_regions = desc.NumRegions();
+    total_regions += desc.NumRegions();
+    bytes += desc.wire.size();
+  }
+  std::printf("frames=%d first_frame_regions=%d total_regions=%ld label_fnv1a32=%08x bytes=%zu "
+              "width=%d height=%d header_flags=%zu last_pts=%lld\n",
+              reader.NumFrames(), first_regions, total_regions, hash, bytes, width, height,
+              reader.GetHeaderFlags().size(),
+              reader.NumFrames() ? (long long)reader.TimeStamps().back() : 0ll);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   int width = 64, height = 48, frames = 45, chunk = 20, flow = 1, device = -1;
-  std::string input = "probe", write_to_file, flow_file, save_flow;
+  std::string input = "probe", write_to_file, flow_file, save_flow, input_file, read_pb;
   for (int i = 1; i + 1 < argc; i += 2) {
     const std::string k = argv[i];
     const char* v = argv[i + 1];
@@ -162,9 +197,25 @@ int main(int argc, char** argv) {
     else if (k == "--write_to_file") write_to_file = v;   // seg_tree.cpp:65
     else if (k == "--flow_file") flow_file = v;           // <input>.flow, seg_tree.cpp:121-125
     else if (k == "--save_flow") save_flow = v;           // seg_tree.cpp:67, 177-179
+    else if (k == "--input_file") input_file = v;         // raw BGR24 video, seg_tree.cpp:45
+    else if (k == "--read_pb") read_pb = v;
     else {
       std::fprintf(stderr, "unknown flag %s\n", k.c_str());
       return 2;
+    }
+  }
+  if (!read_pb.empty()) return ReadBack(read_pb);
+  // With --input_file the video comes from a raw BGR24 file and, as in seg_tree.cpp:120-126, the
+  // flow from "<input base>.flow" when that file exists.
+  std::unique_ptr<RawVideoReaderUnit> raw_reader;
+  if (!input_file.empty()) {
+    RawVideoReaderOptions ro;
+    ro.trim_frames = 0;
+    raw_reader.reset(new RawVideoReaderUnit(ro, input_file));
+    if (flow && flow_file.empty()) {
+      const std::string candidate = input_file.substr(0, input_file.find_last_of(".")) + ".flow";
+      if (std::ifstream(candidate.c_str()).good()) flow_file = candidate;
+      else flow = 0;   // no flow unit in this build: segment without temporal displacement
     }
   }
   // With --flow_file the flow comes from DenseFlowReaderUnit instead of the source
@@ -173,7 +224,8 @@ int main(int argc, char** argv) {
   SyntheticVideoUnit source(width, height, frames, flow != 0 && !flow_from_file, input == "bench",
                             save_flow);
   std::unique_ptr<DenseFlowReaderUnit> flow_reader;
-  VideoUnit* input_unit = &source;
+  VideoUnit* root_unit = raw_reader ? static_cast<VideoUnit*>(raw_reader.get()) : &source;
+  VideoUnit* input_unit = root_unit;
   if (flow_from_file) {
     flow_reader.reset(new DenseFlowReaderUnit(DenseFlowReaderOptions(), flow_file));
     flow_reader->AttachTo(input_unit);
@@ -196,12 +248,13 @@ int main(int argc, char** argv) {
     writer->AttachTo(&sink);
   }
 
-  if (!source.PrepareProcessing()) {
+  if (!root_unit->PrepareProcessing()) {
     std::fprintf(stderr, "ERROR: setup failed\n");
     return 1;
   }
   const auto t0 = std::chrono::steady_clock::now();
-  source.Run();
+  root_unit->Run();
+  if (raw_reader) frames = raw_reader->num_frames();
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::printf("frames=%d first_frame_regions=%d total_regions=%ld label_fnv1a32=%08x bytes=%zu "
               "seconds=%.3f fps=%.2f\n",

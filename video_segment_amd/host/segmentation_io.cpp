@@ -2,6 +2,7 @@
 #include "segmentation_io.h"
 
 #include <cstdio>
+#include <cstring>
 
 namespace segmentation {
 
@@ -93,6 +94,94 @@ void SegmentationWriterUnit::ProcessFrame(FrameSetPtr input, std::list<FrameSetP
 bool SegmentationWriterUnit::PostProcess(std::list<FrameSetPtr>* append) {
   writer_.WriteTermHeaderAndClose();
   return false;
+}
+
+// ---- SegmentationReader ------------------------------------------------------------------------
+bool SegmentationReader::OpenFileAndReadHeaders() {
+  ifs_.open(filename_.c_str(), std::ios_base::in | std::ios_base::binary);
+  if (!ifs_) {
+    std::fprintf(stderr, "ERROR: could not open segmentation file %s\n", filename_.c_str());
+    return false;
+  }
+  file_offsets_.clear();
+  time_stamps_.clear();
+  header_flags_.clear();
+  curr_frame_ = 0;
+  int32_t prev_header_id = -1;
+  for (;;) {
+    char tag[5] = {0, 0, 0, 0, 0};
+    ifs_.read(tag, 4);
+    if (!ifs_) {
+      std::fprintf(stderr, "ERROR: segmentation file ends without a TERM header\n");
+      return false;
+    }
+    if (std::strcmp(tag, "TERM") == 0) break;
+    if (std::strcmp(tag, "HEAD") == 0) {
+      int32_t num_entries = 0;
+      ifs_.read(reinterpret_cast<char*>(&num_entries), sizeof(num_entries));
+      if (!ifs_ || num_entries < 0 || num_entries > (1 << 20)) return false;
+      header_flags_.resize((size_t)num_entries);
+      ifs_.read(reinterpret_cast<char*>(header_flags_.data()), sizeof(int32_t) * (size_t)num_entries);
+      continue;
+    }
+    if (std::strcmp(tag, "CHNK") != 0) {
+      std::fprintf(stderr, "ERROR: parsing error, expected chunk header, found %s\n", tag);
+      return false;
+    }
+    int32_t header_id = 0, num_frames = 0;
+    ifs_.read(reinterpret_cast<char*>(&header_id), sizeof(header_id));
+    ifs_.read(reinterpret_cast<char*>(&num_frames), sizeof(num_frames));
+    if (!ifs_ || header_id != prev_header_id + 1 || num_frames < 0) return false;
+    prev_header_id = header_id;
+    const size_t old = file_offsets_.size();
+    file_offsets_.resize(old + (size_t)num_frames);
+    time_stamps_.resize(old + (size_t)num_frames);
+    ifs_.read(reinterpret_cast<char*>(file_offsets_.data() + old), sizeof(int64_t) * (size_t)num_frames);
+    ifs_.read(reinterpret_cast<char*>(time_stamps_.data() + old), sizeof(int64_t) * (size_t)num_frames);
+    int64_t next_header_pos = 0;
+    ifs_.read(reinterpret_cast<char*>(&next_header_pos), sizeof(next_header_pos));
+    if (!ifs_) return false;
+    ifs_.seekg(next_header_pos);
+  }
+  return true;
+}
+
+bool SegmentationReader::SeekToFrame(int frame) {
+  if (frame < 0 || frame >= NumFrames()) return false;
+  curr_frame_ = frame;
+  return true;
+}
+
+bool SegmentationReader::ReadNextFrameBinary(std::string* data) {
+  if (curr_frame_ >= NumFrames()) return false;
+  ifs_.clear();
+  ifs_.seekg(file_offsets_[(size_t)curr_frame_]);
+  char tag[5] = {0, 0, 0, 0, 0};
+  ifs_.read(tag, 4);
+  int32_t frame_sz = 0;
+  ifs_.read(reinterpret_cast<char*>(&frame_sz), sizeof(frame_sz));
+  if (!ifs_ || std::strcmp(tag, "SEGD") != 0 || frame_sz < 0) {
+    std::fprintf(stderr, "ERROR: expecting segmentation header, error parsing file\n");
+    return false;
+  }
+  data->resize((size_t)frame_sz);
+  if (frame_sz) ifs_.read(&(*data)[0], frame_sz);
+  if (!ifs_) return false;
+  ++curr_frame_;
+  return true;
+}
+
+bool SegmentationReader::ReadNextFrame(SegmentationDesc* desc) {
+  return ReadNextFrameBinary(&desc->wire) && desc->NumRegions() >= 0;
+}
+
+bool SegmentationReader::SegmentationResolution(int* width, int* height) {
+  const int playhead = curr_frame_;
+  SegmentationDesc first;
+  if (!SeekToFrame(0) || !ReadNextFrame(&first)) return false;
+  const bool ok = first.FrameSize(width, height);
+  if (playhead < NumFrames()) SeekToFrame(playhead);
+  return ok;
 }
 
 }  // namespace segmentation

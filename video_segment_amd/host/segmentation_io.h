@@ -38,6 +38,31 @@ class SegmentationWriter {
   std::vector<std::string> chunk_buffer_;
 };
 
+// Reader of the same container (segment_util/segmentation_io.h:117-170, segmentation_io.cpp:168-300):
+// walks the CHNK headers up to TERM, then serves frames by file offset.
+class SegmentationReader {
+ public:
+  explicit SegmentationReader(const std::string& filename) : filename_(filename) {}
+  bool OpenFileAndReadHeaders();
+  // Width / height of the first frame (SegmentationDesc.frame_width / frame_height).
+  bool SegmentationResolution(int* width, int* height);
+  bool ReadNextFrameBinary(std::string* data);
+  bool ReadNextFrame(SegmentationDesc* desc);
+  const std::vector<int32_t>& GetHeaderFlags() const { return header_flags_; }
+  const std::vector<int64_t>& TimeStamps() const { return time_stamps_; }
+  bool SeekToFrame(int frame);
+  int NumFrames() const { return (int)file_offsets_.size(); }
+  int RemainingFrames() const { return NumFrames() - curr_frame_; }
+  void CloseFile() { ifs_.close(); }
+
+ private:
+  std::string filename_;
+  std::ifstream ifs_;
+  std::vector<int64_t> file_offsets_, time_stamps_;
+  std::vector<int32_t> header_flags_;
+  int curr_frame_ = 0;
+};
+
 struct SegmentationWriterUnitOptions {
   std::string video_stream_name = "VideoStream";
   std::string segment_stream_name = "SegmentationStream";

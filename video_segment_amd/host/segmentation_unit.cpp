@@ -107,6 +107,20 @@ int SegmentationDesc::NumRegions() const {
   return top.ok ? n : -1;
 }
 
+bool SegmentationDesc::FrameSize(int* width, int* height) const {
+  Cursor top{reinterpret_cast<const uint8_t*>(wire.data()),
+             reinterpret_cast<const uint8_t*>(wire.data()) + wire.size()};
+  int f, wt, seen = 0;
+  uint64_t v;
+  Cursor sub{nullptr, nullptr};
+  while (top.Next(&f, &wt, &sub, &v)) {
+    if (wt != 0) continue;
+    if (f == 4) { *width = (int)(int64_t)v; seen |= 1; }
+    if (f == 5) { *height = (int)(int64_t)v; seen |= 2; }
+  }
+  return top.ok && seen == 3;
+}
+
 // ---- DenseSegmentationUnit ------------------------------------------------------------------
 DenseSegmentationUnit::DenseSegmentationUnit(const DenseSegmentationUnitOptions& options,
                                              const DenseSegmentationOptions* dense_seg_options)

@@ -29,6 +29,8 @@ struct SegmentationDesc {
   // segment_util/segmentation_util.cpp:741-770).  Returns false on malformed input.
   bool ToIdImage(int width, int height, std::vector<int32_t>* out) const;
   int NumRegions() const;
+  // frame_width (field 4) / frame_height (field 5); false if absent or malformed.
+  bool FrameSize(int* width, int* height) const;
 };
 
 // Same fields and defaults as the reference (dense_segmentation.h:42-95).
