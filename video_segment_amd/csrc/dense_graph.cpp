@@ -314,11 +314,12 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
       if (te - ts > 1.0) {
         std::fprintf(stderr, "[vsg] stage b=%d n_b=%d wall %.2f ms wave %.2f ms | wave edges %llu batches %llu "
                      "rounds %llu nwin %llu (solo %llu) chain %llu cuts %llu | max_seg %llu slowest %.2f Mcyc | "
-                     "cyc load %.1f M loop %.1f M wait %.1f M | producer work %.1f M wait %.1f M\n",
+                     "cyc load %.1f M loop %.1f M wait %.1f M | producer work %.1f M wait %.1f M | taken %llu live %llu\n",
                      b, n_b, te - ts, wave_ms, s1[3] - s0[3], s1[7] - s0[7], s1[5] - s0[5],
                      s1[4] - s0[4], s1[6] - s0[6], s1[20] - s0[20], s1[21] - s0[21], s1[17],
                      s1[16] / 1e6, (s1[18] - s0[18]) / 1e6, (s1[19] - s0[19]) / 1e6,
-                     (s1[26] - s0[26]) / 1e6, (s1[27] - s0[27]) / 1e6, (s1[28] - s0[28]) / 1e6);
+                     (s1[26] - s0[26]) / 1e6, (s1[27] - s0[27]) / 1e6, (s1[28] - s0[28]) / 1e6,
+                     s1[29] - s0[29], s1[30] - s0[30]);
       }
     }
   }

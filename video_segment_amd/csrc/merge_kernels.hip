@@ -870,7 +870,10 @@ __device__ __forceinline__ int WaveMax(int v) {
 }
 
 constexpr int kFill = 4;        // 64-edge chunks read per fill
-constexpr int kQueue = 512;     // ring capacity >= 63 + kFill * 64, power of two
+constexpr int kQueue = 512;     // ring capacity >= kLag + kFill * 64, power of two
+// The producer reads on while fewer than kLag edges wait in the ring: enough to keep the consumer
+// busy for a batch or two, few enough that the roots it found are mostly still current.
+constexpr int kLag = 128;
 
 struct WaveQueue {
   int32_t ra[kQueue];
@@ -879,6 +882,13 @@ struct WaveQueue {
   int produced;   // entries pushed by the producer wave (monotonic)
   int consumed;   // entries taken by the consumer wave (monotonic)
   int done;       // the producer has read the whole component
+};
+
+// Live edges staged by the consumer (<= 63 left over + 64 new).
+struct WaveStage {
+  int32_t ra[128];
+  int32_t rb[128];
+  uint32_t gpos[128];
 };
 
 // Orders the LDS accesses of the lanes of ONE wavefront (they execute in order in hardware; this
@@ -904,6 +914,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
   __shared__ WaveTable tab;
   auto Clock = []() -> unsigned long long { return kDbg ? __builtin_readcyclecounter() : 0ull; };
   __shared__ WaveQueue queue;
+  __shared__ WaveStage stage;
   const int lane = threadIdx.x & 63;
   const bool producer = threadIdx.x >= 64;   // wave 1 reads ahead, wave 0 replays
   for (int s = threadIdx.x; s < kTabSize; s += 128) {
@@ -915,6 +926,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
   const int nseg = *num_segs;
   unsigned n_forced = 0, n_regular = 0, n_small = 0;   // per lane, reduced at the end
   unsigned dbg_rounds = 0, dbg_nwin = 0, dbg_chain = 0, dbg_solo = 0, dbg_batches = 0, dbg_cut = 0;
+  unsigned long long dbg_taken = 0, dbg_live = 0;
   unsigned long long cyc_load = 0, cyc_loop = 0, cyc_wait = 0;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int cnt = seg_cnt[seg];
@@ -937,7 +949,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
       for (int next = beg; next < end; next += kFill * 64) {
         const unsigned long long pt0 = Clock();
         while (produced - __hip_atomic_load(&queue.consumed, __ATOMIC_ACQUIRE,
-                                            __HIP_MEMORY_SCOPE_WORKGROUP) > kQueue - kFill * 64) {
+                                            __HIP_MEMORY_SCOPE_WORKGROUP) > kLag) {
           __builtin_amdgcn_s_sleep(2);
         }
         const unsigned long long pt1 = Clock();
@@ -1005,42 +1017,106 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
     if (lane == 0) atomicAdd(&stats[3], (unsigned long long)cnt);
     const unsigned long long seg_t0 = Clock();
     int consumed = 0;   // wave-uniform
+    int n_raw = 0;      // staged edges left over from the previous batch: roots to be re-validated
     for (;;) {
       const unsigned long long bt0 = Clock();
-      int avail;
-      for (;;) {   // `done` is read before `produced`: once done is set, produced is final
-        const int done = __hip_atomic_load(&queue.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        avail = __hip_atomic_load(&queue.produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) -
-                consumed;
-        if (avail >= 64 || done) break;
-        __builtin_amdgcn_s_sleep(2);
+      // ---- stage 64 live edges -----------------------------------------------------------------------
+      // The roots the producer found may be stale by now (the ring holds several batches); a large
+      // share of the ring's edges is internal by the time it is taken.  A pass re-validates up
+      // to 64 candidates (the left-overs of the previous batch first, then ring entries) and packs
+      // the live ones in order; passes repeat until 64 live edges are staged or the component is
+      // drained, so that the fixed cost of a batch is spent on live edges only.
+      int n_valid = 0;
+      bool drained = false;
+      while (n_valid < 64 && !drained) {
+        const int want = 64 - n_raw;
+        int avail;
+        for (;;) {   // `done` is read before `produced`: once done is set, produced is final
+          const int done = __hip_atomic_load(&queue.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          avail = __hip_atomic_load(&queue.produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) -
+                  consumed;
+          if (avail >= want || done) {
+            if (done && avail <= want) drained = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        const int t = avail < want ? avail : want;
+        if (n_raw + t == 0) break;
+        int ca = 0, cb = 0;
+        uint32_t cg = 0;
+        const bool cand = lane < n_raw + t;
+        if (lane < n_raw) {
+          ca = stage.ra[lane];
+          cb = stage.rb[lane];
+          cg = stage.gpos[lane];
+        } else if (cand) {
+          const int slot = (consumed + lane - n_raw) & (kQueue - 1);
+          ca = queue.ra[slot];
+          cb = queue.rb[slot];
+          cg = queue.gpos[slot];
+        }
+        for (bool more = cand; more;) {
+          const int pa = nodes.parent[ca], pb = nodes.parent[cb];
+          more = (pa != ca) || (pb != cb);
+          ca = pa;
+          cb = pb;
+        }
+        consumed += t;
+        WaveSync();   // the candidates are in registers: ring slots and stage slots may be reused
+        if (lane == 0 && t > 0) {
+          __hip_atomic_store(&queue.consumed, consumed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const bool live = cand && ca != cb;
+        const unsigned long long lm = __ballot(live);
+        if (live) {
+          const int pos = n_valid + (int)__popcll(lm & ((1ull << lane) - 1ull));
+          stage.ra[pos] = ca;
+          stage.rb[pos] = cb;
+          stage.gpos[pos] = cg;
+        }
+        if (kDbg && lane == 0) {
+          dbg_taken += (unsigned)(n_raw + t);
+          dbg_live += (unsigned)__popcll(lm);
+        }
+        n_valid += (int)__popcll(lm);
+        n_raw = 0;
+        WaveSync();
       }
-      if (avail == 0) break;
+      if (n_valid == 0) {
+        if (drained) break;
+        continue;
+      }
       const unsigned long long bt0b = Clock();
       cyc_wait += bt0b - bt0;
-      // ---- take up to 64 pending edges: current roots, region table --------------------------------
-      const int take = avail < 64 ? avail : 64;
+      // ---- the batch: the first 64 staged edges (their roots are current) ------------------------
+      const int take = n_valid < 64 ? n_valid : 64;
       const bool valid = lane < take;
       int ra = -1, rb = -1;
       uint32_t gpos = 0;
       if (valid) {
-        const int slot = (consumed + lane) & (kQueue - 1);
-        ra = queue.ra[slot];
-        rb = queue.rb[slot];
-        gpos = queue.gpos[slot];
-        for (bool more = true; more;) {   // the producer's roots may be stale by now
-          const int pa = nodes.parent[ra], pb = nodes.parent[rb];
-          more = (pa != ra) || (pb != rb);
-          ra = pa;
-          rb = pb;
+        ra = stage.ra[lane];
+        rb = stage.rb[lane];
+        gpos = stage.gpos[lane];
+      }
+      n_raw = n_valid - take;
+      if (n_raw > 0) {   // move the rest to the front; it is re-validated by the next pass
+        int xa = 0, xb = 0;
+        uint32_t xg = 0;
+        if (lane < n_raw) {
+          xa = stage.ra[64 + lane];
+          xb = stage.rb[64 + lane];
+          xg = stage.gpos[64 + lane];
+        }
+        WaveSync();
+        if (lane < n_raw) {
+          stage.ra[lane] = xa;
+          stage.rb[lane] = xb;
+          stage.gpos[lane] = xg;
         }
       }
-      consumed += take;
       WaveSync();
-      if (lane == 0) {
-        __hip_atomic_store(&queue.consumed, consumed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      bool pending = valid && ra != rb;
+      bool pending = valid;
       int sa = 0, sb = 0;     // table slots of the current roots of the two end regions
       int mine_a = -1, mine_b = -1;   // slots this lane inserted (it writes them back and frees them)
       if (pending) {
@@ -1135,33 +1211,42 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           // lane is replayed the region is part of the hot one.  So a run of edges p1-p2, p2-p3, ...
           // hanging off the hot region joins the chain in one round.  The set of absorbing lanes
           // only grows, so the loop ends (no memory access inside).
+          // Per end, evaluated once: would this end qualify as the partner of a chain edge
+          // (plain, smaller, owned by this lane) and would the edge merge?
+          // Case S (partner with the hot region's constraint) merges unless the descriptors are
+          // further apart than the split threshold, whatever the sizes and flags; Case U
+          // (unconstrained partner): regular test while the hot region is not finalized, a finalized
+          // hot region (>= min size) absorbs small partners only.
+          const bool base = pending && mode_ok && !failed;
+          const bool part_a = base && own_a && A.flags == 0 && (A.cons < 0 || A.cons == Hs.cons) &&
+                              A.sz < Hs.sz;
+          const bool part_b = base && own_b && B.flags == 0 && (B.cons < 0 || B.cons == Hs.cons) &&
+                              B.sz < Hs.sz;
+          const bool merge_a = part_a && (A.cons >= 0 || !fin || A.sz < T.min_size);
+          const bool merge_b = part_b && (B.cons >= 0 || !fin || B.sz < T.min_size);
+          const bool abs_a = pending && !own_a, abs_b = pending && !own_b;   // may be absorbed
           unsigned long long em = 0;   // chain lanes that merge
+          bool ea, eb;
           for (;;) {
-            const bool ea = a_hot || (pending && !own_a && ((em >> oa) & 1ull));
-            const bool eb = b_hot || (pending && !own_b && ((em >> ob) & 1ull));
-            hot_lane = pending && (ea || eb);
-            both = hot_lane && ea && eb;
-            const bool part_b = ea;   // the partner is the end that is not effectively hot
-            P.d0 = part_b ? B.d0 : A.d0;
-            P.d1 = part_b ? B.d1 : A.d1;
-            P.d2 = part_b ? B.d2 : A.d2;
-            P.sz = part_b ? B.sz : A.sz;
-            P.cons = part_b ? B.cons : A.cons;
-            P.flags = part_b ? B.flags : A.flags;
-            ps = part_b ? sb : sa;
-            const bool own_p = part_b ? own_b : own_a;
-            // unconstrained partner (Case U), or partner with the hot region's constraint (Case S)
-            elig = hot_lane && !both && mode_ok && own_p && !failed && P.flags == 0 &&
-                   (P.cons < 0 || P.cons == Hs.cons) && P.sz < Hs.sz;
-            case_s = P.cons >= 0;
-            // Case S merges unless the descriptors are further apart than the split threshold,
-            // whatever the sizes and flags; Case U: regular test while the hot region is not
-            // finalized, a finalized hot region (>= min size) absorbs small partners only.
-            merging = elig && (case_s || !fin || P.sz < T.min_size);
-            const unsigned long long em2 = __ballot(merging);
+            ea = a_hot || (abs_a && ((em >> oa) & 1ull));
+            eb = b_hot || (abs_b && ((em >> ob) & 1ull));
+            const unsigned long long em2 = __ballot((ea && !eb && merge_b) || (eb && !ea && merge_a));
             if (em2 == em) break;
             em = em2;
           }
+          hot_lane = pending && (ea || eb);
+          both = hot_lane && ea && eb;
+          const bool pb_side = ea;   // the partner is the end that is not effectively hot
+          P.d0 = pb_side ? B.d0 : A.d0;
+          P.d1 = pb_side ? B.d1 : A.d1;
+          P.d2 = pb_side ? B.d2 : A.d2;
+          P.sz = pb_side ? B.sz : A.sz;
+          P.cons = pb_side ? B.cons : A.cons;
+          P.flags = 0;
+          ps = pb_side ? sb : sa;
+          elig = hot_lane && !both && (pb_side ? part_b : part_a);
+          merging = hot_lane && !both && (pb_side ? merge_b : merge_a);
+          case_s = P.cons >= 0;
         }
         const unsigned long long hot_mask = __ballot(hot_lane);
         const unsigned long long elig_mask = __ballot(elig);
@@ -1418,6 +1503,8 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
     atomicAdd(&stats[19], cyc_loop);
     atomicAdd(&stats[20], (unsigned long long)dbg_chain);
     atomicAdd(&stats[21], (unsigned long long)dbg_cut);
+    atomicAdd(&stats[29], dbg_taken);
+    atomicAdd(&stats[30], dbg_live);
   }
 }
 
