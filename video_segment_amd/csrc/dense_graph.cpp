@@ -57,7 +57,7 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   keys_sorted_tmp_.alloc(9 * wh_);
   vals_tmp_.alloc(9 * wh_);
   scalars_.alloc(16);
-  stats_.alloc(32);
+  stats_.alloc(48);
   size_t temp = SortPairsU16TempBytes((int)(9 * wh_));
   temp = std::max(temp, ScanTempBytes((int)N));
   cub_temp_.alloc(temp);
@@ -204,7 +204,7 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   LaunchBuildBucketTable(list_desc_dev_.get(), L, bucket_base_dev_.get(), stream_);
   bucket_base_host_.resize((size_t)(kNumBuckets + 1) * (L + 1));
   D2H(bucket_base_host_.data(), bucket_base_dev_.get(), bucket_base_host_.size(), stream_);
-  VSG_HIP(hipMemsetAsync(stats_.get(), 0, 32 * sizeof(unsigned long long), stream_));
+  VSG_HIP(hipMemsetAsync(stats_.get(), 0, 48 * sizeof(unsigned long long), stream_));
   LaunchInitIdentity(cc_.get(), N, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
 
@@ -288,12 +288,12 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   for (int b = 0; b < kNumBuckets; ++b) {
     const int n_b = bucket_base_host_[(size_t)b * (L + 1) + L];
     if (n_b == 0) continue;
-    unsigned long long s0[32] = {0}, s1[32] = {0};
+    unsigned long long s0[48] = {0}, s1[48] = {0};
     double ts = 0;
     size_t ev0 = 0;
     if (debug_stages) {
       VSG_HIP(hipMemsetAsync(stats_.get() + 16, 0, 2 * sizeof(unsigned long long), stream_));
-      D2H(s0, stats_.get(), 32, stream_);
+      D2H(s0, stats_.get(), 48, stream_);
       VSG_HIP(hipStreamSynchronize(stream_));
       ts = NowMs();
       ev0 = ev_wave_.size();
@@ -302,7 +302,7 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
                    list_slot_base_dev_.get(), kept_all_.get(), nodes(), P, inert_mode, S,
                    stream_);
     if (debug_stages) {
-      D2H(s1, stats_.get(), 32, stream_);
+      D2H(s1, stats_.get(), 48, stream_);
       VSG_HIP(hipStreamSynchronize(stream_));
       const double te = NowMs();
       float wave_ms = 0;
@@ -314,12 +314,17 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
       if (te - ts > 1.0) {
         std::fprintf(stderr, "[vsg] stage b=%d n_b=%d wall %.2f ms wave %.2f ms | wave edges %llu batches %llu "
                      "rounds %llu nwin %llu (solo %llu) chain %llu cuts %llu | max_seg %llu slowest %.2f Mcyc | "
-                     "cyc load %.1f M loop %.1f M wait %.1f M | producer work %.1f M wait %.1f M | taken %llu live %llu\n",
+                     "cyc load %.1f M loop %.1f M wait %.1f M | producer work %.1f M wait %.1f M | taken %llu live %llu | "
+                     "round phases (Mcyc): reserve+load %.0f closure %.0f masks %.0f generic %.0f chain %.0f | per round sums: pending %llu hot %llu "
+                     "blocked %llu chain-rounds %llu generic-rounds %llu waiting-nonhot %llu\n",
                      b, n_b, te - ts, wave_ms, s1[3] - s0[3], s1[7] - s0[7], s1[5] - s0[5],
                      s1[4] - s0[4], s1[6] - s0[6], s1[20] - s0[20], s1[21] - s0[21], s1[17],
                      s1[16] / 1e6, (s1[18] - s0[18]) / 1e6, (s1[19] - s0[19]) / 1e6,
                      (s1[26] - s0[26]) / 1e6, (s1[27] - s0[27]) / 1e6, (s1[28] - s0[28]) / 1e6,
-                     s1[29] - s0[29], s1[30] - s0[30]);
+                     s1[29] - s0[29], s1[30] - s0[30], (s1[32] - s0[32]) / 1e6, (s1[33] - s0[33]) / 1e6,
+                     (s1[34] - s0[34]) / 1e6, (s1[35] - s0[35]) / 1e6, (s1[36] - s0[36]) / 1e6,
+                     s1[38] - s0[38], s1[39] - s0[39], s1[40] - s0[40], s1[41] - s0[41], s1[42] - s0[42],
+                     s1[43] - s0[43]);
       }
     }
   }

@@ -927,6 +927,8 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
   unsigned n_forced = 0, n_regular = 0, n_small = 0;   // per lane, reduced at the end
   unsigned dbg_rounds = 0, dbg_nwin = 0, dbg_chain = 0, dbg_solo = 0, dbg_batches = 0, dbg_cut = 0;
   unsigned long long dbg_taken = 0, dbg_live = 0;
+  unsigned long long cyc_ph[5] = {0, 0, 0, 0, 0};
+  unsigned long long dbg_x[6] = {0, 0, 0, 0, 0, 0};   // reserve+load, closure, masks, generic, chain
   unsigned long long cyc_load = 0, cyc_loop = 0, cyc_wait = 0;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int cnt = seg_cnt[seg];
@@ -1174,6 +1176,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           if (lane == 0) atomicAdd(&stats[22], 1ull);
           break;
         }
+        const unsigned long long ph0 = Clock();
         const bool a_hot = (sa == hot), b_hot = (sb == hot);
         const uint32_t key = ((0xfffffu - round) << 6) | (uint32_t)lane;
         if (pending) {
@@ -1190,6 +1193,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           B = TabLoad(tab, sb);
         }
         // own_x: this lane is the earliest pending edge on region x (the hot region is not reserved)
+        const unsigned long long ph1 = Clock();
         const bool own_a = pending && !a_hot && res_a == key;
         const bool own_b = pending && !b_hot && res_b == key;
         const int oa = (int)(res_a & 63u), ob = (int)(res_b & 63u);   // owners (earlier lanes)
@@ -1201,7 +1205,13 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
         bool merging = false;
         bool case_s = false;
         bool fin = false;
-        if (__ballot(hot_lane)) {
+        // A chain starts at the first edge that touches the hot region and only if that lane is the
+        // earliest pending edge on its other end; otherwise nothing can be absorbed in this round
+        // and the classification below is skipped (the other hot edges just wait).
+        const unsigned long long lit_mask = __ballot(hot_lane);
+        const bool chain_possible =
+            lit_mask != 0 && ((__ballot(hot_lane && (own_a || own_b)) >> __builtin_ctzll(lit_mask)) & 1ull);
+        if (chain_possible) {
           Hs = TabLoad(tab, hot);   // uniform
           fin = (Hs.flags & kFlagFinalized) != 0;
           const bool mode_ok = !(Hs.flags & kFlagNoDesc) && (!fin || Hs.sz >= T.min_size) &&
@@ -1248,6 +1258,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           merging = hot_lane && !both && (pb_side ? merge_b : merge_a);
           case_s = P.cons >= 0;
         }
+        const unsigned long long ph2 = Clock();
         const unsigned long long hot_mask = __ballot(hot_lane);
         const unsigned long long elig_mask = __ballot(elig);
         // hot lanes that are neither chain lanes nor internal end the chain
@@ -1269,13 +1280,21 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
         if (kDbg && (dbg_flags & 8)) n_win = n_win && lane == (int)__builtin_ctzll(__ballot(pending));
         if constexpr (kDbg) {
           const unsigned long long nwin_mask = __ballot(n_win), solo_mask = __ballot(solo);
+          const unsigned long long pend_mask = __ballot(pending);
           if (lane == 0) {
             ++dbg_rounds;
             dbg_nwin += (unsigned)__popcll(nwin_mask);
             dbg_solo += (unsigned)__popcll(solo_mask);
+            dbg_x[0] += (unsigned)__popcll(pend_mask);                 // pending lanes per round
+            dbg_x[1] += (unsigned)__popcll(hot_mask);                  // (effectively) hot lanes
+            dbg_x[2] += (unsigned)__popcll(blocked);                   // hot lanes that end the chain
+            dbg_x[3] += (chain_mask != 0);                             // rounds with a chain
+            dbg_x[4] += (nwin_mask != 0);                              // rounds with generic commits
+            dbg_x[5] += (unsigned)__popcll(pend_mask & ~hot_mask & ~nwin_mask);   // waiting non-hot lanes
           }
         }
 
+        const unsigned long long ph3 = Clock();
         // ---- lanes that own both regions: generic edge ------------------------------------------
         if (n_win) {
           const RState& s1 = A;
@@ -1343,6 +1362,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           pending = false;
         }
 
+        const unsigned long long ph4 = Clock();
         // ---- the chain on the hot region -----------------------------------------------------
         if (chain_mask) {
           const bool in_chain = (chain_mask >> lane) & 1ull;
@@ -1446,6 +1466,14 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
             if (merging_mask & below) TabStore(tab, hot, Hn, kTabDirty);
           }
         }
+        if constexpr (kDbg) {
+          const unsigned long long ph5 = Clock();
+          cyc_ph[0] += ph1 - ph0;
+          cyc_ph[1] += ph2 - ph1;
+          cyc_ph[2] += ph3 - ph2;
+          cyc_ph[3] += ph4 - ph3;
+          cyc_ph[4] += ph5 - ph4;
+        }
         if (!__ballot(pending)) break;   // nothing left: skip the next round's root resolution
         WaveSync();
       }
@@ -1504,6 +1532,8 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
     atomicAdd(&stats[20], (unsigned long long)dbg_chain);
     atomicAdd(&stats[21], (unsigned long long)dbg_cut);
     atomicAdd(&stats[29], dbg_taken);
+    for (int k = 0; k < 5; ++k) atomicAdd(&stats[32 + k], cyc_ph[k]);
+    for (int k = 0; k < 6; ++k) atomicAdd(&stats[38 + k], dbg_x[k]);
     atomicAdd(&stats[30], dbg_live);
   }
 }
