@@ -56,6 +56,11 @@ def parse():
                     help="concurrent independent 1080p streams per GPU (default 1 = the BASELINE "
                          "workload; >1 only quantifies how idle one stream leaves the GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 "
+                         "control flow on a box with fewer GPUs than ranks, with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing only: all ranks use device 0")
     ap.add_argument("--cpu-frames", type=int, default=20)
     return ap.parse_args()
 
@@ -92,10 +97,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     import synth
     import video_segment_amd as vsg
 

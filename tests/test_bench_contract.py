@@ -1,0 +1,62 @@
+"""bench.py contract: one JSON line with the required keys; the N > 1 control flow (barriers,
+reductions, chunk-chain hand-off) exercised with two ranks sharing the one GPU of the test box
+(gloo instead of RCCL, which refuses two ranks on one device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def last_json_line(text):
+    for line in reversed(text.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError(text)
+
+
+def check(out, n_gpus, steps, warmup):
+    for k in REQUIRED:
+        assert k in out, k
+    assert out["n_gpus"] == n_gpus and out["steps"] == steps and out["warmup"] == warmup
+    assert out["value"] > 0 and out["higher_is_better"] is True and out["scaling"] == "weak"
+    assert out["unit"] == "frames/s" and out["dtype"] == "f32" and out["data"] == "synthetic"
+    assert "workload" in out["config"] and "model" not in out["config"]
+    r = out["roofline"]
+    for k in ["bound", "achieved", "peak", "unit", "frac", "traffic"]:
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_and_cpu_baseline():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                        "--width", "320", "--height", "240", "--cpu-frames", "20"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = last_json_line(p.stdout)
+    check(out, 1, 2, 1)
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,port", [("streams", "29611"), ("chain", "29612")])
+def test_two_ranks_control_flow(mode, port):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "256", "--height", "144",
+           "--mode", mode, "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    out = last_json_line(p.stdout)
+    check(out, 2, 2, 1)
+    # two ranks x two timed steps x 19 frames (streams) or one 4-chunk video (chain: 20 + 3 x 19)
+    frames = out["value"] * out["ms_per_step"] * out["steps"] / 1e3
+    assert abs(frames - (76 if mode == "streams" else 77)) < 1e-6

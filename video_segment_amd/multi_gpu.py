@@ -109,7 +109,13 @@ def run_chain(engine_factory, get_frame, get_flow, num_frames, chunk, width, hei
 
 
 def run_chain_bench(args, rank, world, local_rank):
-    """bench.py --mode chain: one long video sharded chunk-wise over the ranks (RCCL hand-off)."""
+    """bench.py --mode chain: one long video sharded chunk-wise over the ranks (RCCL hand-off).
+
+    The chain is a pipeline (rank r cannot start chunk c before rank r-1 has finished chunk c-1),
+    so a barrier in the middle of a video would deadlock against the blocking hand-off.  Warm-up
+    and measurement are therefore two separate videos: `warmup` chunks per rank, barrier, then
+    `steps` chunks per rank timed between two barriers (weak scaling: the video grows with the
+    number of ranks)."""
     import time
     import torch
     import torch.distributed as dist
@@ -119,69 +125,73 @@ def run_chain_bench(args, rank, world, local_rank):
     W, H, chunk = args.width, args.height, args.chunk
     K, Wm = args.steps, args.warmup
     dev = torch.device("cuda", local_rank)
-    # K timed chunks per rank (weak scaling: the video grows with the number of ranks), after Wm
-    # warm-up chunks per rank.
-    total_chunks = (Wm + K) * world
-    num_frames = chunk + (chunk - 1) * (total_chunks - 1)
-    plan = chunk_plan(num_frames, chunk)
-    mine = [c for c in range(len(plan)) if c % world == rank]
-    frames = {}
-    for c in mine:
-        for k in range(plan[c][0], plan[c][1] + 1):
-            if k not in frames:
-                frames[k] = torch.from_numpy(synth.bench_frame(W, H, k)).to(dev)
     flow = torch.from_numpy(synth.const_flow(W, H)).to(dev)
     transport = DistTransport(dev)
-    eng = None
-    torch.cuda.synchronize()
-    dist.barrier()
     acc = {"wave_ms": 0.0, "wave_launches": 0, "wave_edges": 0, "merge_ms": 0.0, "pre_ms": 0.0,
            "edges_ms": 0.0, "readout_ms": 0.0, "host_ms": 0.0, "filter_ms": 0.0,
            "filter_launches": 0, "edges_total": 0, "merges": 0}
-    frames_out = 0
-    t0 = None
-    for idx, c in enumerate(mine):
-        if idx == Wm:
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-        first, last = plan[c]
-        eng = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=local_rank),
-                                    has_flow=True)
-        if c > 0:
-            virt, cons, scal = transport.recv((c - 1) % world, c,
-                                              [((H, W), torch.int32), ((H, W), torch.int32),
-                                               ((4,), torch.int64)])
-            eng.import_halo(virt, cons, scal.cpu().numpy())
-        for k in range(first, last + 1):
-            n = eng.process_frame(frames[k], flow if k > 0 else None, flush=(k == num_frames - 1))
-            if n and idx >= Wm:
-                frames_out += n
-                t = eng.last_timings()
-                acc["wave_ms"] += t.wave_kernel_ms
-                acc["wave_launches"] += t.wave_kernel_launches
-                acc["wave_edges"] += t.wave_kernel_edges
-                acc["filter_ms"] += t.filter_kernel_ms
-                acc["filter_launches"] += t.filter_kernel_launches
-                acc["merge_ms"] += t.merge_ms
-                acc["pre_ms"] += t.preprocess_ms
-                acc["edges_ms"] += t.edges_ms
-                acc["readout_ms"] += t.readout_ms
-                acc["host_ms"] += t.host_post_ms
-                acc["edges_total"] += t.edges_total
-                acc["merges"] += t.merges
-        if c + 1 < len(plan):
-            pa, pb, scal = eng.export_halo()
-            n_el = W * H
-            ta = torch.empty((H, W), dtype=torch.int32, device=dev)
-            tb = torch.empty((H, W), dtype=torch.int32, device=dev)
-            # device-to-device copies out of the library-owned planes
-            torch.cuda.synchronize()
-            ta.copy_(_wrap_device_int32(pa, n_el, dev).view(H, W))
-            tb.copy_(_wrap_device_int32(pb, n_el, dev).view(H, W))
-            transport.send((c + 1) % world, c + 1,
-                           [ta, tb, torch.from_numpy(scal).to(dev)])
-        eng.close()
+
+    def load(total_chunks):
+        num_frames = chunk + (chunk - 1) * (total_chunks - 1)
+        plan = chunk_plan(num_frames, chunk)
+        mine = [c for c in range(len(plan)) if c % world == rank]
+        frames = {}
+        for c in mine:
+            for k in range(plan[c][0], plan[c][1] + 1):
+                if k not in frames:
+                    frames[k] = torch.from_numpy(synth.bench_frame(W, H, k)).to(dev)
+        return num_frames, plan, mine, frames
+
+    def run_video(video, record):
+        num_frames, plan, mine, frames = video
+        frames_out = 0
+        for c in mine:
+            first, last = plan[c]
+            eng = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=local_rank),
+                                        has_flow=True)
+            if c > 0:
+                virt, cons, scal = transport.recv((c - 1) % world, c,
+                                                  [((H, W), torch.int32), ((H, W), torch.int32),
+                                                   ((4,), torch.int64)])
+                eng.import_halo(virt, cons, scal.cpu().numpy())
+            for k in range(first, last + 1):
+                n = eng.process_frame(frames[k], flow if k > 0 else None, flush=(k == num_frames - 1))
+                if n and record:
+                    frames_out += n
+                    t = eng.last_timings()
+                    acc["wave_ms"] += t.wave_kernel_ms
+                    acc["wave_launches"] += t.wave_kernel_launches
+                    acc["wave_edges"] += t.wave_kernel_edges
+                    acc["filter_ms"] += t.filter_kernel_ms
+                    acc["filter_launches"] += t.filter_kernel_launches
+                    acc["merge_ms"] += t.merge_ms
+                    acc["pre_ms"] += t.preprocess_ms
+                    acc["edges_ms"] += t.edges_ms
+                    acc["readout_ms"] += t.readout_ms
+                    acc["host_ms"] += t.host_post_ms
+                    acc["edges_total"] += t.edges_total
+                    acc["merges"] += t.merges
+            if c + 1 < len(plan):
+                pa, pb, scal = eng.export_halo()
+                n_el = W * H
+                ta = torch.empty((H, W), dtype=torch.int32, device=dev)
+                tb = torch.empty((H, W), dtype=torch.int32, device=dev)
+                # device-to-device copies out of the library-owned planes
+                torch.cuda.synchronize()
+                ta.copy_(_wrap_device_int32(pa, n_el, dev).view(H, W))
+                tb.copy_(_wrap_device_int32(pb, n_el, dev).view(H, W))
+                transport.send((c + 1) % world, c + 1, [ta, tb, torch.from_numpy(scal).to(dev)])
+            eng.close()
+        return frames_out
+
+    warm = load(Wm * world) if Wm > 0 else None
+    timed = load(K * world)
+    if warm is not None:
+        run_video(warm, False)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    frames_out = run_video(timed, True)
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
