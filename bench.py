@@ -150,6 +150,10 @@ def main():
                 n = stream.process_frame(frames[k], flow if k > 0 else None)
                 pos[si] = k + 1
                 if n:
+                    # the consumer side of the boundary: every SegmentationDesc is fetched
+                    # (serialized message copied out) inside the timed region
+                    fetched = sum(len(stream.result_bytes(i)) for i in range(n))
+                    assert fetched > 0
                     done += 1
                     if record:
                         outs[si] += n

@@ -2,6 +2,9 @@
 // segmentation/dense_segmentation.cpp:50-432 and segmentation/segmentation.cpp:392-773.
 #include "stream.h"
 
+#include <atomic>
+#include <thread>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -308,19 +311,45 @@ void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
   const int chunk_size = last_output_frame - curr_chunk_start_ + 1;
   overlap_segmentations_.clear();
   const int hierarchy_frame_idx = num_output_frames_;
-  for (int frame_idx = curr_chunk_start_; frame_idx <= max_result_frame; ++frame_idx) {
-    std::unique_ptr<SegDesc> desc(new SegDesc());
-    Retrieve(frame_idx, frame_idx == curr_chunk_start_, desc.get());
-    desc->chunk_size = chunk_size;
-    desc->overlap_start = chunk_size;
-    desc->hierarchy_frame_idx = hierarchy_frame_idx;
+  // Per-frame results (RetrieveSegmentation3D, segmentation.cpp:458-535) and their serialized
+  // form -- what the C ABI hands out -- are built here, inside the chunk boundary, one frame per
+  // host thread (the frames only read the region table).
+  const int num_result_frames = max_result_frame - curr_chunk_start_ + 1;
+  std::vector<std::unique_ptr<SegDesc>> descs((size_t)num_result_frames);
+  std::vector<std::string> wires((size_t)num_result_frames);
+  {
+    std::atomic<int> next(0);
+    auto work = [&]() {
+      for (int i = next.fetch_add(1); i < num_result_frames; i = next.fetch_add(1)) {
+        const int frame_idx = curr_chunk_start_ + i;
+        std::unique_ptr<SegDesc> desc(new SegDesc());
+        Retrieve(frame_idx, frame_idx == curr_chunk_start_, desc.get());
+        desc->chunk_size = chunk_size;
+        desc->overlap_start = chunk_size;
+        desc->hierarchy_frame_idx = hierarchy_frame_idx;
+        if (frame_idx <= last_output_frame) wires[(size_t)i] = EncodeSegDesc(*desc);
+        descs[(size_t)i] = std::move(desc);
+      }
+    };
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int num_threads = std::max(1, std::min({num_result_frames, hw > 0 ? hw : 1, 8}));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < num_threads; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
+  }
+  for (int i = 0; i < num_result_frames; ++i) {
+    const int frame_idx = curr_chunk_start_ + i;
+    std::unique_ptr<SegDesc>& desc = descs[(size_t)i];
     if (frame_idx < last_output_frame) {
       results_.push_back(std::move(desc));
+      encoded_.push_back(std::move(wires[(size_t)i]));
       ++num_output_frames_;
       continue;
     }
     if (frame_idx == last_output_frame) {
       results_.push_back(std::unique_ptr<SegDesc>(new SegDesc(*desc)));
+      encoded_.push_back(std::move(wires[(size_t)i]));
       ++num_output_frames_;
     }
     overlap_segmentations_.push_back(std::move(desc));

@@ -156,6 +156,9 @@ def run_chain_bench(args, rank, world, local_rank):
                 eng.import_halo(virt, cons, scal.cpu().numpy())
             for k in range(first, last + 1):
                 n = eng.process_frame(frames[k], flow if k > 0 else None, flush=(k == num_frames - 1))
+                if n:
+                    fetched = sum(len(eng.result_bytes(i)) for i in range(n))   # consumer side
+                    assert fetched > 0
                 if n and record:
                     frames_out += n
                     t = eng.last_timings()
