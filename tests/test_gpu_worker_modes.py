@@ -4,6 +4,8 @@ The round-based wave worker has debug switches that disabl
 one by one (VSG_WAVE_DBG bit mask), a self check that replays every committed chain with the
 generic edge code, and the edge-by-edge worker of round 1a (VSG_WAVE_V1).  Every mode must give the
 oracle's bytes.  Shapes: odd sizes, padded rows, tiny frames, random (out of range) flow."""
+import os
+
 import numpy as np
 import pytest
 
@@ -91,3 +93,16 @@ def test_invalid_arguments_are_rejected(vsg):
     with pytest.raises(VsgError):      # a stream created with flow needs a flow field from frame 1 on
         s.process_frame(synth.probe_frame(64, 48, 1), None)
     s.close()
+
+
+def test_randomised_streams_against_oracle(vsg):
+    """tools/stress_parity.py: random sizes, chunk sizes, content kinds, flows and lengths.
+    Case (11, 30) is the regression for a region that acquires a constraint and is merged away
+    within one batch of the wave worker (its own constraint field must still reach memory:
+    MergeConstrainedRegions reads it per node)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_parity as sp
+    sp.one_case(np.random.default_rng([11, 30]), 30)
+    for idx in range(40):
+        sp.one_case(np.random.default_rng([5, idx]), idx)

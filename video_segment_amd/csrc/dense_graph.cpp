@@ -333,7 +333,9 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   LaunchKeepVirtualBucket(list_desc_dev_.get(), L, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
   const double t_buckets = NowMs();
+  if (getenv("VSG_DEBUG_HASH")) DebugHash("after buckets");
   if (force_constraints && has_constraints_) MergeConstrainedHostAssisted();
+  if (getenv("VSG_DEBUG_HASH")) DebugHash("after constrained merge");
   const double t_mc = NowMs();
   if (getenv("VSG_DEBUG_STATS")) {
     std::fprintf(stderr, "[vsg] segment: buckets %.1f ms, merge-constrained %.1f ms\n",
@@ -388,6 +390,47 @@ struct SimRegion {
   bool dirty;
 };
 }  // namespace
+
+// Debug aid (VSG_DEBUG_HASH): FNV hashes of the partition (labels renumbered by first occurrence),
+// of the representative identities and of the representatives' states, to compare two runs.
+void DenseGraphHip::DebugHash(const char* where) {
+  const size_t N = wh_ * (size_t)num_frames_;
+  std::vector<int32_t> parent(N), cons(N);
+  std::vector<float4> ds(N);
+  std::vector<uint8_t> flags(N);
+  D2H(parent.data(), parent_.get(), N, stream_);
+  D2H(cons.data(), cons_.get(), N, stream_);
+  D2H(ds.data(), desc_sz_.get(), N, stream_);
+  D2H(flags.data(), flags_.get(), N, stream_);
+  VSG_HIP(hipStreamSynchronize(stream_));
+  auto fnv = [](uint64_t h, const void* p, size_t n) {
+    const uint8_t* b = static_cast<const uint8_t*>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+  };
+  std::vector<int32_t> root(N), canon(N, -1);
+  uint64_t h_part = 1469598103934665603ull, h_root = h_part, h_state = h_part, h_cons = h_part;
+  int next = 0, nroots = 0;
+  for (size_t i = 0; i < N; ++i) {
+    int r = (int)i;
+    while (parent[(size_t)r] != r) r = parent[(size_t)r];
+    root[i] = r;
+    if (canon[(size_t)r] < 0) canon[(size_t)r] = next++;
+    const int32_t c = canon[(size_t)r];
+    h_part = fnv(h_part, &c, 4);
+    h_root = fnv(h_root, &r, 4);
+  }
+  for (size_t i = 0; i < N; ++i) {
+    if (parent[i] != (int)i) continue;
+    ++nroots;
+    h_state = fnv(h_state, &ds[i], 16);
+    h_state = fnv(h_state, &flags[i], 1);
+    h_cons = fnv(h_cons, &cons[i], 4);
+  }
+  std::fprintf(stderr, "[vsg] hash %s: roots %d partition %016llx root-ids %016llx states %016llx cons %016llx\n",
+               where, nroots, (unsigned long long)h_part, (unsigned long long)h_root,
+               (unsigned long long)h_state, (unsigned long long)h_cons);
+}
 
 void DenseGraphHip::MergeConstrainedHostAssisted() {
   const int N = (int)(wh_ * (size_t)num_frames_);

@@ -74,6 +74,7 @@ class DenseGraphHip {
   };
 
   void EnsureScratch(size_t n_edges_max);
+  void DebugHash(const char* where);
   void SortList(ListBuf& lb, int n);
   void MergeConstrainedHostAssisted();
   NodeArrays nodes() {

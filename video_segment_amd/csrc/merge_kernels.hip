@@ -899,6 +899,18 @@ __device__ __forceinline__ void WaveSync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
+// Commit of a merge inside the wave worker: `ls` (loser slot) is linked to `ws` (winner slot).
+// A region that stops being a representative keeps its own constraint field in the reference
+// (MergeRegions only updates the survivor), and MergeConstrainedRegions later reads that field of
+// every *node* -- so a constraint the loser acquired or lost earlier in this batch (its table
+// entry is dirty and will never be written back) has to reach memory now.
+__device__ __forceinline__ void CommitLoser(WaveTable& t, const NodeArrays& nodes, int ls, int ws) {
+  t.link[ls] = ws;
+  const int lid = t.key[ls];
+  nodes.parent[lid] = t.key[ws];
+  if (t.flags[ls] & kTabDirty) nodes.cons[lid] = t.cons[ls];
+}
+
 template <bool kDbg>
 __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ num_segs,
                                                     const int32_t* __restrict__ seg_off,
@@ -988,7 +1000,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
         for (int k = 0; k < kFill; ++k) {
           // Path compression of the start node only (it is not a root, so the consumer never
           // writes it); an optimistic stage must stay undoable and does not compress.
-          if (!optimistic) {
+          if (!optimistic && !(kDbg && (dbg_flags & 1024))) {
             if (vd[k] && ca[k] != xa[k]) nodes.parent[xa[k]] = ca[k];
             if (vd[k] && cb[k] != xb[k]) nodes.parent[xb[k]] = cb[k];
           }
@@ -1303,7 +1315,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           // not finalized, unmarked) that pass the regular test.  Same arithmetic as
           // DecideEdge / MergeStates for this case.
           if (s1.cons < 0 && s2.cons < 0 && (s1.flags | s2.flags) == 0 &&
-              SquaredDistance(s1, s2) <= T.pass_s) {
+              SquaredDistance(s1, s2) <= T.pass_s && !(kDbg && (dbg_flags & 256))) {
             const bool first = s1.sz > s2.sz;   // ties keep region 2
             const int ws = first ? sa : sb, ls = first ? sb : sa;
             RState m, o;
@@ -1325,8 +1337,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
             m.cons = max(s1.cons, s2.cons);
             m.flags = 0;
             TabStore(tab, ws, m, kTabDirty);
-            tab.link[ls] = ws;
-            nodes.parent[tab.key[ls]] = tab.key[ws];
+            CommitLoser(tab, nodes, ls, ws);
             ++n_regular;
             pending = false;
             n_win = false;
@@ -1352,12 +1363,10 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
             if (!SameState(o2, s2)) TabStore(tab, sb, s2, kTabDirty);
           } else if (out == kOutMerge1) {
             TabStore(tab, sa, s1, kTabDirty);
-            tab.link[sb] = sa;
-            nodes.parent[tab.key[sb]] = tab.key[sa];
+            CommitLoser(tab, nodes, sb, sa);
           } else {
             TabStore(tab, sb, s2, kTabDirty);
-            tab.link[sa] = sb;
-            nodes.parent[tab.key[sa]] = tab.key[sb];
+            CommitLoser(tab, nodes, sa, sb);
           }
           pending = false;
         }
@@ -1446,8 +1455,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           }
           if (do_commit) {
             if (merging) {
-              tab.link[ps] = hot;
-              nodes.parent[tab.key[ps]] = tab.key[hot];
+              CommitLoser(tab, nodes, ps, hot);
               if (case_s) ++n_forced; else if (fin) ++n_small; else ++n_regular;
             } else {
               my_kept = true;   // both regions large, the hot one finalized: nothing changes
