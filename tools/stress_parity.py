@@ -44,8 +44,9 @@ def make_frame(rng, W, H, kind, k):
 
 
 def one_case(rng, idx):
-    W = int(rng.integers(24, 200))
-    H = int(rng.integers(16, 130))
+    scale = float(os.environ.get("STRESS_SCALE", "1"))
+    W = int(rng.integers(24, int(200 * scale)))
+    H = int(rng.integers(16, int(130 * scale)))
     chunk = int(rng.choice([8, 9, 10, 13, 20]))
     N = int(rng.integers(1, 3 * chunk + 3))
     kind = str(rng.choice(["noise", "smooth", "blocks", "twotone", "bench"]))
