@@ -401,7 +401,9 @@ __global__ __launch_bounds__(256) void k_first_of_label(const int32_t* __restric
   const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (pix >= n) return;
   const int l = labels[pix];
-  // most pixels of a region lose against an earlier pixel: test before issuing the atomic
+  // The first pixel of a label in scan order starts a run of that label, so only run starts
+  // compete (a few thousand atomics instead of one per pixel on a few hundred addresses).
+  if (pix > 0 && labels[pix - 1] == l) return;
   if (l >= 0 && l < num_labels && first[l] > (int)pix) atomicMin(&first[l], (int)pix);
 }
 

@@ -165,7 +165,7 @@ int DenseSegmentationHip::ProcessFrame(bool flush, const uint8_t* bgr, size_t st
       } else {
         VSG_REQUIRE(flow != nullptr, -1, "Flow always has to be passed or be absent.");
         DevPlane fd(new DevBuf<float>(2 * wh_));
-        HostFlow fh(new std::vector<float>(2 * wh_));
+        HostFlow fh = AcquireHostFlow();
         if (mem == VSG_MEM_HOST) {
           std::memcpy(fh->data(), flow, 2 * wh_ * sizeof(float));
           VSG_HIP(hipMemcpyAsync(fd->get(), flow, 2 * wh_ * sizeof(float), hipMemcpyHostToDevice,
@@ -254,6 +254,18 @@ void DenseSegmentationHip::ChunkBoundaryOutput(bool flush) {
   halo_valid_ = true;
   StartConstrainedGraph(halo_ids_dev_[0].get(), halo_ids_dev_[1].get(), max_region_id_);
   overlap_segmentations_.clear();
+}
+
+DenseSegmentationHip::HostFlow DenseSegmentationHip::AcquireHostFlow() {
+  std::unique_ptr<HostFlowBuf> b;
+  if (!flow_pool_.empty()) {
+    b = std::move(flow_pool_.back());
+    flow_pool_.pop_back();
+  } else {
+    b.reset(new HostFlowBuf());
+    b->buf.ensure(2 * wh_);
+  }
+  return HostFlow(b.release(), [this](HostFlowBuf* p) { flow_pool_.emplace_back(p); });
 }
 
 void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {

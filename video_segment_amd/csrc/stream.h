@@ -62,7 +62,15 @@ class DenseSegmentationHip {
 
  private:
   typedef std::shared_ptr<DevBuf<float>> DevPlane;
-  typedef std::shared_ptr<std::vector<float>> HostFlow;
+  // Host copy of a flow field (the tube analysis samples it at component centres).  Pinned so that
+  // the device->host copy of device-resident flow runs at full PCIe rate and asynchronously;
+  // recycled through flow_pool_.
+  struct HostFlowBuf {
+    PinnedBuf<float> buf;
+    float* data() const { return buf.get(); }
+  };
+  typedef std::shared_ptr<HostFlowBuf> HostFlow;
+  HostFlow AcquireHostFlow();
 
   int MinRegionSize() const;
   void ChunkBoundaryOutput(bool flush);
@@ -89,6 +97,7 @@ class DenseSegmentationHip {
   int curr_chunk_start_ = 0;
   bool assigned_constrained_ids_ = false;
 
+  std::vector<std::unique_ptr<HostFlowBuf>> flow_pool_;   // declared before its users
   std::vector<DevPlane> feature_buffer_;
   std::vector<DevPlane> flow_dev_buffer_;     // W*H*2 f32, null = empty flow
   std::vector<HostFlow> flow_host_buffer_;
