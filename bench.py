@@ -211,7 +211,7 @@ def main():
         # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes cannot run inside the
         # timed process, so the committed summary of the same workload is quoted (null if absent).
         traffic, traffic_note = None, "no PMC summary under profiles/"
-        pmc_path = os.path.join(ROOT, "profiles", "r1_d_pmc_wave.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r1_e_pmc_wave.json")
         if os.path.exists(pmc_path) and (W, H, chunk) == (1920, 1080, 20):
             pmc = json.load(open(pmc_path))
             traffic = pmc["fetch_bytes_per_launch_raw"] + pmc["write_bytes_per_launch_raw"]
