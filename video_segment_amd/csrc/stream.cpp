@@ -113,6 +113,8 @@ DenseSegmentationHip::DenseSegmentationHip(const vsg_options& o, int W, int H)
   constraint_frames_ = std::min(options_.num_constraint_frames, overlap_frames_ - 1);
   if (options_.device >= 0) VSG_HIP(hipSetDevice(options_.device));
   VSG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  VSG_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+  VSG_HIP(hipEventCreateWithFlags(&flow_ready_, hipEventDisableTiming));
   graph_.reset(new DenseGraphHip(W, H, options_.chunk_size + 1, options_.color_distance == 0, stream_));
   pre_.reset(new Preprocessor(W, H, stream_));
   std::memset(&last_timings_, 0, sizeof(last_timings_));
@@ -122,8 +124,11 @@ DenseSegmentationHip::DenseSegmentationHip(const vsg_options& o, int W, int H)
 DenseSegmentationHip::~DenseSegmentationHip() {
   if (stream_) {
     (void)hipStreamSynchronize(stream_);
+    if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
     graph_.reset();
     pre_.reset();
+    if (flow_ready_) (void)hipEventDestroy(flow_ready_);
+    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     (void)hipStreamDestroy(stream_);
   }
 }
@@ -173,8 +178,11 @@ int DenseSegmentationHip::ProcessFrame(bool flush, const uint8_t* bgr, size_t st
         } else {
           VSG_HIP(hipMemcpyAsync(fd->get(), flow, 2 * wh_ * sizeof(float),
                                  hipMemcpyDeviceToDevice, stream_));
-          VSG_HIP(hipMemcpyAsync(fh->data(), flow, 2 * wh_ * sizeof(float), hipMemcpyDeviceToHost,
-                                 stream_));
+          // host copy from our own device copy (the caller's buffer is only valid during the call)
+          VSG_HIP(hipEventRecord(flow_ready_, stream_));
+          VSG_HIP(hipStreamWaitEvent(copy_stream_, flow_ready_, 0));
+          VSG_HIP(hipMemcpyAsync(fh->data(), fd->get(), 2 * wh_ * sizeof(float),
+                                 hipMemcpyDeviceToHost, copy_stream_));
         }
         flow_dev_buffer_.push_back(fd);
         flow_host_buffer_.push_back(fh);
@@ -269,6 +277,7 @@ DenseSegmentationHip::HostFlow DenseSegmentationHip::AcquireHostFlow() {
 }
 
 void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
+  VSG_HIP(hipStreamSynchronize(copy_stream_));   // host copies of the flow fields
   std::vector<const float*> flows;
   const bool have_flows = !flow_host_buffer_.empty();
   if (have_flows) {

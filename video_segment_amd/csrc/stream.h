@@ -83,6 +83,10 @@ class DenseSegmentationHip {
   int W_, H_;
   size_t wh_;
   hipStream_t stream_ = nullptr;
+  // Device-resident flow is copied to the host (tube analysis) on its own stream, behind an event
+  // of the main stream; it is only waited for at the chunk boundary.
+  hipStream_t copy_stream_ = nullptr;
+  hipEvent_t flow_ready_ = nullptr;
   std::unique_ptr<DenseGraphHip> graph_;
   std::unique_ptr<Preprocessor> pre_;
   bool graph_open_ = false;
