@@ -353,7 +353,7 @@ void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
       }
     };
     const int hw = (int)std::thread::hardware_concurrency();
-    const int num_threads = std::max(1, std::min({num_result_frames, hw > 0 ? hw : 1, 8}));
+    const int num_threads = std::max(1, std::min({num_result_frames, hw > 0 ? hw : 1, 32}));
     std::vector<std::thread> pool;
     for (int t = 1; t < num_threads; ++t) pool.emplace_back(work);
     work();
