@@ -240,6 +240,7 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   S.bk_flags = bk_flags_.get();
   S.force_rollback = getenv("VSG_FORCE_ROLLBACK") ? 1 : 0;
   S.wave_v1 = getenv("VSG_WAVE_V1") ? 1 : 0;
+  S.block_worker = getenv("VSG_BLOCK_WORKER") ? atoi(getenv("VSG_BLOCK_WORKER")) : 0;
   S.wave_dbg = getenv("VSG_WAVE_DBG") ? atoi(getenv("VSG_WAVE_DBG")) : 0;
   S.wave_debug = (S.wave_dbg != 0 || getenv("VSG_DEBUG_STAGES") || getenv("VSG_DEBUG_STATS")) ? 1 : 0;
   optimistic_stages_ = 0;
