@@ -1574,7 +1574,9 @@ struct BlockShared {
   int32_t st_rb[kBStage];
   uint32_t st_gpos[kBStage];
   unsigned long long bm[4][4];   // ballot exchange (rotating slots)
-  float c_cb[kBlk], c_t0[kBlk], c_t1[kBlk], c_t2[kBlk];   // chain inputs by lane
+  unsigned long long bmn[2][4][4];   // multi-predicate exchange (two alternating slots)
+  float c_p0[kBlk], c_p1[kBlk], c_p2[kBlk];   // partner means by lane
+  int32_t c_v[kBlk], c_incl[kBlk];            // partner size of merging lanes, wave-local prefix
   float c_r0[kBlk], c_r1[kBlk], c_r2[kBlk];               // hot mean before the lane's merge
   int32_t c_S[kBlk];                                      // hot size before the lane's merge
   float h_fin[4];
@@ -1662,6 +1664,25 @@ __device__ __forceinline__ void BCommitLoser(BlockShared& t, const NodeArrays& n
   if (t.flags[ls] & kTabDirty) nodes.cons[lid] = t.cons[ls];   // see CommitLoser
 }
 
+// Workgroup ballot of up to four predicates with ONE barrier.
+template <int N>
+__device__ __forceinline__ void BlockBallotN(BlockShared& sh, int& slot, const bool (&pred)[N],
+                                             Mask256 (&out)[N]) {
+  const int s = slot & 1;
+  ++slot;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const unsigned long long m = __ballot(pred[i]);
+    if ((threadIdx.x & 63) == 0) sh.bmn[s][i][threadIdx.x >> 6] = m;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[i].w[k] = sh.bmn[s][i][k];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__ num_segs,
                                                       const int32_t* __restrict__ seg_off,
                                                       const int32_t* __restrict__ seg_cnt,
@@ -1744,8 +1765,13 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
         next += t_new;
         const bool live0 = cand[0] && ca[0] != cb[0];
         const bool live1 = cand[1] && ca[1] != cb[1];
-        const Mask256 m0 = BlockBallot(sh, slot, live0);   // barrier: every candidate is in registers
-        const Mask256 m1 = BlockBallot(sh, slot, live1);
+        Mask256 lm[2];
+        {
+          const bool pr[2] = {live0, live1};
+          BlockBallotN<2>(sh, slot, pr, lm);   // barrier: every candidate is in registers
+        }
+        const Mask256& m0 = lm[0];
+        const Mask256& m1 = lm[1];
         const int c0 = MaskCount(m0);
         if (live0) {
           const int pos = n_valid + MaskRank(m0, g);
@@ -1880,8 +1906,13 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
         int ps = 0;
         bool hot_lane = pending && (a_hot || b_hot);
         bool elig = false, both = false, merging = false, case_s = false, fin = false;
-        const Mask256 lit = BlockBallot(sh, slot, hot_lane);
-        const Mask256 lit_own = BlockBallot(sh, slot, hot_lane && (own_a || own_b));
+        Mask256 la[2];
+        {
+          const bool pr[2] = {hot_lane, hot_lane && (own_a || own_b)};
+          BlockBallotN<2>(sh, slot, pr, la);
+        }
+        const Mask256& lit = la[0];
+        const Mask256& lit_own = la[1];
         const int first_lit = MaskFirst(lit);
         const bool chain_possible = first_lit < 256 && MaskBit(lit_own, first_lit) && !(dbg_flags & 1);
         if (chain_possible) {
@@ -1920,11 +1951,20 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
           merging = hot_lane && !both && (pb_side ? merge_b : merge_a);
           case_s = P.cons >= 0;
         }
-        const Mask256 hot_mask = BlockBallot(sh, slot, hot_lane);
-        const Mask256 ok_mask = BlockBallot(sh, slot, elig || both);
-        Mask256 blocked;
-        for (int k = 0; k < 4; ++k) blocked.w[k] = hot_mask.w[k] & ~ok_mask.w[k];
-        const int cut = MaskFirst(blocked);              // first hot lane that ends the chain
+        // Without a chain the hot lanes are the literal ones and all of them wait.
+        Mask256 hot_mask = lit, elig_mask = {{0, 0, 0, 0}}, mm_all = {{0, 0, 0, 0}};
+        int cut = first_lit;   // first hot lane that ends the chain
+        if (chain_possible) {
+          Mask256 lb[4];
+          const bool pr[4] = {hot_lane, elig, both, merging};
+          BlockBallotN<4>(sh, slot, pr, lb);
+          hot_mask = lb[0];
+          elig_mask = lb[1];
+          mm_all = lb[3];
+          Mask256 blocked;
+          for (int k = 0; k < 4; ++k) blocked.w[k] = lb[0].w[k] & ~(lb[1].w[k] | lb[2].w[k]);
+          cut = MaskFirst(blocked);
+        }
         const bool in_chain = elig && g < cut;
         const int first_hot = MaskFirst(hot_mask);
         const bool own = pending && (a_hot || own_a) && (b_hot || own_b);
@@ -1998,42 +2038,46 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
         }
 
         // ---- the chain on the hot region -----------------------------------------------------
-        const Mask256 chain_mask = BlockBallot(sh, slot, in_chain);
+        // chain lanes = candidates below the cut (no exchange needed: both masks are known)
+        Mask256 chain_mask, mm;
+        for (int k = 0; k < 4; ++k) {
+          const int lo = k * 64;
+          const unsigned long long below_cut =
+              cut >= lo + 64 ? ~0ull : (cut <= lo ? 0ull : ((1ull << (cut - lo)) - 1ull));
+          chain_mask.w[k] = elig_mask.w[k] & below_cut;
+          mm.w[k] = mm_all.w[k] & chain_mask.w[k];
+        }
         if (MaskAny(chain_mask)) {
           merging = in_chain && merging;
           case_s = in_chain && case_s;
           const bool tested = case_s || (in_chain && !fin);
-          // sizes: inclusive prefix sum over the 256 lanes
+          // hand the per-lane inputs to wavefront 0: partner size and mean, wave-local size prefix
           const int v = merging ? P.sz : 0;
-          int incl = WaveInclusiveSum(v);
+          const int incl = WaveInclusiveSum(v);
+          sh.c_v[g] = v;
+          sh.c_incl[g] = incl;
+          sh.c_p0[g] = P.d0;
+          sh.c_p1[g] = P.d1;
+          sh.c_p2[g] = P.d2;
           if (lane == 63) sh.wsum[wave] = incl;
           __syncthreads();
-          int woff = 0, wtot = 0;
-          for (int k = 0; k < 4; ++k) {
-            const int x = sh.wsum[k];
-            if (k < wave) woff += x;
-            wtot += x;
-          }
-          incl += woff;
-          const int S = Hs.sz + incl - v;     // size of the hot region before this lane's merge
-          const float denom = 1.0f / (float)(P.sz + S);   // MergeStates: o = partner, m = hot region
-          const float ca = (float)P.sz * denom;
-          const float cb = (float)S * denom;
-          sh.c_cb[g] = cb;
-          sh.c_t0[g] = ca * P.d0;
-          sh.c_t1[g] = ca * P.d1;
-          sh.c_t2[g] = ca * P.d2;
-          sh.c_S[g] = S;
-          const Mask256 mm = BlockBallot(sh, slot, merging);   // barrier: the inputs are in LDS
+          const int wtot = sh.wsum[0] + sh.wsum[1] + sh.wsum[2] + sh.wsum[3];
           if (wave == 0) {
-            // the serial part: h = ca*p + cb*h in lane order, recording the mean before each merge
+            // MergeStates with o = partner, m = hot region: sizes are a prefix sum, the weights and
+            // ca*p are lane-parallel, only h = ca*p + cb*h is replayed in lane order; the mean and
+            // the size of the hot region before each merge are recorded for the verification.
             float h0 = Hs.d0, h1 = Hs.d1, h2 = Hs.d2;
+            int woff = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const float x_cb = sh.c_cb[k * 64 + lane];
-              const float x_t0 = sh.c_t0[k * 64 + lane];
-              const float x_t1 = sh.c_t1[k * 64 + lane];
-              const float x_t2 = sh.c_t2[k * 64 + lane];
+              const int e = k * 64 + lane;
+              const int ev = sh.c_v[e];
+              const int S = Hs.sz + woff + sh.c_incl[e] - ev;   // hot size before this lane's merge
+              const float denom = 1.0f / (float)(ev + S);
+              const float ca = (float)ev * denom;
+              const float x_cb = (float)S * denom;
+              const float x_t0 = ca * sh.c_p0[e], x_t1 = ca * sh.c_p1[e], x_t2 = ca * sh.c_p2[e];
+              sh.c_S[e] = S;
               float r0 = 0.f, r1 = 0.f, r2 = 0.f;
               for (unsigned long long w = mm.w[k]; w; w &= w - 1) {
                 const int j = (int)__builtin_ctzll(w);
@@ -2047,9 +2091,10 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
                 h1 = ReadLaneF(x_t1, j) + cbj * h1;
                 h2 = ReadLaneF(x_t2, j) + cbj * h2;
               }
-              sh.c_r0[k * 64 + lane] = r0;
-              sh.c_r1[k * 64 + lane] = r1;
-              sh.c_r2[k * 64 + lane] = r2;
+              sh.c_r0[e] = r0;
+              sh.c_r1[e] = r1;
+              sh.c_r2[e] = r2;
+              woff += sh.wsum[k];
             }
             if (lane == 0) {
               sh.h_fin[0] = h0;
@@ -2092,8 +2137,13 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
           }
           // both ends (by then) inside the hot region: internal once the chain below it is committed
           if (both && g < fcut && g < cut) pending = false;
-          // did any merge commit?  (lanes below fcut that merge)
-          const bool any_merge = __syncthreads_or((do_commit && merging) ? 1 : 0) != 0;
+          bool any_merge = false;   // a merging lane below the failed test, if any
+          for (int k = 0; k < 4; ++k) {
+            const int lo = k * 64;
+            const unsigned long long below_f =
+                fcut >= lo + 64 ? ~0ull : (fcut <= lo ? 0ull : ((1ull << (fcut - lo)) - 1ull));
+            any_merge = any_merge || (mm.w[k] & below_f) != 0;
+          }
           if (g == 0 && any_merge) BTabStore(sh, hot, Hn, kTabDirty);
         }
         __syncthreads();
