@@ -35,6 +35,20 @@ def test_chain_self_check_is_silent(vsg, monkeypatch, capfd):
     assert "self check" not in err, err
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_four_wavefront_worker(vsg, monkeypatch, mode):
+    """k_merge_block (256-edge batches on four wavefronts; opt-in): always, and
+    chosen per bucket by the average component size."""
+    monkeypatch.setenv("VSG_BLOCK_WORKER", mode)
+    for (W, H, N, kind, chunk) in CASES + [(256, 144, 44, "bench", 20)]:
+        run_streams(vsg, W, H, N, kind, True, chunk)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_parity as sp
+    for idx in range(12):
+        sp.one_case(np.random.default_rng([77, idx]), idx)
+
+
 def test_edge_by_edge_worker(vsg, monkeypatch):
     monkeypatch.setenv("VSG_WAVE_V1", "1")
     for (W, H, N, kind, chunk) in CASES:

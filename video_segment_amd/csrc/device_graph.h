@@ -122,7 +122,7 @@ struct MergeScratch {
   int32_t* bk_cons;
   uint8_t* bk_flags;
   int force_rollback;    // test hook: treat every optimistic stage as violated
-  int block_worker;      // use the four-wavefront worker (k_merge_block)
+  int block_worker;      // four-wavefront worker (k_merge_block): 0 never (default), 1 always, 2 per bucket by average component size
   int wave_v1;           // debug hook: use the sequential wave worker (k_merge_wave_v1)
   int wave_debug;        // use the instrumented build of the wave worker (counters, self checks)
   int wave_dbg;          // debug hook (bit mask): 1 no chain, 4 no hot region, 8 one generic lane per round,

@@ -1581,6 +1581,7 @@ struct BlockShared {
   int32_t c_S[kBlk];                                      // hot size before the lane's merge
   float h_fin[4];
   int32_t wsum[4];
+  int32_t rewind;
 };
 
 struct Mask256 {
@@ -1683,6 +1684,101 @@ __device__ __forceinline__ void BlockBallotN(BlockShared& sh, int& slot, const b
   }
 }
 
+// One staging pass of the block worker: R candidates per thread (the left-overs of the previous
+// batch first, then edges read from the component's list), all root searches in flight together;
+// the live candidates are packed in order behind the n_valid edges already staged.  When the stage
+// is full the pass is cut there and `next` is rewound to the first edge that did not fit.
+// Returns the fraction of live candidates in 1/256 units (the caller picks R for the next pass).
+template <int R>
+__device__ __forceinline__ int StagePass(BlockShared& sh, int& slot, const NodeArrays& nodes,
+                                         const int32_t* __restrict__ s_ra,
+                                         const int32_t* __restrict__ s_rb,
+                                         const uint32_t* __restrict__ s_gpos, int end, int optimistic,
+                                         int& next, int& n_raw, int& n_valid) {
+  const int g = threadIdx.x;
+  const int t_new = min(R * kBlk - n_raw, end - next);
+  const int total = n_raw + t_new;
+  const int next_base = next;
+  int ca[R], cb[R], xa[R], xb[R];
+  uint32_t cg[R];
+  bool cand[R], fresh[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int i = g + k * kBlk;
+    cand[k] = i < total;
+    fresh[k] = cand[k] && i >= n_raw;
+    ca[k] = cb[k] = 0;
+    cg[k] = 0;
+    if (cand[k] && !fresh[k]) {
+      ca[k] = sh.st_ra[i];
+      cb[k] = sh.st_rb[i];
+      cg[k] = sh.st_gpos[i];
+    } else if (fresh[k]) {
+      const int p = next_base + (i - n_raw);
+      ca[k] = s_ra[p];
+      cb[k] = s_rb[p];
+      cg[k] = s_gpos[p];
+    }
+    xa[k] = ca[k];
+    xb[k] = cb[k];
+  }
+  for (bool more = true; more;) {   // the 2 R root searches of a thread advance together
+    int pa[R], pb[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      pa[k] = nodes.parent[ca[k]];
+      pb[k] = nodes.parent[cb[k]];
+    }
+    more = false;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      more = more || (pa[k] != ca[k]) || (pb[k] != cb[k]);
+      ca[k] = pa[k];
+      cb[k] = pb[k];
+    }
+  }
+  if (!optimistic) {   // path compression of the start nodes (never representatives)
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (fresh[k] && ca[k] != xa[k]) nodes.parent[xa[k]] = ca[k];
+      if (fresh[k] && cb[k] != xb[k]) nodes.parent[xb[k]] = cb[k];
+    }
+  }
+  if (g == 0) sh.rewind = -1;
+  int base = n_valid, live_total = 0;
+#pragma unroll
+  for (int k0 = 0; k0 < R; k0 += 2) {
+    Mask256 lm[2];
+    const bool pr[2] = {cand[k0] && ca[k0] != cb[k0], cand[k0 + 1] && ca[k0 + 1] != cb[k0 + 1]};
+    BlockBallotN<2>(sh, slot, pr, lm);   // first barrier: every candidate is in registers
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + j;
+      if (pr[j]) {
+        const int pos = base + MaskRank(lm[j], g);
+        if (pos < kBStage) {
+          sh.st_ra[pos] = ca[k];
+          sh.st_rb[pos] = cb[k];
+          sh.st_gpos[pos] = cg[k];
+        } else if (pos == kBStage) {
+          // the first edge that does not fit (a fresh one: the left-overs always fit)
+          sh.rewind = next_base + (g + k * kBlk - n_raw);
+        }
+      }
+      const int c = MaskCount(lm[j]);
+      base += c;
+      live_total += c;
+    }
+  }
+  __syncthreads();
+  const int rw = sh.rewind;
+  next = rw >= 0 ? rw : next_base + t_new;
+  n_valid = base < kBStage ? base : kBStage;
+  n_raw = 0;
+  __syncthreads();   // sh.rewind is rewritten by the next pass
+  return total > 0 ? (live_total * 256) / total : 256;
+}
+
 __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__ num_segs,
                                                       const int32_t* __restrict__ seg_off,
                                                       const int32_t* __restrict__ seg_cnt,
@@ -1707,6 +1803,7 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
   const int nseg = *num_segs;
   unsigned n_forced = 0, n_regular = 0, n_small = 0;
   unsigned long long dbg_rounds = 0, dbg_batches = 0, dbg_generic = 0, dbg_chain = 0;
+  unsigned long long cyc[6] = {0, 0, 0, 0, 0, 0};   // staging, table, round head, generic, chain, write-back
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int cnt = seg_cnt[seg];
     if (cnt <= kSmallSegment) continue;
@@ -1714,82 +1811,22 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
     const int end = beg + cnt;
     if (g == 0) atomicAdd(&stats[3], (unsigned long long)cnt);
     int next = beg;     // next edge of the component to be read (uniform)
+    int live_frac = 256;   // live candidates of the last staging pass, in 1/256
     int n_raw = 0;      // staged edges left over from the previous batch (roots to be re-validated)
     for (;;) {
       // ---- stage up to 256 live edges ---------------------------------------------------------------
-      // A pass re-validates 512 candidates, two per thread: the left-overs first, then edges read
-      // from the component's list; the live ones are packed in order.
+      const unsigned long long c0 = __builtin_readcyclecounter();
       int n_valid = 0;
       while (n_valid < kBlk && (n_raw > 0 || next < end)) {
-        const int t_new = min(2 * kBlk - n_raw, end - next);
-        const int total = n_raw + t_new;
-        int ca[2], cb[2], xa[2], xb[2];
-        uint32_t cg[2];
-        bool cand[2], fresh[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int i = g + k * kBlk;
-          cand[k] = i < total;
-          fresh[k] = cand[k] && i >= n_raw;
-          ca[k] = cb[k] = 0;
-          cg[k] = 0;
-          if (cand[k] && !fresh[k]) {
-            ca[k] = sh.st_ra[i];
-            cb[k] = sh.st_rb[i];
-            cg[k] = sh.st_gpos[i];
-          } else if (fresh[k]) {
-            const int p = next + (i - n_raw);
-            ca[k] = s_ra[p];
-            cb[k] = s_rb[p];
-            cg[k] = s_gpos[p];
-          }
-          xa[k] = ca[k];
-          xb[k] = cb[k];
-        }
-        for (bool more = true; more;) {   // the four root searches of a thread advance together
-          const int pa0 = nodes.parent[ca[0]], pb0 = nodes.parent[cb[0]];
-          const int pa1 = nodes.parent[ca[1]], pb1 = nodes.parent[cb[1]];
-          more = (pa0 != ca[0]) || (pb0 != cb[0]) || (pa1 != ca[1]) || (pb1 != cb[1]);
-          ca[0] = pa0;
-          cb[0] = pb0;
-          ca[1] = pa1;
-          cb[1] = pb1;
-        }
-        if (!optimistic) {   // path compression of the start nodes (never representatives)
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            if (fresh[k] && ca[k] != xa[k]) nodes.parent[xa[k]] = ca[k];
-            if (fresh[k] && cb[k] != xb[k]) nodes.parent[xb[k]] = cb[k];
-          }
-        }
-        next += t_new;
-        const bool live0 = cand[0] && ca[0] != cb[0];
-        const bool live1 = cand[1] && ca[1] != cb[1];
-        Mask256 lm[2];
-        {
-          const bool pr[2] = {live0, live1};
-          BlockBallotN<2>(sh, slot, pr, lm);   // barrier: every candidate is in registers
-        }
-        const Mask256& m0 = lm[0];
-        const Mask256& m1 = lm[1];
-        const int c0 = MaskCount(m0);
-        if (live0) {
-          const int pos = n_valid + MaskRank(m0, g);
-          sh.st_ra[pos] = ca[0];
-          sh.st_rb[pos] = cb[0];
-          sh.st_gpos[pos] = cg[0];
-        }
-        if (live1) {
-          const int pos = n_valid + c0 + MaskRank(m1, g);
-          sh.st_ra[pos] = ca[1];
-          sh.st_rb[pos] = cb[1];
-          sh.st_gpos[pos] = cg[1];
-        }
-        n_valid += c0 + MaskCount(m1);
-        n_raw = 0;
-        __syncthreads();
+        // eight candidates per thread when few of them are live (most of a grown component's
+        // edges are internal), two otherwise
+        live_frac = (live_frac < 77 && n_raw < kBlk)
+                        ? StagePass<8>(sh, slot, nodes, s_ra, s_rb, s_gpos, end, optimistic, next, n_raw, n_valid)
+                        : StagePass<2>(sh, slot, nodes, s_ra, s_rb, s_gpos, end, optimistic, next, n_raw, n_valid);
       }
       if (n_valid == 0) break;   // the component is drained
+      const unsigned long long c1 = __builtin_readcyclecounter();
+      cyc[0] += c1 - c0;
       // ---- the batch: the first 256 staged edges (their roots are current) ------------------------
       const int take = n_valid < kBlk ? n_valid : kBlk;
       const bool valid = g < take;
@@ -1858,10 +1895,12 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
         if ((best >> 10) >= 3 && !(dbg_flags & 4)) hot = best & (kBTab - 1);
       }
       if (g == 0) ++dbg_batches;
+      cyc[1] += __builtin_readcyclecounter() - c1;
 
       bool my_kept = false;
       bool failed = false;
       for (unsigned round = 0;; ++round) {
+        const unsigned long long r0c = __builtin_readcyclecounter();
         {   // current root slots
           int h = hot;
           for (bool more = true; more;) {
@@ -1976,6 +2015,8 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
         }
         if (g == 0) ++dbg_rounds;
 
+        const unsigned long long r1c = __builtin_readcyclecounter();
+        cyc[2] += r1c - r0c;
         // ---- lanes that own both regions: generic edge ------------------------------------------
         if (n_win) {
           if (A.cons < 0 && B.cons < 0 && (A.flags | B.flags) == 0 &&
@@ -2038,6 +2079,8 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
         }
 
         // ---- the chain on the hot region -----------------------------------------------------
+        const unsigned long long r2c = __builtin_readcyclecounter();
+        cyc[3] += r2c - r1c;
         // chain lanes = candidates below the cut (no exchange needed: both masks are known)
         Mask256 chain_mask, mm;
         for (int k = 0; k < 4; ++k) {
@@ -2147,7 +2190,9 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
           if (g == 0 && any_merge) BTabStore(sh, hot, Hn, kTabDirty);
         }
         __syncthreads();
+        cyc[4] += __builtin_readcyclecounter() - r2c;
       }
+      const unsigned long long wb0 = __builtin_readcyclecounter();
 
       if (valid && my_kept) kept_all[gpos] = 1;
       // ---- write the changed regions back, free the table slots ---------------------------------------
@@ -2164,6 +2209,7 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
       // Make this batch's stores visible to the next batch's loads (same CU: L1 is shared).
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __syncthreads();
+      cyc[5] += __builtin_readcyclecounter() - wb0;
     }
     __syncthreads();   // end of the component
   }
@@ -2184,6 +2230,9 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
   if (g == 0) {
     atomicAdd(&stats[5], dbg_rounds);
     atomicAdd(&stats[7], dbg_batches);
+    atomicAdd(&stats[18], cyc[0]);
+    atomicAdd(&stats[26], cyc[1]);
+    for (int k = 0; k < 4; ++k) atomicAdd(&stats[32 + k], cyc[2 + k]);
   }
 }
 
@@ -2278,7 +2327,19 @@ void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* b
                                                                  : n_active / (kSmallSegment + 1));
   const int ew0 = NextEvent(S);
   if (ew0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ew0], s));
-  if (S.block_worker) {
+  // Worker choice (both are exact): the four-wavefront worker pays off when the bucket's active
+  // edges sit in few, large components that are mostly chains on one region (the fixed cost of a
+  // batch is shared by four times the edges); many small clusters growing side by side are still
+  // replayed faster by the one-wavefront worker (cheaper rounds).  S.block_worker: 0 never
+  // (default), 1 always, 2 by the average component size of the bucket (VSG_BLOCK_WORKER).
+  bool use_block = S.block_worker == 1;
+  if (S.block_worker == 2 && n_active >= (1 << 20)) {
+    int num_segs_host = 0;
+    VSG_HIP(hipMemcpyAsync(&num_segs_host, S.num_segs, sizeof(int), hipMemcpyDeviceToHost, s));
+    VSG_HIP(hipStreamSynchronize(s));
+    use_block = num_segs_host > 0 && n_active / num_segs_host >= 64;
+  }
+  if (use_block) {
     hipLaunchKernelGGL(k_merge_block, dim3(wave_grid), dim3(256), 0, s, S.num_segs, S.seg_off,
                        S.seg_cnt, s_ra, s_rb, s_gpos, nodes, kept_all, T, optimistic ? 1 : 0,
                        d_violation, S.stats, S.wave_dbg);
