@@ -1582,6 +1582,7 @@ struct BlockShared {
   float h_fin[4];
   int32_t wsum[4];
   int32_t rewind;
+  int32_t fl_slot;   // slot of the first hot lane's other end (see the round loop)
 };
 
 struct Mask256 {
@@ -1918,12 +1919,25 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
           hot = h;
           if (pending && sa == sb) pending = false;   // became internal
         }
-        if (!__syncthreads_or(pending ? 1 : 0)) break;
+        const bool a_hot = (sa == hot), b_hot = (sb == hot);
+        bool hot_lane = pending && (a_hot || b_hot);
+        // one exchange: who is still pending (loop exit) and which lanes touch the hot region
+        Mask256 pl[2];
+        {
+          const bool pr[2] = {pending, hot_lane};
+          BlockBallotN<2>(sh, slot, pr, pl);
+        }
+        if (!MaskAny(pl[0])) break;
         if (round > 600u) {   // cannot happen (the earliest pending lane commits): report
           if (g == 0) atomicAdd(&stats[22], 1ull);
           break;
         }
-        const bool a_hot = (sa == hot), b_hot = (sb == hot);
+        const Mask256& lit = pl[1];
+        const int first_lit = MaskFirst(lit);
+        // A chain starts at the first edge that touches the hot region and only if that lane is the
+        // earliest pending edge on its other end: it publishes that end's slot, everybody checks
+        // the reservation word after the barrier.
+        if (g == first_lit) sh.fl_slot = a_hot ? sb : sa;
         const uint32_t key = ((0xfffffu - round) << 8) | (uint32_t)g;
         if (pending) {
           if (!a_hot) atomicMin(&sh.res[sa], key);
@@ -1943,17 +1957,10 @@ __global__ __launch_bounds__(256) void k_merge_block(const int32_t* __restrict__
         const int oa = (int)(res_a & 255u), ob = (int)(res_b & 255u);
         RState Hs = {}, P = {};
         int ps = 0;
-        bool hot_lane = pending && (a_hot || b_hot);
         bool elig = false, both = false, merging = false, case_s = false, fin = false;
-        Mask256 la[2];
-        {
-          const bool pr[2] = {hot_lane, hot_lane && (own_a || own_b)};
-          BlockBallotN<2>(sh, slot, pr, la);
-        }
-        const Mask256& lit = la[0];
-        const Mask256& lit_own = la[1];
-        const int first_lit = MaskFirst(lit);
-        const bool chain_possible = first_lit < 256 && MaskBit(lit_own, first_lit) && !(dbg_flags & 1);
+        const bool chain_possible =
+            first_lit < 256 && !(dbg_flags & 1) &&
+            sh.res[sh.fl_slot] == (((0xfffffu - round) << 8) | (uint32_t)first_lit);
         if (chain_possible) {
           Hs = BTabLoad(sh, hot);
           fin = (Hs.flags & kFlagFinalized) != 0;
