@@ -49,7 +49,7 @@ struct MergeParams {
   int min_region_size;
   float force_merge_weight;   // 0.001 (L2) / 0.002 (L1), dense_segmentation.cpp:259-264
   float inv_scale;            // (float)(1.0 / scale_), segmentation_graph.h:348
-  // Squared-distance thresholds (see merge_kernels.hip): largest float s with
+  // Squared-distance thresholds (see merge_common.h): largest float s with
   // sqrtf(s) < 0.05f, (double)sqrtf(s) < 0.2 and sqrtf(s) <= 0.15f respectively.
   float s_lt_005, s_lt_02, s_le_015;
 };
@@ -97,7 +97,7 @@ void UniqueU64(void* temp, size_t temp_bytes, const unsigned long long* in,
                unsigned long long* out,
                int32_t* num_out, int n, hipStream_t s);
 
-// ---- merge_kernels.hip ----------------------------------------------------------------
+// ---- merge_stage.hip (workers: merge_wave.hip, merge_block.hip, merge_wave_v1.hip) ----------------------------------------------------------------
 struct MergeScratch {
   // sized for the largest bucket (n_max edges)
   int32_t* e_ra;         // root of node a at filter time (per bucket edge)

@@ -1,0 +1,297 @@
+// merge_common.h -- device helpers shared by the merge kernels (merge_stage.hip and the workers
+// merge_wave_v1.hip / merge_wave.hip / merge_block.hip): union-find, the exact edge semantics on
+// plain values, wave-level primitives, and the launchers of the workers.
+#ifndef VSG_MERGE_COMMON_H_
+#define VSG_MERGE_COMMON_H_
+
+#include "device_graph.h"
+
+namespace vsg {
+
+constexpr int kSmallSegment = 24;   // components with more active edges go to a wavefront / workgroup
+constexpr int kTabDirty = 0x100;    // region table entry changed since it was loaded
+
+// ------------------------------------------------------------------------------------------
+// Union-find helpers.
+// ------------------------------------------------------------------------------------------
+// Find with full path compression (GetRegion, segmentation_graph.h:651-669).  Concurrent callers
+// may race on parent[] writes; every value ever written is an ancestor of the node, so any
+// interleaving leaves a valid forest with the same roots.
+__device__ __forceinline__ int FindCompress(int32_t* __restrict__ parent, int x) {
+  int root = x;
+  int p = parent[root];
+  while (p != root) {
+    root = p;
+    p = parent[root];
+  }
+  int cur = x;
+  while (cur != root) {
+    const int next = parent[cur];
+    if (next != root) parent[cur] = root;
+    cur = next;
+  }
+  return root;
+}
+
+__device__ __forceinline__ int FindReadOnly(const int32_t* __restrict__ parent, int x) {
+  int p = parent[x];
+  while (p != x) {
+    x = p;
+    p = parent[x];
+  }
+  return x;
+}
+
+// Scratch component structure (min-id hooking with atomicCAS, as in ECL-CC).
+__device__ __forceinline__ int CcFind(int32_t* cc, int x) {
+  int p = cc[x];
+  while (p != x) {
+    const int gp = cc[p];
+    if (gp != p) cc[x] = gp;   // path halving
+    x = p;
+    p = cc[x];
+  }
+  return x;
+}
+
+__device__ __forceinline__ void CcUnion(int32_t* cc, int a, int b) {
+  a = CcFind(cc, a);
+  b = CcFind(cc, b);
+  while (a != b) {
+    if (a < b) {
+      const int t = a;
+      a = b;
+      b = t;
+    }
+    // a > b: hook a under b if a is still a root.
+    const int old = atomicCAS(&cc[a], a, b);
+    if (old == a) return;
+    a = CcFind(cc, old);
+    b = CcFind(cc, b);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Edge decoding.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void DecodeEdge(const ListDesc& L, uint32_t slot, int W, int& a, int& b) {
+  if (L.type == 0) {
+    const uint32_t pix = slot >> 2;
+    const int k = (int)(slot & 3u);
+    a = L.base_a + (int)pix;
+    const int off = (k == 0) ? 1 : (k == 1) ? W : (k == 2) ? (W - 1) : (W + 1);
+    b = a + off;
+  } else {
+    const uint32_t pix = slot / 9u;
+    const int k = (int)(slot - pix * 9u);
+    const int dy = k / 3 - 1, dx = k - (k / 3) * 3 - 1;
+    a = L.base_a + (int)pix;
+    b = L.base_b + L.prev_idx[pix] + dy * W + dx;
+  }
+}
+
+// bucket_base row for one bucket: base[l] = #edges of this bucket in lists < l, base[L] = total.
+__device__ __forceinline__ int LocateList(const int32_t* __restrict__ base, int num_lists, int j) {
+  int lo = 0, hi = num_lists;   // largest l with base[l] <= j
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (base[mid] <= j) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact edge semantics on plain values (shared by the lane and the wave worker).
+// ------------------------------------------------------------------------------------------
+struct RState {
+  float d0, d1, d2;
+  int sz;
+  int cons;
+  int flags;
+};
+
+enum : int { kOutSkip = 0, kOutKeep = 1, kOutMerge1 = 2, kOutMerge2 = 3 };
+// kOutMerge1: region 1 survives (s1 holds the merged state); kOutMerge2: region 2 survives.
+
+// ColorMeanDescriptorTraits::DescriptorDistance (pixel_distance.h:479-493) is
+//   dist = sqrt((dx^2+dy^2+dz^2) * (1/3));  return (w < force_w && dist < 0.2) ? 0 : dist
+// and is only ever compared with a threshold.  sqrtf is correctly rounded and monotone, so every
+// comparison is rewritten on s = (dx^2+dy^2+dz^2) * (1/3) against a float threshold that the host
+// derives with the same correctly rounded sqrtf (dense_graph.cpp: SquaredThresholds):
+//   regular merge test  d < 0.05f   <=>  s <= pass_s
+//   constrained split   d > 0.15f   <=>  s >  split_s
+// (with the force-merge rule of the stage's edge weight folded in).
+__device__ __forceinline__ float SquaredDistance(const RState& a, const RState& b) {
+  const float x = a.d0 - b.d0, y = a.d1 - b.d1, z = a.d2 - b.d2;
+  return (x * x + y * y + z * z) * (1.0f / 3.0f);
+}
+
+// MergeRegions (segmentation_graph.h:671-701) + MergeDescriptor (pixel_distance.h:495-505).
+// Returns kOutMerge1 / kOutMerge2; the survivor's RState receives the merged values.
+__device__ __forceinline__ int MergeStates(RState& s1, RState& s2) {
+  const bool first_wins = s1.sz > s2.sz;       // ties keep rep_2
+  RState& m = first_wins ? s1 : s2;
+  const RState& o = first_wins ? s2 : s1;
+  if (!((m.flags | o.flags) & kFlagNoDesc)) {
+    const float denom = 1.0f / (float)(o.sz + m.sz);
+    const float a = (float)o.sz * denom;
+    const float b = (float)m.sz * denom;
+    m.d0 = a * o.d0 + b * m.d0;
+    m.d1 = a * o.d1 + b * m.d1;
+    m.d2 = a * o.d2 + b * m.d2;
+  }
+  m.sz += o.sz;
+  m.cons = max(s1.cons, s2.cons);
+  m.flags |= (o.flags & kFlagTentative);   // tentatively settled edges of `o` now hang on `m`
+  return first_wins ? kOutMerge1 : kOutMerge2;
+}
+
+// One edge of SegmentGraph (segmentation_graph.h:374-440).  s1/s2 are updated in place (flags,
+// constraints, merged state).  stat: 0 none, 1 forced, 2 regular, 3 small.
+struct StageThr {
+  float pass_s;    // regular test passes  <=> s <= pass_s
+  float split_s;   // constrained split    <=> s >  split_s
+  int min_size;
+};
+
+__device__ __forceinline__ int DecideEdge(RState& s1, RState& s2, const StageThr& T, int& stat) {
+  stat = 0;
+  if (s1.cons < 0 || s2.cons < 0) {
+    if (!((s1.flags | s2.flags) & kFlagFinalized)) {
+      if (SquaredDistance(s1, s2) <= T.pass_s) {   // d < MergeDistanceThreshold
+        stat = 2;
+        return MergeStates(s1, s2);
+      }
+      s1.flags |= kFlagFinalized;
+      s2.flags |= kFlagFinalized;
+    }
+    // at least one finalized here
+    if (s1.sz < T.min_size || s2.sz < T.min_size) {
+      stat = 3;
+      return MergeStates(s1, s2);
+    }
+    return kOutKeep;
+  } else if (s1.cons == s2.cons) {
+    if (SquaredDistance(s1, s2) > T.split_s) {     // d > SplitDistanceThreshold
+      if ((double)s1.sz < (double)s2.sz * 0.3) {
+        s1.cons = -1;
+      } else if ((double)s2.sz < (double)s1.sz * 0.3) {
+        s2.cons = -1;
+      } else {
+        s1.cons = -1;
+        s2.cons = -1;
+      }
+      return kOutKeep;
+    }
+    stat = 1;
+    return MergeStates(s1, s2);
+  }
+  return kOutKeep;
+}
+
+// A tentatively settled edge stays settled only while the constraints of its two regions do not
+// change.  o1/o2: states before the edge, n1/n2: states that replace them (for a merge both are
+// the survivor's state).
+__device__ __forceinline__ bool TentativeViolated(const RState& o1, const RState& o2,
+                                                  const RState& n1, const RState& n2) {
+  return ((o1.flags & kFlagTentative) && n1.cons != o1.cons) ||
+         ((o2.flags & kFlagTentative) && n2.cons != o2.cons);
+}
+
+__device__ __forceinline__ RState LoadState(const NodeArrays& nodes, int r) {
+  const float4 ds = nodes.desc_sz[r];
+  RState s;
+  s.d0 = ds.x;
+  s.d1 = ds.y;
+  s.d2 = ds.z;
+  s.sz = __float_as_int(ds.w);
+  s.cons = nodes.cons[r];
+  s.flags = nodes.flags[r];
+  return s;
+}
+
+__device__ __forceinline__ void StoreState(const NodeArrays& nodes, int r, const RState& s) {
+  nodes.desc_sz[r] = make_float4(s.d0, s.d1, s.d2, __int_as_float(s.sz));
+  nodes.cons[r] = s.cons;
+  nodes.flags[r] = (uint8_t)s.flags;
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave-level primitives.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ReadLaneI(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float ReadLaneF(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ RState ReadLaneState(const RState& s, int lane) {
+  RState r;
+  r.d0 = ReadLaneF(s.d0, lane);
+  r.d1 = ReadLaneF(s.d1, lane);
+  r.d2 = ReadLaneF(s.d2, lane);
+  r.sz = ReadLaneI(s.sz, lane);
+  r.cons = ReadLaneI(s.cons, lane);
+  r.flags = ReadLaneI(s.flags, lane);
+  return r;
+}
+
+__device__ __forceinline__ bool SameState(const RState& a, const RState& b) {
+  return a.sz == b.sz && a.cons == b.cons && a.flags == b.flags;   // descriptor only changes with sz
+}
+
+// Wave-wide inclusive prefix sum / maximum with DPP row shifts and row broadcasts (no LDS round
+// trips).  Lanes without a source keep the identity 0 (`old` operand, bound_ctrl off).
+template <int kCtrl, int kRowMask, int kBankMask>
+__device__ __forceinline__ int Dpp0(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, kCtrl, kRowMask, kBankMask, false);
+}
+
+__device__ __forceinline__ int WaveInclusiveSum(int v) {
+  int t = v + Dpp0<0x111, 0xf, 0xf>(v);     // row_shr:1
+  t += Dpp0<0x112, 0xf, 0xf>(v);            // row_shr:2
+  int o = t + Dpp0<0x113, 0xf, 0xf>(v);     // row_shr:3
+  o += Dpp0<0x114, 0xf, 0xe>(o);            // row_shr:4, banks 1-3
+  o += Dpp0<0x118, 0xf, 0xc>(o);            // row_shr:8, banks 2-3
+  o += Dpp0<0x142, 0xa, 0xf>(o);            // row_bcast:15 into rows 1 and 3
+  o += Dpp0<0x143, 0xc, 0xf>(o);            // row_bcast:31 into rows 2 and 3
+  return o;
+}
+
+// Maximum of non-negative values, returned to every lane.
+__device__ __forceinline__ int WaveMax(int v) {
+  int t = max(v, Dpp0<0x111, 0xf, 0xf>(v));
+  t = max(t, Dpp0<0x112, 0xf, 0xf>(v));
+  int o = max(t, Dpp0<0x113, 0xf, 0xf>(v));
+  o = max(o, Dpp0<0x114, 0xf, 0xe>(o));
+  o = max(o, Dpp0<0x118, 0xf, 0xc>(o));
+  o = max(o, Dpp0<0x142, 0xa, 0xf>(o));
+  o = max(o, Dpp0<0x143, 0xc, 0xf>(o));
+  return __builtin_amdgcn_readlane(o, 63);
+}
+
+// ------------------------------------------------------------------------------------------
+// Workers of the components with more than kSmallSegment active edges (one launch per stage).
+// ------------------------------------------------------------------------------------------
+struct WorkerArgs {
+  const int32_t* num_segs;
+  const int32_t* seg_off;
+  const int32_t* seg_cnt;
+  const int32_t* s_ra;      // active edges in component order: roots at filter time, kept position
+  const int32_t* s_rb;
+  const uint32_t* s_gpos;
+  NodeArrays nodes;
+  uint8_t* kept_all;
+  StageThr T;
+  int optimistic;
+  int32_t* violation;
+  unsigned long long* stats;
+};
+// Edge-by-edge replay by one wavefront (round 1a; debug reference, VSG_WAVE_V1).
+void LaunchMergeWaveV1(int grid, const WorkerArgs& a, hipStream_t s);
+// Round-based replay by one consumer wavefront + one reader wavefront (the default).
+void LaunchMergeWave(int grid, const WorkerArgs& a, bool instrumented, int dbg_flags, hipStream_t s);
+// Round-based replay of 256-edge batches by four wavefronts (opt-in, VSG_BLOCK_WORKER).
+void LaunchMergeBlock(int grid, const WorkerArgs& a, int dbg_flags, hipStream_t s);
+
+}  // namespace vsg
+
+#endif  // VSG_MERGE_COMMON_H_

@@ -1,0 +1,501 @@
+// merge_stage.hip -- the ordered union-find merge (K6), gfx950: the stage of one bucket.
+//
+// Reference semantics restated: FastSegmentationGraph::SegmentGraph / GetRegion / MergeRegions
+// (segmentation/segmentation_graph.h:339-463, 651-701) with ColorMeanDescriptorTraits
+// (segmentation/pixel_distance.h:469-521).  The reference walks every edge sequentially in
+// (bucket, bucket list, insertion) order and its merge predicate depends on evolving float state,
+// so the result is order dependent.  This file keeps that order *exactly* and extracts the
+// parallelism that is provably free:
+//
+//   stage = one bucket.  k_filter (all CUs): find both roots with path compression, drop edges
+//   that are already internal, settle edges between two finalized, large, unconstrained-graph
+//   regions as "kept" (they can never change state again), and hook the roots of the remaining
+//   *active* edges into a scratch union-find (ECL-CC style atomicCAS hooking).
+//   Two active edges can only influence each other if they are connected through active edges of
+//   the same bucket, so each connected component of that scratch graph is an independent
+//   sequential sub-problem.  Active edges are stably sorted by component and every component is
+//   replayed in the reference's order by its own worker: one lane for a small component, one
+//   64-lane wavefront for a large one (lanes prefetch roots + region state for 64 edges, then the
+//   wave resolves them in order with readlane broadcasts, keeping region state in registers).
+//
+// This is memory-latency / dependency bound integer + scalar float work: no MFMA, no LDS tiling;
+// what matters is coalesced streaming in the filter and keeping the serial chains in registers.
+// The workers of the large components live in merge_wave.hip (default), merge_block.hip (opt-in)
+// and merge_wave_v1.hip (edge-by-edge reference); shared device helpers in merge_common.h.
+#include "merge_common.h"
+
+namespace vsg {
+
+__global__ __launch_bounds__(256) void k_build_bucket_table(const ListDesc* __restrict__ lists,
+                                                             int num_lists,
+                                                             int32_t* __restrict__ bucket_base) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b > kNumBuckets) return;
+  int acc = 0;
+  int32_t* row = bucket_base + (size_t)b * (num_lists + 1);
+  for (int l = 0; l < num_lists; ++l) {
+    row[l] = acc;
+    const int32_t* off = lists[l].offsets;
+    if (off) acc += off[b + 1] - off[b];
+  }
+  row[num_lists] = acc;
+}
+
+void LaunchBuildBucketTable(const ListDesc* lists, int num_lists, int32_t* bucket_base,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(k_build_bucket_table, dim3((kNumBuckets + 1 + 255) / 256), dim3(256), 0, s,
+                     lists, num_lists, bucket_base);
+  VSG_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_init_identity(int32_t* a, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] = (int32_t)i;
+}
+
+void LaunchInitIdentity(int32_t* a, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_identity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n);
+  VSG_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage step 1: filter.
+// ------------------------------------------------------------------------------------------
+// inert_mode 0: every non-internal edge is active.
+// inert_mode 1 (graph without constraints): an edge between two finalized regions of at least
+//   min size is kept and changes no state whenever it is visited -- exact, because such a region
+//   stays finalized and large and there is no constraint that could force a merge.
+// inert_mode 2 (graph with constraints): the same edges, and edges between regions with different
+//   constraints, are *tentatively* settled as kept.  That is only valid while the constraint of
+//   the regions involved does not change during this stage, so both regions are marked
+//   (kFlagTentative in the region flags, which travel with the state into the workers); a worker
+//   that changes the constraint of a marked region raises the stage's violation flag and the host
+//   rolls the stage back and replays it with inert_mode 0 (see RunBucketStage).
+__global__ __launch_bounds__(256) void k_filter(int bucket, int n_b,
+                                                 const ListDesc* __restrict__ lists,
+                                                 const int32_t* __restrict__ base_row,
+                                                 const uint32_t* __restrict__ list_slot_base,
+                                                 uint8_t* __restrict__ kept_all, NodeArrays nodes,
+                                                 MergeParams P, int inert_mode,
+                                                 int32_t* __restrict__ cc,
+                                                 int32_t* __restrict__ e_ra,
+                                                 int32_t* __restrict__ e_rb,
+                                                 uint32_t* __restrict__ e_gpos,
+                                                 int32_t* __restrict__ e_active,
+                                                 uint8_t* __restrict__ e_ti,
+                                                 int32_t* __restrict__ num_ti) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  int ti = 0;
+  if (j < n_b) {
+    const int l = LocateList(base_row, P.num_lists, j);
+    const ListDesc L = lists[l];
+    const int pos = L.offsets[bucket] + (j - base_row[l]);
+    int a, b;
+    DecodeEdge(L, L.slots[pos], P.W, a, b);
+    const int ra = FindCompress(nodes.parent, a);
+    const int rb = FindCompress(nodes.parent, b);
+    const uint32_t gpos = list_slot_base[l] + (uint32_t)pos;
+    int active = 0;
+    if (ra != rb) {
+      bool inert = false;
+      if (inert_mode != 0) {
+        const int f1 = nodes.flags[ra], f2 = nodes.flags[rb];
+        bool both_final_large = false;
+        if ((f1 & kFlagFinalized) && (f2 & kFlagFinalized)) {
+          const int s1 = __float_as_int(nodes.desc_sz[ra].w);
+          const int s2 = __float_as_int(nodes.desc_sz[rb].w);
+          both_final_large = (s1 >= P.min_region_size) && (s2 >= P.min_region_size);
+        }
+        if (inert_mode == 1) {
+          inert = both_final_large;
+        } else {
+          const int c1 = nodes.cons[ra], c2 = nodes.cons[rb];
+          if (c1 >= 0 && c2 >= 0) {
+            inert = (c1 != c2);            // different constraints: never merged
+          } else {
+            inert = both_final_large;      // at least one unconstrained
+          }
+          if (inert) {
+            ti = 1;
+            if (!(f1 & kFlagTentative)) nodes.flags[ra] = (uint8_t)(f1 | kFlagTentative);
+            if (!(f2 & kFlagTentative)) nodes.flags[rb] = (uint8_t)(f2 | kFlagTentative);
+          }
+        }
+      }
+      if (inert) {
+        kept_all[gpos] = 1;
+      } else {
+        active = 1;
+        CcUnion(cc, ra, rb);
+      }
+    }
+    e_ra[j] = ra;
+    e_rb[j] = rb;
+    e_gpos[j] = gpos;
+    e_active[j] = active;
+    e_ti[j] = (uint8_t)ti;
+  }
+  const unsigned long long m = __ballot(ti != 0);
+  if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(num_ti, (int)__popcll(m));
+}
+
+// Clears the tentative marks of a stage: on the regions marked by the filter and on whatever
+// region they have been merged into since.
+__global__ __launch_bounds__(256) void k_clear_tentative(int n_b, const uint8_t* __restrict__ e_ti,
+                                                          const int32_t* __restrict__ e_ra,
+                                                          const int32_t* __restrict__ e_rb,
+                                                          NodeArrays nodes) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_b || !e_ti[j]) return;
+  int r[2] = {e_ra[j], e_rb[j]};
+  for (int k = 0; k < 2; ++k) {
+    int x = r[k];
+    for (;;) {
+      const int f = nodes.flags[x];
+      if (f & kFlagTentative) nodes.flags[x] = (uint8_t)(f & ~kFlagTentative);
+      const int p = nodes.parent[x];
+      if (p == x) break;
+      x = p;
+    }
+  }
+}
+
+// Undo support for an optimistic stage: region states of every active edge's two regions.
+__global__ __launch_bounds__(256) void k_backup_roots(int n, const int32_t* __restrict__ a_ra,
+                                                       const int32_t* __restrict__ a_rb,
+                                                       NodeArrays nodes, float4* __restrict__ bk_ds,
+                                                       int32_t* __restrict__ bk_cons,
+                                                       uint8_t* __restrict__ bk_flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ra = a_ra[i], rb = a_rb[i];
+  bk_ds[2 * i] = nodes.desc_sz[ra];
+  bk_cons[2 * i] = nodes.cons[ra];
+  bk_flags[2 * i] = nodes.flags[ra];
+  bk_ds[2 * i + 1] = nodes.desc_sz[rb];
+  bk_cons[2 * i + 1] = nodes.cons[rb];
+  bk_flags[2 * i + 1] = nodes.flags[rb];
+}
+
+__global__ __launch_bounds__(256) void k_restore_roots(int n, const int32_t* __restrict__ a_ra,
+                                                        const int32_t* __restrict__ a_rb,
+                                                        NodeArrays nodes,
+                                                        const float4* __restrict__ bk_ds,
+                                                        const int32_t* __restrict__ bk_cons,
+                                                        const uint8_t* __restrict__ bk_flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ra = a_ra[i], rb = a_rb[i];
+  nodes.parent[ra] = ra;
+  nodes.desc_sz[ra] = bk_ds[2 * i];
+  nodes.cons[ra] = bk_cons[2 * i];
+  nodes.flags[ra] = bk_flags[2 * i];
+  nodes.parent[rb] = rb;
+  nodes.desc_sz[rb] = bk_ds[2 * i + 1];
+  nodes.cons[rb] = bk_cons[2 * i + 1];
+  nodes.flags[rb] = bk_flags[2 * i + 1];
+}
+
+__global__ __launch_bounds__(256) void k_clear_kept(int n_b, const uint32_t* __restrict__ e_gpos,
+                                                     uint8_t* __restrict__ kept_all) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n_b) kept_all[e_gpos[j]] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_compact_active(int n_b, const int32_t* __restrict__ e_active,
+                                                         const int32_t* __restrict__ e_apos,
+                                                         const int32_t* __restrict__ e_ra,
+                                                         const int32_t* __restrict__ e_rb,
+                                                         const uint32_t* __restrict__ e_gpos,
+                                                         int32_t* __restrict__ a_ra,
+                                                         int32_t* __restrict__ a_rb,
+                                                         uint32_t* __restrict__ a_gpos,
+                                                         int32_t* __restrict__ num_active) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_b) return;
+  if (e_active[j]) {
+    const int p = e_apos[j];
+    a_ra[p] = e_ra[j];
+    a_rb[p] = e_rb[j];
+    a_gpos[p] = e_gpos[j];
+  }
+  if (j == n_b - 1) *num_active = e_apos[j] + e_active[j];
+}
+
+__global__ __launch_bounds__(256) void k_component_ids(int n, const int32_t* __restrict__ a_ra,
+                                                        int32_t* __restrict__ cc,
+                                                        uint32_t* __restrict__ a_comp,
+                                                        uint32_t* __restrict__ a_idx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  a_comp[i] = (uint32_t)CcFind(cc, a_ra[i]);
+  a_idx[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_reset_cc(int n, const int32_t* __restrict__ a_ra,
+                                                   const int32_t* __restrict__ a_rb,
+                                                   int32_t* __restrict__ cc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ra = a_ra[i], rb = a_rb[i];
+  cc[ra] = ra;
+  cc[rb] = rb;
+}
+
+// Active edges in component order (contiguous input of the workers).
+__global__ __launch_bounds__(256) void k_gather_sorted(int n, const uint32_t* __restrict__ s_idx,
+                                                        const int32_t* __restrict__ a_ra,
+                                                        const int32_t* __restrict__ a_rb,
+                                                        const uint32_t* __restrict__ a_gpos,
+                                                        int32_t* __restrict__ s_ra,
+                                                        int32_t* __restrict__ s_rb,
+                                                        uint32_t* __restrict__ s_gpos) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t i = s_idx[p];
+  s_ra[p] = a_ra[i];
+  s_rb[p] = a_rb[i];
+  s_gpos[p] = a_gpos[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Worker A: one lane replays one small component.
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__ num_segs,
+                                                      const int32_t* __restrict__ seg_off,
+                                                      const int32_t* __restrict__ seg_cnt,
+                                                      const int32_t* __restrict__ s_ra,
+                                                      const int32_t* __restrict__ s_rb,
+                                                      const uint32_t* __restrict__ s_gpos,
+                                                      NodeArrays nodes, uint8_t* __restrict__ kept_all,
+                                                      StageThr T, int optimistic,
+                                                      int32_t* __restrict__ violation,
+                                                      unsigned long long* __restrict__ stats) {
+  const int seg = blockIdx.x * 256 + threadIdx.x;
+  unsigned n_forced = 0, n_regular = 0, n_small = 0;
+  if (seg < *num_segs) {
+    const int cnt = seg_cnt[seg];
+    if (cnt <= kSmallSegment) {
+      const int beg = seg_off[seg];
+      for (int p = beg; p < beg + cnt; ++p) {
+        // An optimistic stage must stay undoable from the backed-up region states alone, so it
+        // does not compress paths.
+        const int r1 = optimistic ? FindReadOnly(nodes.parent, s_ra[p])
+                                  : FindCompress(nodes.parent, s_ra[p]);
+        const int r2 = optimistic ? FindReadOnly(nodes.parent, s_rb[p])
+                                  : FindCompress(nodes.parent, s_rb[p]);
+        if (r1 == r2) continue;
+        RState s1 = LoadState(nodes, r1);
+        RState s2 = LoadState(nodes, r2);
+        const RState o1 = s1, o2 = s2;
+        int stat;
+        const int out = DecideEdge(s1, s2, T, stat);
+        if (optimistic) {
+          const bool v = (out == kOutKeep)     ? TentativeViolated(o1, o2, s1, s2)
+                         : (out == kOutMerge1) ? TentativeViolated(o1, o2, s1, s1)
+                                               : TentativeViolated(o1, o2, s2, s2);
+          if (v) *violation = 1;
+        }
+        n_forced += (stat == 1);
+        n_regular += (stat == 2);
+        n_small += (stat == 3);
+        if (out == kOutKeep) {
+          kept_all[s_gpos[p]] = 1;
+          StoreState(nodes, r1, s1);
+          StoreState(nodes, r2, s2);
+        } else if (out == kOutMerge1) {
+          StoreState(nodes, r1, s1);
+          nodes.parent[r2] = r1;
+        } else {
+          StoreState(nodes, r2, s2);
+          nodes.parent[r1] = r2;
+        }
+      }
+    }
+  }
+  // wave-level reduction of the statistics
+  for (int off = 32; off > 0; off >>= 1) {
+    n_forced += __shfl_down(n_forced, off);
+    n_regular += __shfl_down(n_regular, off);
+    n_small += __shfl_down(n_small, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (n_forced) atomicAdd(&stats[0], (unsigned long long)n_forced);
+    if (n_regular) atomicAdd(&stats[1], (unsigned long long)n_regular);
+    if (n_small) atomicAdd(&stats[2], (unsigned long long)n_small);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host driver of one bucket stage.
+// ------------------------------------------------------------------------------------------
+static inline unsigned Blocks(int n) { return (unsigned)((n + 255) / 256); }
+
+static int NextEvent(MergeScratch& S) {
+  if (!S.ev_pool) return -1;
+  if (*S.ev_used >= (int)S.ev_pool->size()) {
+    hipEvent_t e;
+    VSG_HIP(hipEventCreate(&e));
+    S.ev_pool->push_back(e);
+  }
+  return (*S.ev_used)++;
+}
+
+void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* bucket_base,
+                    const uint32_t* list_slot_base, uint8_t* kept_all, NodeArrays nodes,
+                    const MergeParams& P, int inert_mode, MergeScratch& S, hipStream_t s) {
+  if (n_b <= 0) return;
+  const int32_t* base_row = bucket_base + (size_t)bucket * (P.num_lists + 1);
+  int32_t* d_num_ti = S.num_active + 2;
+  int32_t* d_violation = S.num_active + 3;
+  VSG_HIP(hipMemsetAsync(d_num_ti, 0, 2 * sizeof(int32_t), s));
+  const int ef0 = NextEvent(S);
+  if (ef0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ef0], s));
+  hipLaunchKernelGGL(k_filter, dim3(Blocks(n_b)), dim3(256), 0, s, bucket, n_b, lists, base_row,
+                     list_slot_base, kept_all, nodes, P, inert_mode, S.cc, S.e_ra, S.e_rb, S.e_gpos,
+                     S.e_active, S.e_ti, d_num_ti);
+  const int ef1 = NextEvent(S);
+  if (ef1 >= 0) {
+    VSG_HIP(hipEventRecord((*S.ev_pool)[ef1], s));
+    S.ev_filter->emplace_back(ef0, ef1);
+  }
+  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, S.e_active, S.e_apos, n_b, s);
+  hipLaunchKernelGGL(k_compact_active, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_active,
+                     S.e_apos, S.e_ra, S.e_rb, S.e_gpos, S.a_ra, S.a_rb, S.a_gpos, S.num_active);
+  VSG_HIP(hipGetLastError());
+  int h[4] = {0, 0, 0, 0};   // num_active, num_segs (unused), num_ti, violation
+  VSG_HIP(hipMemcpyAsync(h, S.num_active, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  VSG_HIP(hipStreamSynchronize(s));
+  const int n_active = h[0];
+  const int n_ti = h[2];
+  auto clear_marks = [&]() {
+    if (n_ti > 0) {
+      hipLaunchKernelGGL(k_clear_tentative, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_ti, S.e_ra,
+                         S.e_rb, nodes);
+    }
+  };
+  if (n_active == 0) {
+    clear_marks();
+    return;
+  }
+
+  hipLaunchKernelGGL(k_component_ids, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra,
+                     S.cc, S.a_comp, S.a_idx);
+  SortPairsU32(S.cub_temp, S.cub_temp_bytes, S.a_comp, S.s_comp, S.a_idx, S.s_idx, n_active, 32,
+               s);
+  RunLengthEncodeU32(S.cub_temp, S.cub_temp_bytes, S.s_comp, S.seg_key, S.seg_cnt, S.num_segs,
+                     n_active, s);
+  // Segment offsets: exclusive scan over n_active counts (only the first num_segs are defined;
+  // the prefix of an exclusive scan never depends on later elements).
+  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, S.seg_cnt, S.seg_off, n_active, s);
+
+  const bool optimistic = (inert_mode == 2) && n_ti > 0;
+  if (optimistic) {
+    hipLaunchKernelGGL(k_backup_roots, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra,
+                       S.a_rb, nodes, S.bk_ds, S.bk_cons, S.bk_flags);
+    VSG_HIP(hipMemcpyAsync(S.stats + 8, S.stats, 8 * sizeof(unsigned long long),
+                           hipMemcpyDeviceToDevice, s));
+  }
+
+  const float weight = (float)bucket * P.inv_scale;
+  const bool force = weight < P.force_merge_weight;
+  StageThr T;
+  T.pass_s = force ? P.s_lt_02 : P.s_lt_005;
+  T.split_s = force ? P.s_lt_02 : P.s_le_015;
+  T.min_size = P.min_region_size;
+  // Active edges in component order; the scratch arrays of the earlier steps are free by now.
+  int32_t* s_ra = reinterpret_cast<int32_t*>(S.a_comp);
+  int32_t* s_rb = reinterpret_cast<int32_t*>(S.a_idx);
+  uint32_t* s_gpos = reinterpret_cast<uint32_t*>(S.e_apos);
+  hipLaunchKernelGGL(k_gather_sorted, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.s_idx,
+                     S.a_ra, S.a_rb, S.a_gpos, s_ra, s_rb, s_gpos);
+  hipLaunchKernelGGL(k_merge_small, dim3(Blocks(n_active)), dim3(256), 0, s, S.num_segs, S.seg_off,
+                     S.seg_cnt, s_ra, s_rb, s_gpos, nodes, kept_all, T,
+                     optimistic ? 1 : 0, d_violation, S.stats);
+  const int wave_grid = n_active / (kSmallSegment + 1) < 1 ? 1
+                        : (n_active / (kSmallSegment + 1) > 8192 ? 8192
+                                                                 : n_active / (kSmallSegment + 1));
+  const int ew0 = NextEvent(S);
+  if (ew0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ew0], s));
+  // Worker choice (both are exact): the four-wavefront worker pays off when the bucket's active
+  // edges sit in few, large components that are mostly chains on one region (the fixed cost of a
+  // batch is shared by four times the edges); many small clusters growing side by side are still
+  // replayed faster by the one-wavefront worker (cheaper rounds).  S.block_worker: 0 never
+  // (default), 1 always, 2 by the average component size of the bucket (VSG_BLOCK_WORKER).
+  bool use_block = S.block_worker == 1;
+  if (S.block_worker == 2 && n_active >= (1 << 20)) {
+    int num_segs_host = 0;
+    VSG_HIP(hipMemcpyAsync(&num_segs_host, S.num_segs, sizeof(int), hipMemcpyDeviceToHost, s));
+    VSG_HIP(hipStreamSynchronize(s));
+    use_block = num_segs_host > 0 && n_active / num_segs_host >= 64;
+  }
+  WorkerArgs wa;
+  wa.num_segs = S.num_segs;
+  wa.seg_off = S.seg_off;
+  wa.seg_cnt = S.seg_cnt;
+  wa.s_ra = s_ra;
+  wa.s_rb = s_rb;
+  wa.s_gpos = s_gpos;
+  wa.nodes = nodes;
+  wa.kept_all = kept_all;
+  wa.T = T;
+  wa.optimistic = optimistic ? 1 : 0;
+  wa.violation = d_violation;
+  wa.stats = S.stats;
+  if (use_block) {
+    LaunchMergeBlock(wave_grid, wa, S.wave_dbg, s);
+  } else if (S.wave_v1) {
+    LaunchMergeWaveV1(wave_grid, wa, s);
+  } else {
+    LaunchMergeWave(wave_grid, wa, S.wave_debug != 0, S.wave_dbg, s);
+  }
+  const int ew1 = NextEvent(S);
+  if (ew1 >= 0) {
+    VSG_HIP(hipEventRecord((*S.ev_pool)[ew1], s));
+    S.ev_wave->emplace_back(ew0, ew1);
+  }
+  hipLaunchKernelGGL(k_reset_cc, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra, S.a_rb,
+                     S.cc);
+  VSG_HIP(hipGetLastError());
+  if (optimistic) {
+    int violated = 0;
+    VSG_HIP(hipMemcpyAsync(&violated, d_violation, sizeof(int), hipMemcpyDeviceToHost, s));
+    VSG_HIP(hipStreamSynchronize(s));
+    ++*S.optimistic_stages;
+    if (violated || S.force_rollback) {
+      // Undo the stage and replay it without any tentatively settled edge.
+      ++*S.rollbacks;
+      hipLaunchKernelGGL(k_restore_roots, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra,
+                         S.a_rb, nodes, S.bk_ds, S.bk_cons, S.bk_flags);
+      VSG_HIP(hipMemcpyAsync(S.stats, S.stats + 8, 8 * sizeof(unsigned long long),
+                             hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_gpos, kept_all);
+      clear_marks();
+      VSG_HIP(hipGetLastError());
+      RunBucketStage(bucket, n_b, lists, bucket_base, list_slot_base, kept_all, nodes, P, 0, S, s);
+      return;
+    }
+  }
+  clear_marks();
+  VSG_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_keep_virtual_bucket(const ListDesc* __restrict__ lists,
+                                                              int num_lists) {
+  // grid.y = list
+  const int l = blockIdx.y;
+  if (l >= num_lists) return;
+  const ListDesc L = lists[l];
+  if (!L.offsets) return;
+  const int beg = L.offsets[kNumBuckets], end = L.offsets[kNumBuckets + 1];
+  for (int p = beg + blockIdx.x * 256 + threadIdx.x; p < end; p += gridDim.x * 256) L.kept[p] = 1;
+}
+
+void LaunchKeepVirtualBucket(const ListDesc* lists, int num_lists, hipStream_t s) {
+  hipLaunchKernelGGL(k_keep_virtual_bucket, dim3(64, num_lists), dim3(256), 0, s, lists,
+                     num_lists);
+  VSG_HIP(hipGetLastError());
+}
+
+}  // namespace vsg

@@ -2,7 +2,7 @@
 //
 // Only generic building blocks (stable LSD radix sort, exclusive scan, run-length encode,
 // unique) come from the library; every kernel that encodes the segmentation algorithm itself
-// is hand-written in build_kernels.hip / merge_kernels.hip / readout_kernels.hip.
+// is hand-written in build_kernels.hip / merge_*.hip / readout_kernels.hip.
 // The stable radix sort is what realises the reference's implicit counting sort: edges are
 // generated in (scan order, neighbour order) and pushed back into per-bucket vectors
 // (segmentation_graph.h:158-162), i.e. a stable sort by bucket index.
