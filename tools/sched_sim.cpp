@@ -32,6 +32,8 @@ struct TraceRecord {
 };
 static_assert(sizeof(TraceRecord) == 40, "record layout");
 
+static int kHotMin = 2;   // VS_HOT_MIN: endpoints a region needs to become hot in strategy 2
+
 struct UF {
   std::vector<int> p;
   int find(int x) {
@@ -155,6 +157,224 @@ static void SimComponentMulti(const std::vector<TraceRecord>& rec, const std::ve
       if (!commits) {
         std::fprintf(stderr, "multi model stuck\n");
         std::exit(1);
+      }
+    }
+  }
+  *comp_rounds = rounds_here;
+}
+
+// Strategy 2: the kernel's transitive chain on the K most contended regions of a batch (K hot
+// regions, each with its own closure and cut; an edge with ends in two different hot groups waits
+// and ends both chains), everything else by reservations as in the kernel.
+static void SimComponentKHot(const std::vector<TraceRecord>& rec, const std::vector<int>& ed,
+                             std::unordered_map<int, int>& remap_scratch, int B, int K, Stats* st,
+                             long* comp_rounds) {
+  remap_scratch.clear();
+  auto id = [&](int r) {
+    auto it = remap_scratch.find(r);
+    if (it != remap_scratch.end()) return it->second;
+    const int v = (int)remap_scratch.size();
+    remap_scratch.emplace(r, v);
+    return v;
+  };
+  std::vector<int> ea(ed.size()), eb(ed.size());
+  for (size_t i = 0; i < ed.size(); ++i) {
+    ea[i] = id(rec[ed[i]].s1);
+    eb[i] = id(rec[ed[i]].s2);
+  }
+  const int R = (int)remap_scratch.size();
+  UF uf;
+  uf.p.resize(R);
+  std::iota(uf.p.begin(), uf.p.end(), 0);
+  std::vector<int> owner(R), cnt(R, 0), hot_of(R, -1);
+  size_t next = 0;
+  long rounds_here = 0;
+  std::vector<int> lanes;
+  std::vector<char> pending, failed;
+  while (next < ed.size()) {
+    lanes.clear();
+    while (next < ed.size() && (int)lanes.size() < B) {
+      if (uf.find(ea[next]) != uf.find(eb[next])) lanes.push_back((int)next);
+      ++next;
+    }
+    if (lanes.empty()) break;
+    ++st->batches;
+    st->live += (long)lanes.size();
+    const int n = (int)lanes.size();
+    pending.assign(n, 1);
+    failed.assign(n, 0);
+    std::vector<int> A(n), Bv(n), oa(n), ob(n), ga(n), gb(n);
+    std::vector<char> owna(n), ownb(n), elig(n), both(n), em(n), cross(n);
+    for (;;) {
+      int npend = 0;
+      std::vector<int> touched;
+      for (int l = 0; l < n; ++l) {
+        if (!pending[l]) continue;
+        A[l] = uf.find(ea[lanes[l]]);
+        Bv[l] = uf.find(eb[lanes[l]]);
+        if (A[l] == Bv[l]) {
+          pending[l] = 0;
+          ++st->retired_internal;
+          continue;
+        }
+        ++npend;
+        for (int r : {A[l], Bv[l]}) {
+          if (cnt[r]++ == 0) touched.push_back(r);
+        }
+      }
+      if (!npend) break;
+      ++st->rounds;
+      ++rounds_here;
+      // the K most contended regions of this round (>= 2 pending endpoints)
+      std::vector<int> hots;
+      {
+        std::vector<int> order(touched);
+        std::sort(order.begin(), order.end(), [&](int x, int y) {
+          return cnt[x] != cnt[y] ? cnt[x] > cnt[y] : x > y;
+        });
+        for (int r : order) {
+          if ((int)hots.size() >= K || cnt[r] < kHotMin) break;
+          hots.push_back(r);
+        }
+      }
+      if (kHotMin < 0) {
+        // variant: the hot region is the larger end of the earliest pending edge (no counting)
+        hots.clear();
+        for (int l = 0; l < n; ++l) {
+          if (!pending[l]) continue;
+          const TraceRecord& r = rec[ed[lanes[l]]];
+          hots.push_back(r.sz1 >= r.sz2 ? A[l] : Bv[l]);
+          break;
+        }
+      }
+      for (int r : touched) cnt[r] = 0;
+      for (size_t k = 0; k < hots.size(); ++k) hot_of[hots[k]] = (int)k;
+      // reservations (hot regions are not reserved)
+      touched.clear();
+      for (int l = 0; l < n; ++l) {
+        if (!pending[l]) continue;
+        for (int r : {A[l], Bv[l]}) {
+          if (hot_of[r] >= 0) continue;
+          if (cnt[r]++ == 0) {
+            owner[r] = l;
+            touched.push_back(r);
+          }
+        }
+      }
+      for (int r : touched) cnt[r] = 0;
+      for (int l = 0; l < n; ++l) {
+        if (!pending[l]) continue;
+        owna[l] = hot_of[A[l]] < 0 && owner[A[l]] == l;
+        ownb[l] = hot_of[Bv[l]] < 0 && owner[Bv[l]] == l;
+        oa[l] = hot_of[A[l]] < 0 ? owner[A[l]] : -1;
+        ob[l] = hot_of[Bv[l]] < 0 ? owner[Bv[l]] : -1;
+      }
+      // closure: effective group of every end (-1 none), absorbing lanes em
+      std::fill(em.begin(), em.end(), 0);
+      for (bool changed = true; changed;) {
+        changed = false;
+        for (int l = 0; l < n; ++l) {
+          if (!pending[l]) continue;
+          int g1 = hot_of[A[l]], g2 = hot_of[Bv[l]];
+          if (g1 < 0 && !owna[l] && oa[l] >= 0 && em[oa[l]]) g1 = ga[oa[l]] >= 0 ? ga[oa[l]] : gb[oa[l]];
+          if (g2 < 0 && !ownb[l] && ob[l] >= 0 && em[ob[l]]) g2 = ga[ob[l]] >= 0 ? ga[ob[l]] : gb[ob[l]];
+          // (an absorbing lane has exactly one effective end: its group)
+          ga[l] = g1;
+          gb[l] = g2;
+          both[l] = g1 >= 0 && g1 == g2;
+          cross[l] = g1 >= 0 && g2 >= 0 && g1 != g2;
+          elig[l] = 0;
+          if ((g1 >= 0) == (g2 >= 0)) continue;
+          const TraceRecord& r = rec[ed[lanes[l]]];
+          const bool part_is_2 = g1 >= 0;
+          const int psz = part_is_2 ? r.sz2 : r.sz1, hsz = part_is_2 ? r.sz1 : r.sz2;
+          const int pcons = part_is_2 ? r.cons2 : r.cons1, hcons = part_is_2 ? r.cons1 : r.cons2;
+          const int pfl = part_is_2 ? r.flags2 : r.flags1, hfl = part_is_2 ? r.flags1 : r.flags2;
+          const bool own_p = part_is_2 ? ownb[l] : owna[l];
+          const bool ok = own_p && !failed[l] && pfl == 0 && (pcons < 0 || pcons == hcons) &&
+                          psz < hsz && !(hfl & 2);
+          if (!ok) continue;
+          elig[l] = 1;
+          const bool fin = hfl & 1;
+          const bool m = pcons >= 0 || !fin || r.outcome == 2;
+          if (m && !em[l]) {
+            em[l] = 1;
+            changed = true;
+          }
+        }
+      }
+      // per group: cut at the first lane of the group that is neither chain lane nor internal
+      std::vector<int> cut(hots.size(), n);
+      for (int l = 0; l < n; ++l) {
+        if (!pending[l]) continue;
+        const bool ok = elig[l] || both[l];
+        for (int g : {ga[l], gb[l]}) {
+          if (g >= 0 && !ok && l < cut[g]) cut[g] = l;
+        }
+      }
+      for (int l = 0; l < n; ++l) {   // failed tests cut their group
+        if (!pending[l] || !elig[l]) continue;
+        const int g = ga[l] >= 0 ? ga[l] : gb[l];
+        if (l >= cut[g]) continue;
+        const TraceRecord& r = rec[ed[lanes[l]]];
+        const bool is_merge = r.outcome >= 1 && r.outcome <= 3;
+        if (r.pad[0] || (em[l] && !is_merge)) {
+          failed[l] = 1;
+          cut[g] = l;
+        }
+      }
+      std::vector<int> commit;
+      for (int l = 0; l < n; ++l) {
+        if (!pending[l]) continue;
+        const bool hl = ga[l] >= 0 || gb[l] >= 0;
+        if (hl) {
+          if (elig[l] || both[l]) {
+            const int g = ga[l] >= 0 ? ga[l] : gb[l];
+            // an absorbed end is only valid if its absorber commits: absorbers precede and are in
+            // the same group, so "below the cut" covers it
+            if (l < cut[g]) {
+              commit.push_back(l);
+              if (elig[l]) ++st->chain; else ++st->retired_internal;
+            }
+          } else {
+            // a lane that touches hot regions literally, is the first pending lane of each of
+            // those groups and owns its other end runs alone (generic code)
+            const bool lit_a = hot_of[A[l]] >= 0, lit_b = hot_of[Bv[l]] >= 0;
+            const bool eff_only = (ga[l] >= 0 && !lit_a) || (gb[l] >= 0 && !lit_b);
+            const bool own = (lit_a || owna[l]) && (lit_b || ownb[l]);
+            if ((lit_a || lit_b) && !eff_only && own) {
+              bool first = true;
+              for (int g : {lit_a ? ga[l] : -1, lit_b ? gb[l] : -1}) {
+                if (g < 0) continue;
+                for (int e = 0; e < l; ++e) {
+                  if (pending[e] && (ga[e] == g || gb[e] == g)) first = false;
+                }
+              }
+              if (first) {
+                commit.push_back(l);
+                ++st->generic;
+              }
+            }
+          }
+        } else if (owna[l] && ownb[l]) {
+          commit.push_back(l);
+          ++st->generic;
+        }
+      }
+      for (int r : hots) hot_of[r] = -1;
+      if (commit.empty()) {
+        std::fprintf(stderr, "k-hot model stuck (n=%d)\n", n);
+        std::exit(1);
+      }
+      for (int l : commit) {
+        pending[l] = 0;
+        const TraceRecord& r = rec[ed[lanes[l]]];
+        if (r.outcome >= 1 && r.outcome <= 3) {
+          const int x = uf.find(ea[lanes[l]]), y = uf.find(eb[lanes[l]]);
+          if (x != y) {
+            if (r.first_wins) uf.p[y] = x; else uf.p[x] = y;
+          }
+        }
       }
     }
   }
@@ -364,6 +584,7 @@ int main(int argc, char** argv) {
   std::vector<int> sizes;
   for (int i = 2; i < argc; ++i) sizes.push_back(std::atoi(argv[i]));
   if (sizes.empty()) sizes = {64, 128, 256, 512};
+  if (std::getenv("VS_HOT_MIN")) kHotMin = std::atoi(std::getenv("VS_HOT_MIN"));
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) return 1;
   std::vector<TraceRecord> rec;
@@ -402,8 +623,10 @@ int main(int argc, char** argv) {
     std::printf("call %d bucket %d: %zu traced edges, %ld active, %zu components\n", call,
                 rec[0].bucket, rec.size(), active, comps.size());
     for (int Bs : sizes) {
-      const bool multi = Bs < 0;   // negative size: strategy 1 (chains on every region)
-      const int B = multi ? -Bs : Bs;
+      // negative size: strategy 1 (chains on every region); size + 1000*K: strategy 2 (K hot regions)
+      const bool multi = Bs < 0;
+      const int khot = Bs >= 1000 ? Bs / 1000 : 0;
+      const int B = multi ? -Bs : Bs % 1000;
       Stats st;
       for (auto& kv : comps) {
         if (kv.second.size() <= 24) continue;
@@ -411,6 +634,7 @@ int main(int argc, char** argv) {
         st.edges += (long)kv.second.size();
         long cr = 0;
         if (multi) SimComponentMulti(rec, kv.second, remap, B, &st, &cr);
+        else if (khot) SimComponentKHot(rec, kv.second, remap, B, khot, &st, &cr);
         else SimComponent(rec, kv.second, remap, B, &st, &cr);
         if ((long)kv.second.size() > st.max_comp) {
           st.max_comp = (long)kv.second.size();
@@ -419,7 +643,7 @@ int main(int argc, char** argv) {
       }
       std::printf("  %s B=%4d: wave components %ld (edges %ld, largest %ld) batches %ld live %ld rounds %ld "
                   "(%.2f per batch, %.2f per 64 live edges) generic %ld chain %ld | largest component: %ld rounds\n",
-                  multi ? "multi " : "kernel", B, st.comps, st.edges, st.max_comp, st.batches, st.live, st.rounds,
+                  multi ? "multi " : (khot ? "k-hot " : "kernel"), khot ? khot * 1000 + B : B, st.comps, st.edges, st.max_comp, st.batches, st.live, st.rounds,
                   st.batches ? (double)st.rounds / st.batches : 0.0,
                   st.live ? (double)st.rounds * 64.0 / st.live : 0.0, st.generic, st.chain,
                   st.critical_rounds);
