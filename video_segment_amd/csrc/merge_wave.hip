@@ -448,15 +448,23 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           const bool merge_a = part_a && (A.cons >= 0 || !fin || A.sz < T.min_size);
           const bool merge_b = part_b && (B.cons >= 0 || !fin || B.sz < T.min_size);
           const bool abs_a = pending && !own_a, abs_b = pending && !own_b;   // may be absorbed
-          unsigned long long em = 0;   // chain lanes that merge
-          bool ea, eb;
+          // A lane merges into the chain when one end is effectively hot and the other end is a
+          // partner it owns (merge_x implies own_x, so that end can only be hot literally).  Hence a
+          // lane depends on at most ONE earlier lane -- the owner of its not-owned end -- and the
+          // closure is an OR propagation along those single links:
+          //   em = stat | { j : dyn_j in em }.
+          const bool cand1 = merge_b && !b_hot;   // partner b, hot side a
+          const bool cand2 = merge_a && !a_hot;   // partner a, hot side b
+          const unsigned long long stat = __ballot((cand1 && a_hot) || (cand2 && b_hot));
+          const int dyn = (cand1 && abs_a && !a_hot) ? oa : ((cand2 && abs_b && !b_hot) ? ob : -1);
+          unsigned long long em = stat;   // chain lanes that merge
           for (;;) {
-            ea = a_hot || (abs_a && ((em >> oa) & 1ull));
-            eb = b_hot || (abs_b && ((em >> ob) & 1ull));
-            const unsigned long long em2 = __ballot((ea && !eb && merge_b) || (eb && !ea && merge_a));
+            const unsigned long long em2 = stat | __ballot(dyn >= 0 && ((em >> (dyn & 63)) & 1ull));
             if (em2 == em) break;
             em = em2;
           }
+          const bool ea = a_hot || (abs_a && ((em >> oa) & 1ull));
+          const bool eb = b_hot || (abs_b && ((em >> ob) & 1ull));
           hot_lane = pending && (ea || eb);
           both = hot_lane && ea && eb;
           const bool pb_side = ea;   // the partner is the end that is not effectively hot
