@@ -32,6 +32,8 @@ struct TraceRecord {
 };
 static_assert(sizeof(TraceRecord) == 40, "record layout");
 
+static long g_cut_why[7] = {0, 0, 0, 0, 0, 0, 0};   // partner not owned, not plain, not smaller, hot w/o descriptor, two hot ends, other, no cut
+static int kPhases = 1;   // VS_TWO_PHASE=1: generic edges first, then the hot edges, in one round
 static int kHotMin = 2;   // VS_HOT_MIN: endpoints a region needs to become hot in strategy 2
 
 struct UF {
@@ -205,7 +207,9 @@ static void SimComponentKHot(const std::vector<TraceRecord>& rec, const std::vec
     failed.assign(n, 0);
     std::vector<int> A(n), Bv(n), oa(n), ob(n), ga(n), gb(n);
     std::vector<char> owna(n), ownb(n), elig(n), both(n), em(n), cross(n);
-    for (;;) {
+    for (bool batch_done = false; !batch_done;) {
+     int committed_in_round = 0;
+     for (int phase = 0; phase < kPhases && !batch_done; ++phase) {
       int npend = 0;
       std::vector<int> touched;
       for (int l = 0; l < n; ++l) {
@@ -222,9 +226,14 @@ static void SimComponentKHot(const std::vector<TraceRecord>& rec, const std::vec
           if (cnt[r]++ == 0) touched.push_back(r);
         }
       }
-      if (!npend) break;
-      ++st->rounds;
-      ++rounds_here;
+      if (!npend) {
+        batch_done = true;
+        break;
+      }
+      if (phase == 0) {
+        ++st->rounds;
+        ++rounds_here;
+      }
       // the K most contended regions of this round (>= 2 pending endpoints)
       std::vector<int> hots;
       {
@@ -312,6 +321,24 @@ static void SimComponentKHot(const std::vector<TraceRecord>& rec, const std::vec
           if (g >= 0 && !ok && l < cut[g]) cut[g] = l;
         }
       }
+      if (!hots.empty() && cut[0] < n) {   // why does the chain of the (first) hot region end?
+        const int l = cut[0];
+        const TraceRecord& r = rec[ed[lanes[l]]];
+        const bool part_is_2 = ga[l] >= 0;
+        const int psz = part_is_2 ? r.sz2 : r.sz1, hsz = part_is_2 ? r.sz1 : r.sz2;
+        const int pcons = part_is_2 ? r.cons2 : r.cons1, hcons = part_is_2 ? r.cons1 : r.cons2;
+        const int pfl = part_is_2 ? r.flags2 : r.flags1, hfl = part_is_2 ? r.flags1 : r.flags2;
+        const bool own_p = part_is_2 ? ownb[l] : owna[l];
+        int why = 5;
+        if (cross[l]) why = 4;
+        else if (!own_p) why = 0;
+        else if (pfl != 0 || !(pcons < 0 || pcons == hcons)) why = 1;
+        else if (!(psz < hsz)) why = 2;
+        else if (hfl & 2) why = 3;
+        ++g_cut_why[why];
+      } else if (!hots.empty()) {
+        ++g_cut_why[6];
+      }
       for (int l = 0; l < n; ++l) {   // failed tests cut their group
         if (!pending[l] || !elig[l]) continue;
         const int g = ga[l] >= 0 ? ga[l] : gb[l];
@@ -327,6 +354,8 @@ static void SimComponentKHot(const std::vector<TraceRecord>& rec, const std::vec
       for (int l = 0; l < n; ++l) {
         if (!pending[l]) continue;
         const bool hl = ga[l] >= 0 || gb[l] >= 0;
+        // two-phase rounds: generic (non-hot) edges first, then the hot edges on the updated state
+        if (kPhases == 2 && (phase == 0) == hl) continue;
         if (hl) {
           if (elig[l] || both[l]) {
             const int g = ga[l] >= 0 ? ga[l] : gb[l];
@@ -362,7 +391,8 @@ static void SimComponentKHot(const std::vector<TraceRecord>& rec, const std::vec
         }
       }
       for (int r : hots) hot_of[r] = -1;
-      if (commit.empty()) {
+      committed_in_round += (int)commit.size();
+      if (phase == kPhases - 1 && committed_in_round == 0) {
         std::fprintf(stderr, "k-hot model stuck (n=%d)\n", n);
         std::exit(1);
       }
@@ -376,6 +406,7 @@ static void SimComponentKHot(const std::vector<TraceRecord>& rec, const std::vec
           }
         }
       }
+     }
     }
   }
   *comp_rounds = rounds_here;
@@ -584,6 +615,7 @@ int main(int argc, char** argv) {
   std::vector<int> sizes;
   for (int i = 2; i < argc; ++i) sizes.push_back(std::atoi(argv[i]));
   if (sizes.empty()) sizes = {64, 128, 256, 512};
+  if (std::getenv("VS_TWO_PHASE")) kPhases = 2;
   if (std::getenv("VS_HOT_MIN")) kHotMin = std::atoi(std::getenv("VS_HOT_MIN"));
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) return 1;
@@ -660,6 +692,8 @@ int main(int argc, char** argv) {
     rec.push_back(r);
   }
   flush_stage();
+  std::printf("chain ends: partner not owned %ld, not plain %ld, not smaller %ld, hot without descriptor %ld, two hot ends %ld, other %ld, not cut %ld\n",
+              g_cut_why[0], g_cut_why[1], g_cut_why[2], g_cut_why[3], g_cut_why[4], g_cut_why[5], g_cut_why[6]);
   std::fclose(f);
   return 0;
 }
