@@ -33,6 +33,7 @@ struct TraceRecord {
 static_assert(sizeof(TraceRecord) == 40, "record layout");
 
 static long g_cut_why[7] = {0, 0, 0, 0, 0, 0, 0};   // partner not owned, not plain, not smaller, hot w/o descriptor, two hot ends, other, no cut
+static int kAnySize = 0;
 static int kPhases = 1;   // VS_TWO_PHASE=1: generic edges first, then the hot edges, in one round
 static int kHotMin = 2;   // VS_HOT_MIN: endpoints a region needs to become hot in strategy 2
 
@@ -248,12 +249,16 @@ static void SimComponentKHot(const std::vector<TraceRecord>& rec, const std::vec
       }
       if (kHotMin < 0) {
         // variant: the hot region is the larger end of the earliest pending edge (no counting)
+        // (K > 1: the next hot region is the larger end of the earliest pending edge that touches
+        // none of the hot regions chosen so far)
         hots.clear();
-        for (int l = 0; l < n; ++l) {
+        for (int l = 0; l < n && (int)hots.size() < K; ++l) {
           if (!pending[l]) continue;
+          bool touches = false;
+          for (int h : hots) touches = touches || A[l] == h || Bv[l] == h;
+          if (touches) continue;
           const TraceRecord& r = rec[ed[lanes[l]]];
           hots.push_back(r.sz1 >= r.sz2 ? A[l] : Bv[l]);
-          break;
         }
       }
       for (int r : touched) cnt[r] = 0;
@@ -300,8 +305,11 @@ static void SimComponentKHot(const std::vector<TraceRecord>& rec, const std::vec
           const int pcons = part_is_2 ? r.cons2 : r.cons1, hcons = part_is_2 ? r.cons1 : r.cons2;
           const int pfl = part_is_2 ? r.flags2 : r.flags1, hfl = part_is_2 ? r.flags1 : r.flags2;
           const bool own_p = part_is_2 ? ownb[l] : owna[l];
+          // VS_ANY_SIZE: a plain hot region may also be absorbed by a larger plain partner (the
+          // chain then continues on the partner's representative)
+          const bool size_ok = psz < hsz || (kAnySize && hfl == 0 && hcons < 0 && pcons < 0);
           const bool ok = own_p && !failed[l] && pfl == 0 && (pcons < 0 || pcons == hcons) &&
-                          psz < hsz && !(hfl & 2);
+                          size_ok && !(hfl & 2);
           if (!ok) continue;
           elig[l] = 1;
           const bool fin = hfl & 1;
@@ -616,6 +624,7 @@ int main(int argc, char** argv) {
   for (int i = 2; i < argc; ++i) sizes.push_back(std::atoi(argv[i]));
   if (sizes.empty()) sizes = {64, 128, 256, 512};
   if (std::getenv("VS_TWO_PHASE")) kPhases = 2;
+  if (std::getenv("VS_ANY_SIZE")) kAnySize = 1;
   if (std::getenv("VS_HOT_MIN")) kHotMin = std::atoi(std::getenv("VS_HOT_MIN"));
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) return 1;
