@@ -65,11 +65,14 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(W, H, chunk, n_frames):
+def cpu_baseline(W, H, chunk, n_frames, device):
     """Times the CPU oracle (single thread) on the first n_frames frames of the same workload
-    (one flushed chunk).  Reported baseline only."""
+    (one flushed chunk), outside the timed region, and -- since the oracle's output is there
+    anyway -- compares it byte for byte with what the HIP path produces for the same frames
+    ("parity_checked").  Reported baseline only."""
     import oracle_lib as ol
     import synth
+    import video_segment_amd as vsg
     s = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
     fl = synth.const_flow(W, H)
     frames = [synth.bench_frame(W, H, k) for k in range(n_frames)]
@@ -78,13 +81,21 @@ def cpu_baseline(W, H, chunk, n_frames):
     for k in range(n_frames):
         out += s.process_frame(frames[k], fl if k > 0 else None, flush=(k == n_frames - 1))
     dt = time.perf_counter() - t0
-    s.close()
     assert out == n_frames
+    g = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=device),
+                              has_flow=True)
+    got = 0
+    for k in range(n_frames):
+        got += g.process_frame(frames[k], fl if k > 0 else None, flush=(k == n_frames - 1))
+    parity = got == out and all(g.result_bytes(i) == s.result_bytes(i) for i in range(out))
+    parity = parity and bool((g.last_merge_stats() == s.last_merge_stats()).all())
+    g.close()
+    s.close()
     return {
         "value": n_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
         "sample": "first %d frames of the same %dx%d workload (flow, chunk %d) as one flushed "
                   "chunk, oracle/libvs_oracle.so, %.1f s" % (n_frames, W, H, chunk, dt),
-    }
+    }, parity
 
 
 def main():
@@ -92,6 +103,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves.
+        os.execvp(sys.executable, [
+            sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+            "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+            "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)]
+            + sys.argv[1:])
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -142,7 +161,15 @@ def main():
         outs = [0] * S
         pos = [0] * S
 
+        errors = []
+
         def run(si, steps, record):
+            try:
+                run_stream(si, steps, record)
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the main thread
+                errors.append(e)
+
+        def run_stream(si, steps, record):
             stream = streams[si]
             done = 0
             while done < steps:
@@ -174,13 +201,15 @@ def main():
 
         def run_all(steps, record):
             if S == 1:
-                run(0, steps, record)
+                run_stream(0, steps, record)
                 return
             th = [threading.Thread(target=run, args=(si, steps, record)) for si in range(S)]
             for t_ in th:
                 t_.start()
             for t_ in th:
                 t_.join()
+            if errors:
+                raise errors[0]
 
         run_all(Wm, False)          # warm-up: includes the first (unconstrained) chunk
         barrier()
@@ -266,7 +295,9 @@ def main():
             "merges_per_step": acc["merges"] / K,
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, H, chunk, args.cpu_frames)
+            out["cpu_baseline"], out["parity_checked"] = cpu_baseline(W, H, chunk, args.cpu_frames,
+                                                                     local_rank)
+            assert out["parity_checked"], "HIP output differs from the oracle on the bench workload"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -849,50 +849,10 @@ class DenseGraph {
     num_forced_merges_ = num_regular_merges_ = num_small_region_merges_ = 0;
     const float merge_thr = 0.05f;   // pixel_distance.h:471
     const float split_thr = 0.15f;   // pixel_distance.h:472
-    // Analysis aid (tools/sched_sim.cpp), off unless VSO_TRACE names a file: every visited edge of
-    // the buckets below VSO_TRACE_BUCKETS is appended as a TraceRecord.  It does not change what
-    // is computed.
-    const char* trace_path = std::getenv("VSO_TRACE");
-    const int trace_buckets = trace_path && std::getenv("VSO_TRACE_BUCKETS")
-                                  ? std::atoi(std::getenv("VSO_TRACE_BUCKETS")) : (trace_path ? 2 : 0);
-    FILE* trace = trace_path ? std::fopen(trace_path, "ab") : nullptr;
-    struct TraceRecord {
-      int32_t bucket, list;
-      int32_t s1, s2;        // representatives of the two ends when the bucket starts
-      int32_t sz1, sz2;      // state of the representatives when the edge is visited
-      int32_t cons1, cons2;
-      uint8_t flags1, flags2;   // 1 finalized, 2 no descriptor
-      uint8_t outcome;       // 0 internal, 1 regular, 2 small, 3 forced merge, 4 kept, 5 kept after a
-                             // failed test, 6 kept after a constraint split
-      uint8_t first_wins;    // merge: representative 1 survives
-      uint8_t inert;         // settled by the GPU filter (both finalized and large / constraints differ)
-      uint8_t pad[3];        // pad[0]: the descriptor test was made and failed
-    };
-    std::vector<std::pair<int32_t, int32_t>> start_roots;
-    std::vector<uint8_t> start_inert;
     for (int bucket_idx = 0; bucket_idx < num_buckets_; ++bucket_idx) {
       const float weight = (float)bucket_idx * inv_scale;
       BucketCensus& cs = census_[bucket_idx];
       cs = BucketCensus();
-      const bool tracing = trace && bucket_idx < trace_buckets;
-      if (tracing) {
-        start_roots.clear();
-        start_inert.clear();
-        for (size_t bl = 0; bl < bucket_lists_.size(); ++bl) {
-          for (const Edge& e : bucket_lists_[bl][bucket_idx]) {
-            const Region* a = GetRegion(e.region_1);
-            const Region* b = GetRegion(e.region_2);
-            start_roots.emplace_back(a->my_id, b->my_id);
-            const bool both_final_large = a->region_finalized && b->region_finalized &&
-                                          a->sz >= min_region_size && b->sz >= min_region_size;
-            const bool inert = a != b && ((a->constraint_id >= 0 && b->constraint_id >= 0)
-                                              ? a->constraint_id != b->constraint_id
-                                              : both_final_large);
-            start_inert.push_back(inert ? 1 : 0);
-          }
-        }
-      }
-      size_t trace_pos = 0;
       for (size_t bl = 0; bl < bucket_lists_.size(); ++bl) {
         EdgeList remaining;
         EdgeList& edges = bucket_lists_[bl][bucket_idx];
@@ -900,38 +860,6 @@ class DenseGraph {
         for (const Edge& e : edges) {
           Region* rep_1 = GetRegion(e.region_1);
           Region* rep_2 = GetRegion(e.region_2);
-          TraceRecord tr;
-          const BucketCensus before = cs;
-          if (tracing) {
-            std::memset(&tr, 0, sizeof(tr));
-            tr.bucket = bucket_idx;
-            tr.list = (int32_t)bl;
-            tr.s1 = start_roots[trace_pos].first;
-            tr.s2 = start_roots[trace_pos].second;
-            tr.inert = start_inert[trace_pos];
-            ++trace_pos;
-            tr.sz1 = rep_1->sz;
-            tr.sz2 = rep_2->sz;
-            tr.cons1 = rep_1->constraint_id;
-            tr.cons2 = rep_2->constraint_id;
-            tr.flags1 = (uint8_t)((rep_1->region_finalized ? 1 : 0) | (rep_1->virtual_no_desc ? 2 : 0));
-            tr.flags2 = (uint8_t)((rep_2->region_finalized ? 1 : 0) | (rep_2->virtual_no_desc ? 2 : 0));
-            tr.first_wins = rep_1->sz > rep_2->sz;
-          }
-          struct TraceWriter {   // writes the record when the edge has been handled
-            FILE* f; TraceRecord* r; const BucketCensus* b; const BucketCensus* c;
-            ~TraceWriter() {
-              if (!f || r->s1 == r->s2) return;   // internal when the bucket starts: dropped by the filter
-              r->outcome = c->internal != b->internal ? 0
-                           : c->regular != b->regular ? 1
-                           : c->small != b->small     ? 2
-                           : c->forced != b->forced   ? 3
-                           : c->fail != b->fail       ? 5
-                                                      : 4;
-              r->pad[0] = c->fail != b->fail;   // the descriptor test was made and failed
-              std::fwrite(r, sizeof(*r), 1, f);
-            }
-          } trace_writer{tracing ? trace : nullptr, &tr, &before, &cs};
           if (rep_1 == rep_2) {
             ++cs.internal;
             continue;
@@ -985,7 +913,6 @@ class DenseGraph {
         edges.swap(remaining);
       }
     }
-    if (trace) std::fclose(trace);
     if (force_constraints) MergeConstrainedRegions();
   }
 

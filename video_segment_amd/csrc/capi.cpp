@@ -25,6 +25,39 @@ int Guard(F&& f) {
   }
 }
 
+// The HIP current device is a per-thread setting that defaults to 0, and a handle may be driven
+// from any thread (the reference's pipeline calls OpenStreams and ProcessFrame on different
+// threads).  Every entry point therefore binds the calling thread to the handle's device for the
+// duration of the call and restores the caller's device afterwards.
+class DeviceGuard {
+ public:
+  explicit DeviceGuard(int device) {
+    if (device < 0) return;
+    if (hipGetDevice(&prev_) != hipSuccess) return;
+    if (prev_ != device) {
+      VSG_HIP(hipSetDevice(device));
+      changed_ = true;
+    }
+  }
+  ~DeviceGuard() {
+    if (changed_) (void)hipSetDevice(prev_);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+
+ private:
+  int prev_ = -1;
+  bool changed_ = false;
+};
+
+// Resolves -1 (= the caller's current device) to an ordinal at creation time.
+int ResolveDevice(int device) {
+  if (device >= 0) return device;
+  int cur = 0;
+  VSG_HIP(hipGetDevice(&cur));
+  return cur;
+}
+
 void RequireDevice(int device) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -39,11 +72,13 @@ void RequireDevice(int device) {
 }  // namespace
 
 struct vsg_stream {
+  int device = 0;
   std::unique_ptr<vsg::DenseSegmentationHip> impl;
   std::vector<int32_t> id_image;
 };
 
 struct vsg_graph {
+  int device = 0;
   int W = 0, H = 0;
   size_t wh = 0;
   hipStream_t stream = nullptr;
@@ -92,18 +127,32 @@ int vsg_stream_create(const vsg_options* o, int width, int height, vsg_stream** 
   return Guard([&] {
     VSG_REQUIRE(o && out, VSG_ERR_INVALID, "null argument");
     RequireDevice(o->device);
+    VSG_REQUIRE(width >= 2 && height >= 1 && width <= 65535 && height <= 65535, VSG_ERR_INVALID,
+                "unsupported frame size");
     std::unique_ptr<vsg_stream> s(new vsg_stream);
-    s->impl.reset(new vsg::DenseSegmentationHip(*o, width, height));
+    s->device = ResolveDevice(o->device);
+    DeviceGuard dg(s->device);
+    vsg_options opts = *o;
+    opts.device = s->device;
+    s->impl.reset(new vsg::DenseSegmentationHip(opts, width, height));
     *out = s.release();
   });
 }
 
-void vsg_stream_destroy(vsg_stream* s) { delete s; }
+void vsg_stream_destroy(vsg_stream* s) {
+  if (!s) return;
+  (void)Guard([&] {
+    DeviceGuard dg(s->device);
+    s->impl.reset();
+  });
+  delete s;
+}
 
 int vsg_stream_process_frame(vsg_stream* s, int flush, const uint8_t* bgr, size_t stride,
                              const float* flow, int has_flow_stream, int mem, int* num_results) {
   return Guard([&] {
     VSG_REQUIRE(s && num_results, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(s->device);
     *num_results = s->impl->ProcessFrame(flush != 0, bgr, stride, flow, has_flow_stream != 0, mem);
   });
 }
@@ -113,6 +162,7 @@ int vsg_stream_chunk_size(const vsg_stream* s) { return s ? s->impl->ChunkSize()
 int vsg_stream_result_bytes(vsg_stream* s, int i, const uint8_t** data, size_t* len) {
   return Guard([&] {
     VSG_REQUIRE(s && data && len, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(s->device);
     VSG_REQUIRE(i >= 0 && i < s->impl->num_results(), VSG_ERR_INVALID, "result index");
     const std::string& b = s->impl->result_bytes(i);
     *data = reinterpret_cast<const uint8_t*>(b.data());
@@ -123,6 +173,7 @@ int vsg_stream_result_bytes(vsg_stream* s, int i, const uint8_t** data, size_t* 
 int vsg_stream_result_id_image(vsg_stream* s, int i, int32_t* out) {
   return Guard([&] {
     VSG_REQUIRE(s && out, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(s->device);
     VSG_REQUIRE(i >= 0 && i < s->impl->num_results(), VSG_ERR_INVALID, "result index");
     const size_t n = (size_t)s->impl->W() * s->impl->H();
     for (size_t k = 0; k < n; ++k) out[k] = -1;
@@ -133,6 +184,7 @@ int vsg_stream_result_id_image(vsg_stream* s, int i, int32_t* out) {
 int vsg_stream_last_merge_stats(const vsg_stream* s, int64_t* st) {
   return Guard([&] {
     VSG_REQUIRE(s && st, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(s->device);
     s->impl->last_merge_stats(st);
   });
 }
@@ -140,6 +192,7 @@ int vsg_stream_last_merge_stats(const vsg_stream* s, int64_t* st) {
 int vsg_stream_last_timings(const vsg_stream* s, vsg_timings* t) {
   return Guard([&] {
     VSG_REQUIRE(s && t, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(s->device);
     *t = s->impl->last_timings();
   });
 }
@@ -147,6 +200,7 @@ int vsg_stream_last_timings(const vsg_stream* s, vsg_timings* t) {
 int vsg_stream_last_smoothed(vsg_stream* s, float* out) {
   return Guard([&] {
     VSG_REQUIRE(s && out, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(s->device);
     s->impl->CopyLastSmoothed(out);
   });
 }
@@ -155,6 +209,7 @@ int vsg_stream_export_halo(vsg_stream* s, const int32_t** virt, const int32_t** 
                            int64_t scalars[4]) {
   return Guard([&] {
     VSG_REQUIRE(s && virt && cons && scalars, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(s->device);
     s->impl->ExportHalo(virt, cons, scalars);
   });
 }
@@ -163,6 +218,7 @@ int vsg_stream_import_halo(vsg_stream* s, const int32_t* virt, const int32_t* co
                            const int64_t scalars[4]) {
   return Guard([&] {
     VSG_REQUIRE(s && virt && cons && scalars, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(s->device);
     s->impl->ImportHalo(virt, cons, mem, scalars);
   });
 }
@@ -172,8 +228,11 @@ int vsg_graph_create(int width, int height, int max_frames, int l1, int device, 
   return Guard([&] {
     VSG_REQUIRE(out, VSG_ERR_INVALID, "null argument");
     RequireDevice(device);
-    if (device >= 0) VSG_HIP(hipSetDevice(device));
+    VSG_REQUIRE(width >= 2 && height >= 1 && width <= 65535 && height <= 65535, VSG_ERR_INVALID,
+                "unsupported frame size");
     std::unique_ptr<vsg_graph> g(new vsg_graph);
+    g->device = ResolveDevice(device);
+    DeviceGuard dg(g->device);
     g->W = width;
     g->H = height;
     g->wh = (size_t)width * height;
@@ -185,7 +244,23 @@ int vsg_graph_create(int width, int height, int max_frames, int l1, int device, 
   });
 }
 
-void vsg_graph_destroy(vsg_graph* g) { delete g; }
+void vsg_graph_destroy(vsg_graph* g) {
+  if (!g) return;
+  (void)Guard([&] {
+    DeviceGuard dg(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    g->g.reset();
+    g->pre.reset();
+    g->feats.clear();
+    g->staging_bgr.release();
+    g->staging_f32.release();
+    g->staging_ids.release();
+    g->flow_dev.release();
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    g->stream = nullptr;
+  });
+  delete g;
+}
 
 static const int32_t* StageIds(vsg_graph* g, const int32_t* ids, int mem) {
   if (!ids) return nullptr;
@@ -200,6 +275,7 @@ int vsg_graph_add_frame_bgr(vsg_graph* g, const uint8_t* bgr, size_t stride, int
                             const int32_t* constraint_ids, int mem) {
   return Guard([&] {
     VSG_REQUIRE(g && bgr, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     VSG_REQUIRE(stride >= (size_t)g->W * 3, VSG_ERR_INVALID, "stride smaller than a row");
     const uint8_t* dev = bgr;
     if (mem == VSG_MEM_HOST) {
@@ -225,6 +301,7 @@ int vsg_graph_add_frame_features(vsg_graph* g, const float* feat_in, const int32
                                  int mem) {
   return Guard([&] {
     VSG_REQUIRE(g && feat_in, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     const float* src = feat_in;
     if (mem == VSG_MEM_HOST) {
       g->staging_f32.ensure(3 * g->wh);
@@ -245,6 +322,7 @@ int vsg_graph_add_frame_features(vsg_graph* g, const float* feat_in, const int32
 int vsg_graph_add_virtual_frame(vsg_graph* g, const int32_t* constraint_ids, int mem) {
   return Guard([&] {
     VSG_REQUIRE(g && constraint_ids, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     // max label: scan on the host (ids come from a SegmentationDesc, i.e. host data, or are small)
     std::vector<int32_t> host(g->wh);
     if (mem == VSG_MEM_HOST) {
@@ -265,6 +343,7 @@ int vsg_graph_add_virtual_frame(vsg_graph* g, const int32_t* constraint_ids, int
 int vsg_graph_add_temporal(vsg_graph* g, const float* flow, int is_virtual, int mem) {
   return Guard([&] {
     VSG_REQUIRE(g, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     const int nf = g->g->num_frames();
     VSG_REQUIRE(nf >= 2, VSG_ERR_STATE, "temporal edges need two slices");
     const float* fdev = nullptr;
@@ -295,6 +374,7 @@ int vsg_graph_add_temporal(vsg_graph* g, const float* flow, int is_virtual, int 
 int vsg_graph_finish_building(vsg_graph* g) {
   return Guard([&] {
     VSG_REQUIRE(g, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     g->g->FinishBuilding();
   });
 }
@@ -302,6 +382,7 @@ int vsg_graph_finish_building(vsg_graph* g) {
 int vsg_graph_segment(vsg_graph* g, int min_region_size, int force_constraints) {
   return Guard([&] {
     VSG_REQUIRE(g, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     g->g->Segment(min_region_size, force_constraints != 0);
   });
 }
@@ -310,6 +391,7 @@ int vsg_graph_obtain_results(vsg_graph* g, int use_flows, int enforce_n4,
                              int enforce_spatial_connectedness) {
   return Guard([&] {
     VSG_REQUIRE(g, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     std::vector<const float*> flows;
     if (use_flows) {
       for (auto& f : g->flows_host) flows.push_back(f ? f->data() : nullptr);
@@ -333,6 +415,7 @@ int64_t vsg_graph_num_neighbor_links(const vsg_graph* g) {
 int vsg_graph_region_sizes(const vsg_graph* g, int32_t* sizes, int32_t* constrained_ids) {
   return Guard([&] {
     VSG_REQUIRE(g && sizes && constrained_ids, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     const auto& regs = g->g->regions();
     for (size_t i = 0; i < regs.size(); ++i) {
       sizes[i] = regs[i].size;
@@ -344,6 +427,7 @@ int vsg_graph_region_sizes(const vsg_graph* g, int32_t* sizes, int32_t* constrai
 int vsg_graph_index_image(const vsg_graph* g, int t, int32_t* out) {
   return Guard([&] {
     VSG_REQUIRE(g && out, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     for (size_t k = 0; k < g->wh; ++k) out[k] = -1;
     for (const auto& r : g->g->regions()) {
       if (!r.has_raster) continue;
@@ -360,6 +444,7 @@ int vsg_graph_index_image(const vsg_graph* g, int t, int32_t* out) {
 int vsg_graph_smoothed(vsg_graph* g, int t, float* out) {
   return Guard([&] {
     VSG_REQUIRE(g && out, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     VSG_REQUIRE(t >= 0 && t < (int)g->feats.size() && g->feats[t], VSG_ERR_INVALID, "slice index");
     vsg::DevBuf<float> tmp(3 * g->wh);
     vsg::LaunchPlanarToInterleaved(g->feats[t]->get(), g->wh, tmp.get(), g->stream);
@@ -372,6 +457,7 @@ int vsg_graph_smoothed(vsg_graph* g, int t, float* out) {
 int vsg_graph_spatial_buckets(vsg_graph* g, int t, uint16_t* out) {
   return Guard([&] {
     VSG_REQUIRE(g && out, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     g->g->CopySpatialBuckets(t, out);
   });
 }
@@ -379,6 +465,7 @@ int vsg_graph_spatial_buckets(vsg_graph* g, int t, uint16_t* out) {
 int vsg_graph_temporal_buckets(vsg_graph* g, int t, uint16_t* out, int32_t* prev_idx) {
   return Guard([&] {
     VSG_REQUIRE(g && out && prev_idx, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     g->g->CopyTemporalBuckets(t, out, prev_idx);
   });
 }
@@ -386,6 +473,7 @@ int vsg_graph_temporal_buckets(vsg_graph* g, int t, uint16_t* out, int32_t* prev
 int vsg_graph_node_roots(vsg_graph* g, int32_t* out) {
   return Guard([&] {
     VSG_REQUIRE(g && out, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     g->g->CopyNodeRoots(out);
   });
 }
@@ -393,6 +481,7 @@ int vsg_graph_node_roots(vsg_graph* g, int32_t* out) {
 int vsg_graph_merge_stats(const vsg_graph* g, int64_t* s3) {
   return Guard([&] {
     VSG_REQUIRE(g && s3, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     const auto& t = g->g->timings();
     s3[0] = t.merges[0];
     s3[1] = t.merges[1];
@@ -403,6 +492,7 @@ int vsg_graph_merge_stats(const vsg_graph* g, int64_t* s3) {
 int vsg_graph_timings(const vsg_graph* g, vsg_timings* t) {
   return Guard([&] {
     VSG_REQUIRE(g && t, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
     *t = g->timings;
     const auto& gt = g->g->timings();
     t->merge_ms = gt.merge_ms;

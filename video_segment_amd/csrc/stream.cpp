@@ -111,7 +111,7 @@ DenseSegmentationHip::DenseSegmentationHip(const vsg_options& o, int W, int H)
   VSG_REQUIRE(overlap_frames_ == 2, -1, "chunk_overlap_ratio too small: the reference needs a 2 frame overlap");
   VSG_REQUIRE(options_.num_constraint_frames >= 1, -1, "num_constraint_frames >= 1");
   constraint_frames_ = std::min(options_.num_constraint_frames, overlap_frames_ - 1);
-  if (options_.device >= 0) VSG_HIP(hipSetDevice(options_.device));
+  // The caller (capi.cpp) has bound this thread to the handle's device.
   VSG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   VSG_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
   VSG_HIP(hipEventCreateWithFlags(&flow_ready_, hipEventDisableTiming));
@@ -162,6 +162,11 @@ int DenseSegmentationHip::ProcessFrame(bool flush, const uint8_t* bgr, size_t st
     accum_.preprocess_ms += pre_->last_ms();
     accum_.preprocess_launches += 1;
 
+    // "Flow always has to be passed or be absent" (dense_segmentation.cpp:140): the unit either
+    // has a flow stream for the whole video or it has none.
+    VSG_REQUIRE(frames_fed_ == 0 || has_flow_stream == flow_stream_seen_, -1,
+                "has_flow_stream changed in the middle of a stream");
+    ++frames_fed_;
     if (has_flow_stream) {
       flow_stream_seen_ = true;
       if (input_frames_ == 0 && !pending_import_) {

@@ -106,6 +106,7 @@ class DenseSegmentationHip {
   std::vector<DevPlane> flow_dev_buffer_;     // W*H*2 f32, null = empty flow
   std::vector<HostFlow> flow_host_buffer_;
   bool flow_stream_seen_ = false;
+  int64_t frames_fed_ = 0;   // frames handed to this handle (has_flow_stream must not change)
 
   DevBuf<uint8_t> staging_bgr_;
   DevBuf<float> staging_flow_;
