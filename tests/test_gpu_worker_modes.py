@@ -35,11 +35,16 @@ def test_chain_self_check_is_silent(vsg, monkeypatch, capfd):
     assert "self check" not in err, err
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_four_wavefront_worker(vsg, monkeypatch, mode):
-    """k_merge_block (256-edge batches on four wavefronts; opt-in): always, and
-    chosen per bucket by the average component size."""
-    monkeypatch.setenv("VSG_BLOCK_WORKER", mode)
+@pytest.mark.parametrize("env", [{"VSG_RLE": "0"}, {"VSG_WINDOWS": "1"},
+                                 {"VSG_WINDOWS": "5", "VSG_WINDOW_MIN": "1"},
+                                 {"VSG_WINDOWS": "3", "VSG_WINDOW_MIN": "1", "VSG_RLE": "0"},
+                                 {"VSG_WINDOWS": "4", "VSG_WINDOW_MIN": "1", "VSG_FORCE_ROLLBACK": "1"}])
+def test_stage_decomposition_variants(vsg, monkeypatch, env):
+    """The stage driver's two decompositions are exact whatever their parameters: a bucket split
+    into consecutive rank windows (each its own filter -> components -> replay), and runs of equal
+    root pairs replayed through their leader only (with the rollback of a constrained split)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     for (W, H, N, kind, chunk) in CASES + [(256, 144, 44, "bench", 20)]:
         run_streams(vsg, W, H, N, kind, True, chunk)
     import sys

@@ -57,7 +57,7 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   keys_sorted_tmp_.alloc(9 * wh_);
   vals_tmp_.alloc(9 * wh_);
   scalars_.alloc(16);
-  stats_.alloc(48);
+  stats_.alloc(64);
   size_t temp = SortPairsU16TempBytes((int)(9 * wh_));
   temp = std::max(temp, ScanTempBytes((int)N));
   cub_temp_.alloc(temp);
@@ -155,6 +155,10 @@ void DenseGraphHip::EnsureScratch(size_t n) {
   seg_cnt_.alloc(n);
   seg_off_.alloc(n);
   e_ti_.alloc(n);
+  lead_pos_.alloc(n);
+  l_ra_.alloc(n);
+  l_rb_.alloc(n);
+  l_gpos_.alloc(n);
   bk_ds_.alloc(2 * n);
   bk_cons_.alloc(2 * n);
   bk_flags_.alloc(2 * n);
@@ -204,7 +208,7 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   LaunchBuildBucketTable(list_desc_dev_.get(), L, bucket_base_dev_.get(), stream_);
   bucket_base_host_.resize((size_t)(kNumBuckets + 1) * (L + 1));
   D2H(bucket_base_host_.data(), bucket_base_dev_.get(), bucket_base_host_.size(), stream_);
-  VSG_HIP(hipMemsetAsync(stats_.get(), 0, 48 * sizeof(unsigned long long), stream_));
+  VSG_HIP(hipMemsetAsync(stats_.get(), 0, 64 * sizeof(unsigned long long), stream_));
   LaunchInitIdentity(cc_.get(), N, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
 
@@ -240,7 +244,11 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   S.bk_flags = bk_flags_.get();
   S.force_rollback = getenv("VSG_FORCE_ROLLBACK") ? 1 : 0;
   S.wave_v1 = getenv("VSG_WAVE_V1") ? 1 : 0;
-  S.block_worker = getenv("VSG_BLOCK_WORKER") ? atoi(getenv("VSG_BLOCK_WORKER")) : 0;
+  S.lead_pos = lead_pos_.get();
+  S.l_ra = l_ra_.get();
+  S.l_rb = l_rb_.get();
+  S.l_gpos = l_gpos_.get();
+  S.use_rle = getenv("VSG_RLE") ? atoi(getenv("VSG_RLE")) : 1;
   S.wave_dbg = getenv("VSG_WAVE_DBG") ? atoi(getenv("VSG_WAVE_DBG")) : 0;
   S.wave_debug = (S.wave_dbg != 0 || getenv("VSG_DEBUG_STAGES") || getenv("VSG_DEBUG_STATS")) ? 1 : 0;
   optimistic_stages_ = 0;
@@ -286,46 +294,64 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   int inert_mode = has_constraints_ ? 2 : 1;
   if (const char* e = getenv("VSG_INERT_MODE")) inert_mode = std::min(inert_mode, atoi(e));
   const bool debug_stages = getenv("VSG_DEBUG_STAGES") != nullptr;
+  const int num_windows = getenv("VSG_WINDOWS") ? std::max(1, atoi(getenv("VSG_WINDOWS"))) : 12;
+  const int window_bushy = getenv("VSG_WINDOW_BUSHY") ? atoi(getenv("VSG_WINDOW_BUSHY")) : 64;
+  const int window_min_edges = getenv("VSG_WINDOW_MIN") ? atoi(getenv("VSG_WINDOW_MIN")) : (4 << 20);
+  // A bucket is replayed as consecutive *rank windows* (each a full stage: filter -> components ->
+  // workers; exact for any split, see RunBucketStage).  While the regions of a bucket are still
+  // many small clusters growing side by side, the edges of one window fall into many small
+  // components that the whole GPU replays at once, where one stage over the whole bucket would
+  // chain them into a few huge components replayed by one wavefront each.  Once one region
+  // dominates (its component is a chain whatever the split) windows only add overhead.  The first
+  // window tells which case it is: average component size below `bushy` -> keep splitting.
   for (int b = 0; b < kNumBuckets; ++b) {
     const int n_b = bucket_base_host_[(size_t)b * (L + 1) + L];
     if (n_b == 0) continue;
-    unsigned long long s0[48] = {0}, s1[48] = {0};
-    double ts = 0;
-    size_t ev0 = 0;
-    if (debug_stages) {
-      VSG_HIP(hipMemsetAsync(stats_.get() + 16, 0, 2 * sizeof(unsigned long long), stream_));
-      D2H(s0, stats_.get(), 48, stream_);
-      VSG_HIP(hipStreamSynchronize(stream_));
-      ts = NowMs();
-      ev0 = ev_wave_.size();
-    }
-    RunBucketStage(b, n_b, list_desc_dev_.get(), bucket_base_dev_.get(),
-                   list_slot_base_dev_.get(), kept_all_.get(), nodes(), P, inert_mode, S,
-                   stream_);
-    if (debug_stages) {
-      D2H(s1, stats_.get(), 48, stream_);
-      VSG_HIP(hipStreamSynchronize(stream_));
-      const double te = NowMs();
-      float wave_ms = 0;
-      for (size_t k = ev0; k < ev_wave_.size(); ++k) {
-        float ms = 0;
-        VSG_HIP(hipEventElapsedTime(&ms, ev_pool_[ev_wave_[k].first], ev_pool_[ev_wave_[k].second]));
-        wave_ms += ms;
+    int windows = n_b >= window_min_edges ? num_windows : 1;
+    for (int w = 0; w < windows; ++w) {
+      const int j0 = (int)((int64_t)n_b * w / windows);
+      int j1 = (int)((int64_t)n_b * (w + 1) / windows);
+      const bool probe = windows > 1 && w == 0 && window_bushy > 0;
+      unsigned long long s0[64] = {0}, s1[64] = {0};
+      double ts = 0;
+      size_t ev0 = 0;
+      if (debug_stages) {
+        VSG_HIP(hipMemsetAsync(stats_.get() + 16, 0, 2 * sizeof(unsigned long long), stream_));
+        D2H(s0, stats_.get(), 64, stream_);
+        VSG_HIP(hipStreamSynchronize(stream_));
+        ts = NowMs();
+        ev0 = ev_wave_.size();
       }
-      if (te - ts > 1.0) {
-        std::fprintf(stderr, "[vsg] stage b=%d n_b=%d wall %.2f ms wave %.2f ms | wave edges %llu batches %llu "
-                     "rounds %llu nwin %llu (solo %llu) chain %llu cuts %llu | max_seg %llu slowest %.2f Mcyc | "
-                     "cyc load %.1f M loop %.1f M wait %.1f M | producer work %.1f M wait %.1f M | taken %llu live %llu | "
-                     "round phases (Mcyc): reserve+load %.0f closure %.0f masks %.0f generic %.0f chain %.0f | per round sums: pending %llu hot %llu "
-                     "blocked %llu chain-rounds %llu generic-rounds %llu waiting-nonhot %llu\n",
-                     b, n_b, te - ts, wave_ms, s1[3] - s0[3], s1[7] - s0[7], s1[5] - s0[5],
-                     s1[4] - s0[4], s1[6] - s0[6], s1[20] - s0[20], s1[21] - s0[21], s1[17],
-                     s1[16] / 1e6, (s1[18] - s0[18]) / 1e6, (s1[19] - s0[19]) / 1e6,
-                     (s1[26] - s0[26]) / 1e6, (s1[27] - s0[27]) / 1e6, (s1[28] - s0[28]) / 1e6,
-                     s1[29] - s0[29], s1[30] - s0[30], (s1[32] - s0[32]) / 1e6, (s1[33] - s0[33]) / 1e6,
-                     (s1[34] - s0[34]) / 1e6, (s1[35] - s0[35]) / 1e6, (s1[36] - s0[36]) / 1e6,
-                     s1[38] - s0[38], s1[39] - s0[39], s1[40] - s0[40], s1[41] - s0[41], s1[42] - s0[42],
-                     s1[43] - s0[43]);
+      StageInfo info;
+      RunBucketStage(b, j0, j1 - j0, list_desc_dev_.get(), bucket_base_dev_.get(),
+                     list_slot_base_dev_.get(), kept_all_.get(), nodes(), P, inert_mode, S, stream_,
+                     (probe || debug_stages) ? &info : nullptr);
+      if (debug_stages) {
+        D2H(s1, stats_.get(), 64, stream_);
+        VSG_HIP(hipStreamSynchronize(stream_));
+        const double te = NowMs();
+        float wave_ms = 0;
+        for (size_t k = ev0; k < ev_wave_.size(); ++k) {
+          float ms = 0;
+          VSG_HIP(hipEventElapsedTime(&ms, ev_pool_[ev_wave_[k].first], ev_pool_[ev_wave_[k].second]));
+          wave_ms += ms;
+        }
+        if (te - ts > 1.0) {
+          std::fprintf(stderr, "[vsg] stage b=%d w=%d/%d n=%d wall %.2f ms workers %.2f ms | replayed %d components %d | "
+                       "wave edges %llu batches %llu rounds %llu nwin %llu chain %llu | max_seg %llu slowest %.2f Mcyc | "
+                       "cyc load %.0f M loop %.0f M wait %.0f M\n",
+                       b, w, windows, j1 - j0, te - ts, wave_ms, info.replayed, info.components,
+                       s1[3] - s0[3], s1[7] - s0[7], s1[5] - s0[5], s1[4] - s0[4], s1[20] - s0[20],
+                       s1[17], s1[16] / 1e6, (s1[18] - s0[18]) / 1e6, (s1[19] - s0[19]) / 1e6,
+                       (s1[26] - s0[26]) / 1e6);
+        }
+      }
+      if (probe && (int64_t)info.replayed >= (int64_t)window_bushy * std::max(info.components, 1)) {
+        // few, large components already: the rest of the bucket in one stage
+        RunBucketStage(b, j1, n_b - j1, list_desc_dev_.get(), bucket_base_dev_.get(),
+                       list_slot_base_dev_.get(), kept_all_.get(), nodes(), P, inert_mode, S,
+                       stream_);
+        break;
       }
     }
   }
@@ -342,8 +368,8 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
     std::fprintf(stderr, "[vsg] segment: buckets %.1f ms, merge-constrained %.1f ms\n",
                  t_buckets - t0, t_mc - t_buckets);
   }
-  unsigned long long st[24] = {0};
-  D2H(st, stats_.get(), 24, stream_);
+  unsigned long long st[48] = {0};
+  D2H(st, stats_.get(), 48, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
   if (st[23] != 0) std::fprintf(stderr, "[vsg] chain self check: %llu mismatches\n", st[23]);
   if (st[22] != 0) throw Error(-4 /* VSG_ERR_INTERNAL */, "merge worker: a batch did not converge");

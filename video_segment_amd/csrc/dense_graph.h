@@ -112,7 +112,8 @@ class DenseGraphHip {
   DevBuf<int32_t> first_label_scratch_;
   // merge scratch
   DevBuf<int32_t> e_ra_, e_rb_, e_active_, e_apos_, a_ra_, a_rb_, seg_cnt_, seg_off_;
-  DevBuf<uint32_t> e_gpos_, a_gpos_, a_comp_, a_idx_, s_comp_, s_idx_, seg_key_;
+  DevBuf<int32_t> lead_pos_, l_ra_, l_rb_;
+  DevBuf<uint32_t> e_gpos_, a_gpos_, a_comp_, a_idx_, s_comp_, s_idx_, seg_key_, l_gpos_;
   DevBuf<uint8_t> e_ti_, bk_flags_;
   DevBuf<float4> bk_ds_;
   DevBuf<int32_t> bk_cons_;

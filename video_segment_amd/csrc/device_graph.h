@@ -97,7 +97,7 @@ void UniqueU64(void* temp, size_t temp_bytes, const unsigned long long* in,
                unsigned long long* out,
                int32_t* num_out, int n, hipStream_t s);
 
-// ---- merge_stage.hip (workers: merge_wave.hip, merge_block.hip, merge_wave_v1.hip) ----------------------------------------------------------------
+// ---- merge_stage.hip (workers: merge_wave.hip, merge_wave_v1.hip) ----------------------------------------------------------------
 struct MergeScratch {
   // sized for the largest bucket (n_max edges)
   int32_t* e_ra;         // root of node a at filter time (per bucket edge)
@@ -115,14 +115,18 @@ struct MergeScratch {
   uint32_t* seg_key;     // run-length encoding of s_comp
   int32_t* seg_cnt;
   int32_t* seg_off;
-  int32_t* num_active;   // device scalars: [0] num_active [1] num_segs [2] num_ti [3] violation
+  int32_t* num_active;   // device scalars: [0] num_active [1] num_segs [2] num_ti [3] violation [5] num_leaders
   int32_t* num_segs;     // = num_active + 1
   uint8_t* e_ti;         // per bucket edge: tentatively settled by the filter
   float4* bk_ds;         // undo buffers of an optimistic stage (2 entries per active edge)
   int32_t* bk_cons;
   uint8_t* bk_flags;
   int force_rollback;    // test hook: treat every optimistic stage as violated
-  int block_worker;      // four-wavefront worker (k_merge_block): 0 never (default), 1 always, 2 per bucket by average component size
+  int32_t* lead_pos;     // exclusive scan of the run-leader flags (per active edge)
+  int32_t* l_ra;         // run leaders: what the workers replay when use_rle is set
+  int32_t* l_rb;
+  uint32_t* l_gpos;
+  int use_rle;           // replay one edge per run of equal root pairs (default on)
   int wave_v1;           // debug hook: use the sequential wave worker (k_merge_wave_v1)
   int wave_debug;        // use the instrumented build of the wave worker (counters, self checks)
   int wave_dbg;          // debug hook (bit mask): 1 no chain, 4 no hot region, 8 one generic lane per round,
@@ -145,10 +149,17 @@ struct MergeScratch {
 void LaunchBuildBucketTable(const ListDesc* lists, int num_lists, int32_t* bucket_base,
                             hipStream_t s);
 void LaunchInitIdentity(int32_t* a, size_t n, hipStream_t s);
-// Runs one bucket stage (filter -> components -> exact workers).  n_b = edges in the bucket.
-void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* bucket_base,
+// Runs one stage (filter -> components -> exact workers) on the edges [j0, j0 + n_b) of the
+// bucket's edge sequence (list order, then position).  Any split of a bucket into consecutive
+// windows run one after the other is equivalent to one stage over the whole bucket.
+struct StageInfo {
+  int replayed = 0;     // edges handed to the workers (run leaders)
+  int components = 0;   // independent components they fell into
+};
+void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const int32_t* bucket_base,
                     const uint32_t* list_slot_base, uint8_t* kept_all, NodeArrays nodes,
-                    const MergeParams& P, int inert_mode, MergeScratch& S, hipStream_t s);
+                    const MergeParams& P, int inert_mode, MergeScratch& S, hipStream_t s,
+                    StageInfo* info = nullptr);
 // Marks every edge of bucket 2048 (virtual edges) as kept.
 void LaunchKeepVirtualBucket(const ListDesc* lists, int num_lists, hipStream_t s);
 

@@ -1,5 +1,5 @@
 // merge_common.h -- device helpers shared by the merge kernels (merge_stage.hip and the workers
-// merge_wave_v1.hip / merge_wave.hip / merge_block.hip): union-find, the exact edge semantics on
+// merge_wave_v1.hip / merge_wave.hip): union-find, the exact edge semantics on
 // plain values, wave-level primitives, and the launchers of the workers.
 #ifndef VSG_MERGE_COMMON_H_
 #define VSG_MERGE_COMMON_H_
@@ -147,11 +147,14 @@ __device__ __forceinline__ int MergeStates(RState& s1, RState& s2) {
 }
 
 // One edge of SegmentGraph (segmentation_graph.h:374-440).  s1/s2 are updated in place (flags,
-// constraints, merged state).  stat: 0 none, 1 forced, 2 regular, 3 small.
+// constraints, merged state).  stat: 0 none, 1 forced, 2 regular, 3 small, 4 constrained split
+// (the edge is kept and at least one constraint is dropped).
 struct StageThr {
   float pass_s;    // regular test passes  <=> s <= pass_s
   float split_s;   // constrained split    <=> s >  split_s
   int min_size;
+  int rle;         // the stage replays run leaders only (see k_mark_leaders): a constrained split
+                   // invalidates the run's followers and has to be reported as a violation
 };
 
 __device__ __forceinline__ int DecideEdge(RState& s1, RState& s2, const StageThr& T, int& stat) {
@@ -181,6 +184,7 @@ __device__ __forceinline__ int DecideEdge(RState& s1, RState& s2, const StageThr
         s1.cons = -1;
         s2.cons = -1;
       }
+      stat = 4;
       return kOutKeep;
     }
     stat = 1;
@@ -238,6 +242,16 @@ __device__ __forceinline__ bool SameState(const RState& a, const RState& b) {
   return a.sz == b.sz && a.cons == b.cons && a.flags == b.flags;   // descriptor only changes with sz
 }
 
+// Whole-wave shift by one lane (DPP wave_shr:1, gfx9): lane i receives lane i-1; lane 0 receives
+// zero / `first`.
+__device__ __forceinline__ float DppWaveShr1Zero(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float DppWaveShr1Old(float v, float first) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+
 // Wave-wide inclusive prefix sum / maximum with DPP row shifts and row broadcasts (no LDS round
 // trips).  Lanes without a source keep the identity 0 (`old` operand, bound_ctrl off).
 template <int kCtrl, int kRowMask, int kBankMask>
@@ -289,8 +303,6 @@ struct WorkerArgs {
 void LaunchMergeWaveV1(int grid, const WorkerArgs& a, hipStream_t s);
 // Round-based replay by one consumer wavefront + one reader wavefront (the default).
 void LaunchMergeWave(int grid, const WorkerArgs& a, bool instrumented, int dbg_flags, hipStream_t s);
-// Round-based replay of 256-edge batches by four wavefronts (opt-in, VSG_BLOCK_WORKER).
-void LaunchMergeBlock(int grid, const WorkerArgs& a, int dbg_flags, hipStream_t s);
 
 }  // namespace vsg
 

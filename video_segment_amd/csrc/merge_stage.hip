@@ -20,7 +20,7 @@
 //
 // This is memory-latency / dependency bound integer + scalar float work: no MFMA, no LDS tiling;
 // what matters is coalesced streaming in the filter and keeping the serial chains in registers.
-// The workers of the large components live in merge_wave.hip (default), merge_block.hip (opt-in)
+// The workers of the large components live in merge_wave.hip (default)
 // and merge_wave_v1.hip (edge-by-edge reference); shared device helpers in merge_common.h.
 #include "merge_common.h"
 
@@ -71,7 +71,7 @@ void LaunchInitIdentity(int32_t* a, size_t n, hipStream_t s) {
 //   (kFlagTentative in the region flags, which travel with the state into the workers); a worker
 //   that changes the constraint of a marked region raises the stage's violation flag and the host
 //   rolls the stage back and replays it with inert_mode 0 (see RunBucketStage).
-__global__ __launch_bounds__(256) void k_filter(int bucket, int n_b,
+__global__ __launch_bounds__(256) void k_filter(int bucket, int j0, int n_b,
                                                  const ListDesc* __restrict__ lists,
                                                  const int32_t* __restrict__ base_row,
                                                  const uint32_t* __restrict__ list_slot_base,
@@ -84,12 +84,13 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int n_b,
                                                  int32_t* __restrict__ e_active,
                                                  uint8_t* __restrict__ e_ti,
                                                  int32_t* __restrict__ num_ti) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.x * 256 + threadIdx.x;   // index inside the stage's window
   int ti = 0;
   if (j < n_b) {
-    const int l = LocateList(base_row, P.num_lists, j);
+    const int jb = j0 + j;                         // index inside the bucket
+    const int l = LocateList(base_row, P.num_lists, jb);
     const ListDesc L = lists[l];
-    const int pos = L.offsets[bucket] + (j - base_row[l]);
+    const int pos = L.offsets[bucket] + (jb - base_row[l]);
     int a, b;
     DecodeEdge(L, L.slots[pos], P.W, a, b);
     const int ra = FindCompress(nodes.parent, a);
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
                                                : TentativeViolated(o1, o2, s2, s2);
           if (v) *violation = 1;
         }
+        if (stat == 4 && T.rle) *violation = 1;
         n_forced += (stat == 1);
         n_regular += (stat == 2);
         n_small += (stat == 3);
@@ -328,7 +330,67 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// Host driver of one bucket stage.
+// Runs of equal root pairs.
+// ------------------------------------------------------------------------------------------
+// Consecutive active edges (bucket order) with the same pair of roots are a *run*: the nine
+// temporal edges of a pixel that hang on the same two regions, the edges along the common
+// boundary of two regions.  They are consecutive in their component's sequence as well, so once
+// the first edge of the run (the leader) has been replayed, the followers see exactly the state it
+// left behind and repeat its outcome without changing anything:
+//   leader internal or merged  -> followers internal;
+//   leader kept (Case U: a finalized end and both ends large; Case D: different constraints)
+//                              -> followers kept, same state.
+// The one exception is a leader that is kept by a *constrained split* (Case S with d > split
+// threshold): it drops a constraint, and its followers would be decided by Case U.  Such a stage
+// is reported through the violation flag and replayed edge by edge (rollback, like a violated
+// optimistic stage).  Workers therefore replay leaders only; k_resolve_followers copies the kept
+// marks afterwards.
+__global__ __launch_bounds__(256) void k_mark_leaders(int n, const int32_t* __restrict__ a_ra,
+                                                       const int32_t* __restrict__ a_rb,
+                                                       int32_t* __restrict__ lead) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  int l = 1;
+  if (p > 0) {
+    const int ra = a_ra[p], rb = a_rb[p], qa = a_ra[p - 1], qb = a_rb[p - 1];
+    l = !((ra == qa && rb == qb) || (ra == qb && rb == qa));
+  }
+  lead[p] = l;
+}
+
+__global__ __launch_bounds__(256) void k_compact_leaders(int n, const int32_t* __restrict__ lead,
+                                                          const int32_t* __restrict__ lpos,
+                                                          const int32_t* __restrict__ a_ra,
+                                                          const int32_t* __restrict__ a_rb,
+                                                          const uint32_t* __restrict__ a_gpos,
+                                                          int32_t* __restrict__ l_ra,
+                                                          int32_t* __restrict__ l_rb,
+                                                          uint32_t* __restrict__ l_gpos,
+                                                          int32_t* __restrict__ num_leaders) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  if (lead[p]) {
+    const int q = lpos[p];
+    l_ra[q] = a_ra[p];
+    l_rb[q] = a_rb[p];
+    l_gpos[q] = a_gpos[p];
+  }
+  if (p == n - 1) *num_leaders = lpos[p] + lead[p];
+}
+
+__global__ __launch_bounds__(256) void k_resolve_followers(int n, const int32_t* __restrict__ lead,
+                                                            const int32_t* __restrict__ lpos,
+                                                            const uint32_t* __restrict__ a_gpos,
+                                                            const uint32_t* __restrict__ l_gpos,
+                                                            uint8_t* __restrict__ kept_all) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n || lead[p]) return;
+  // exclusive scan of the leader flags: lpos[p] - 1 is the run's leader
+  if (kept_all[l_gpos[lpos[p] - 1]]) kept_all[a_gpos[p]] = 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host driver of one stage.
 // ------------------------------------------------------------------------------------------
 static inline unsigned Blocks(int n) { return (unsigned)((n + 255) / 256); }
 
@@ -342,17 +404,20 @@ static int NextEvent(MergeScratch& S) {
   return (*S.ev_used)++;
 }
 
-void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* bucket_base,
+void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const int32_t* bucket_base,
                     const uint32_t* list_slot_base, uint8_t* kept_all, NodeArrays nodes,
-                    const MergeParams& P, int inert_mode, MergeScratch& S, hipStream_t s) {
+                    const MergeParams& P, int inert_mode, MergeScratch& S, hipStream_t s,
+                    StageInfo* info) {
+  if (info) *info = StageInfo();
   if (n_b <= 0) return;
   const int32_t* base_row = bucket_base + (size_t)bucket * (P.num_lists + 1);
   int32_t* d_num_ti = S.num_active + 2;
   int32_t* d_violation = S.num_active + 3;
+  int32_t* d_num_leaders = S.num_active + 5;
   VSG_HIP(hipMemsetAsync(d_num_ti, 0, 2 * sizeof(int32_t), s));
   const int ef0 = NextEvent(S);
   if (ef0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ef0], s));
-  hipLaunchKernelGGL(k_filter, dim3(Blocks(n_b)), dim3(256), 0, s, bucket, n_b, lists, base_row,
+  hipLaunchKernelGGL(k_filter, dim3(Blocks(n_b)), dim3(256), 0, s, bucket, j0, n_b, lists, base_row,
                      list_slot_base, kept_all, nodes, P, inert_mode, S.cc, S.e_ra, S.e_rb, S.e_gpos,
                      S.e_active, S.e_ti, d_num_ti);
   const int ef1 = NextEvent(S);
@@ -380,20 +445,41 @@ void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* b
     return;
   }
 
-  hipLaunchKernelGGL(k_component_ids, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra,
-                     S.cc, S.a_comp, S.a_idx);
-  SortPairsU32(S.cub_temp, S.cub_temp_bytes, S.a_comp, S.s_comp, S.a_idx, S.s_idx, n_active, 32,
-               s);
-  RunLengthEncodeU32(S.cub_temp, S.cub_temp_bytes, S.s_comp, S.seg_key, S.seg_cnt, S.num_segs,
-                     n_active, s);
-  // Segment offsets: exclusive scan over n_active counts (only the first num_segs are defined;
-  // the prefix of an exclusive scan never depends on later elements).
-  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, S.seg_cnt, S.seg_off, n_active, s);
+  // Run leaders (inert_mode 0 is the conservative replay of a violated stage: every edge).
+  // In a graph with constraints a run-compressed stage has to stay undoable (constrained split).
+  const bool rle = S.use_rle && inert_mode != 0 && n_active >= 64;
+  const int32_t* w_ra = S.a_ra;     // what the workers replay
+  const int32_t* w_rb = S.a_rb;
+  const uint32_t* w_gpos = S.a_gpos;
+  int n_work = n_active;
+  int32_t* lead = S.e_active;       // free after the compaction
+  if (rle) {
+    hipLaunchKernelGGL(k_mark_leaders, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra,
+                       S.a_rb, lead);
+    ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, lead, S.lead_pos, n_active, s);
+    hipLaunchKernelGGL(k_compact_leaders, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, lead,
+                       S.lead_pos, S.a_ra, S.a_rb, S.a_gpos, S.l_ra, S.l_rb, S.l_gpos,
+                       d_num_leaders);
+    VSG_HIP(hipMemcpyAsync(&n_work, d_num_leaders, sizeof(int), hipMemcpyDeviceToHost, s));
+    VSG_HIP(hipStreamSynchronize(s));
+    w_ra = S.l_ra;
+    w_rb = S.l_rb;
+    w_gpos = S.l_gpos;
+  }
 
-  const bool optimistic = (inert_mode == 2) && n_ti > 0;
+  hipLaunchKernelGGL(k_component_ids, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, S.cc,
+                     S.a_comp, S.a_idx);
+  SortPairsU32(S.cub_temp, S.cub_temp_bytes, S.a_comp, S.s_comp, S.a_idx, S.s_idx, n_work, 32, s);
+  RunLengthEncodeU32(S.cub_temp, S.cub_temp_bytes, S.s_comp, S.seg_key, S.seg_cnt, S.num_segs,
+                     n_work, s);
+  // Segment offsets: exclusive scan over n_work counts (only the first num_segs are defined;
+  // the prefix of an exclusive scan never depends on later elements).
+  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, S.seg_cnt, S.seg_off, n_work, s);
+
+  const bool optimistic = (inert_mode == 2) && (n_ti > 0 || rle);
   if (optimistic) {
-    hipLaunchKernelGGL(k_backup_roots, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra,
-                       S.a_rb, nodes, S.bk_ds, S.bk_cons, S.bk_flags);
+    hipLaunchKernelGGL(k_backup_roots, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, w_rb,
+                       nodes, S.bk_ds, S.bk_cons, S.bk_flags);
     VSG_HIP(hipMemcpyAsync(S.stats + 8, S.stats, 8 * sizeof(unsigned long long),
                            hipMemcpyDeviceToDevice, s));
   }
@@ -404,32 +490,18 @@ void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* b
   T.pass_s = force ? P.s_lt_02 : P.s_lt_005;
   T.split_s = force ? P.s_lt_02 : P.s_le_015;
   T.min_size = P.min_region_size;
-  // Active edges in component order; the scratch arrays of the earlier steps are free by now.
+  T.rle = rle ? 1 : 0;
+  // Replayed edges in component order; the scratch arrays of the earlier steps are free by now.
   int32_t* s_ra = reinterpret_cast<int32_t*>(S.a_comp);
   int32_t* s_rb = reinterpret_cast<int32_t*>(S.a_idx);
   uint32_t* s_gpos = reinterpret_cast<uint32_t*>(S.e_apos);
-  hipLaunchKernelGGL(k_gather_sorted, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.s_idx,
-                     S.a_ra, S.a_rb, S.a_gpos, s_ra, s_rb, s_gpos);
-  hipLaunchKernelGGL(k_merge_small, dim3(Blocks(n_active)), dim3(256), 0, s, S.num_segs, S.seg_off,
-                     S.seg_cnt, s_ra, s_rb, s_gpos, nodes, kept_all, T,
-                     optimistic ? 1 : 0, d_violation, S.stats);
-  const int wave_grid = n_active / (kSmallSegment + 1) < 1 ? 1
-                        : (n_active / (kSmallSegment + 1) > 8192 ? 8192
-                                                                 : n_active / (kSmallSegment + 1));
+  hipLaunchKernelGGL(k_gather_sorted, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, S.s_idx, w_ra,
+                     w_rb, w_gpos, s_ra, s_rb, s_gpos);
+  const int wave_grid = n_work / (kSmallSegment + 1) < 1 ? 1
+                        : (n_work / (kSmallSegment + 1) > 8192 ? 8192
+                                                               : n_work / (kSmallSegment + 1));
   const int ew0 = NextEvent(S);
   if (ew0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ew0], s));
-  // Worker choice (both are exact): the four-wavefront worker pays off when the bucket's active
-  // edges sit in few, large components that are mostly chains on one region (the fixed cost of a
-  // batch is shared by four times the edges); many small clusters growing side by side are still
-  // replayed faster by the one-wavefront worker (cheaper rounds).  S.block_worker: 0 never
-  // (default), 1 always, 2 by the average component size of the bucket (VSG_BLOCK_WORKER).
-  bool use_block = S.block_worker == 1;
-  if (S.block_worker == 2 && n_active >= (1 << 20)) {
-    int num_segs_host = 0;
-    VSG_HIP(hipMemcpyAsync(&num_segs_host, S.num_segs, sizeof(int), hipMemcpyDeviceToHost, s));
-    VSG_HIP(hipStreamSynchronize(s));
-    use_block = num_segs_host > 0 && n_active / num_segs_host >= 64;
-  }
   WorkerArgs wa;
   wa.num_segs = S.num_segs;
   wa.seg_off = S.seg_off;
@@ -443,20 +515,23 @@ void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* b
   wa.optimistic = optimistic ? 1 : 0;
   wa.violation = d_violation;
   wa.stats = S.stats;
-  if (use_block) {
-    LaunchMergeBlock(wave_grid, wa, S.wave_dbg, s);
-  } else if (S.wave_v1) {
-    LaunchMergeWaveV1(wave_grid, wa, s);
-  } else {
-    LaunchMergeWave(wave_grid, wa, S.wave_debug != 0, S.wave_dbg, s);
-  }
+  auto general_workers = [&](const WorkerArgs& w, int small_threads, int grid) {
+    hipLaunchKernelGGL(k_merge_small, dim3(Blocks(small_threads)), dim3(256), 0, s, w.num_segs,
+                       w.seg_off, w.seg_cnt, w.s_ra, w.s_rb, w.s_gpos, w.nodes, w.kept_all, w.T,
+                       w.optimistic, w.violation, w.stats);
+    if (S.wave_v1) {
+      LaunchMergeWaveV1(grid, w, s);
+    } else {
+      LaunchMergeWave(grid, w, S.wave_debug != 0, S.wave_dbg, s);
+    }
+  };
+  general_workers(wa, n_work, wave_grid);
   const int ew1 = NextEvent(S);
   if (ew1 >= 0) {
     VSG_HIP(hipEventRecord((*S.ev_pool)[ew1], s));
     S.ev_wave->emplace_back(ew0, ew1);
   }
-  hipLaunchKernelGGL(k_reset_cc, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra, S.a_rb,
-                     S.cc);
+  hipLaunchKernelGGL(k_reset_cc, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, w_rb, S.cc);
   VSG_HIP(hipGetLastError());
   if (optimistic) {
     int violated = 0;
@@ -464,18 +539,28 @@ void RunBucketStage(int bucket, int n_b, const ListDesc* lists, const int32_t* b
     VSG_HIP(hipStreamSynchronize(s));
     ++*S.optimistic_stages;
     if (violated || S.force_rollback) {
-      // Undo the stage and replay it without any tentatively settled edge.
+      // Undo the stage and replay it without any tentatively settled edge, every edge on its own.
       ++*S.rollbacks;
-      hipLaunchKernelGGL(k_restore_roots, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra,
-                         S.a_rb, nodes, S.bk_ds, S.bk_cons, S.bk_flags);
+      hipLaunchKernelGGL(k_restore_roots, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, w_rb,
+                         nodes, S.bk_ds, S.bk_cons, S.bk_flags);
       VSG_HIP(hipMemcpyAsync(S.stats, S.stats + 8, 8 * sizeof(unsigned long long),
                              hipMemcpyDeviceToDevice, s));
       hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_gpos, kept_all);
       clear_marks();
       VSG_HIP(hipGetLastError());
-      RunBucketStage(bucket, n_b, lists, bucket_base, list_slot_base, kept_all, nodes, P, 0, S, s);
+      RunBucketStage(bucket, j0, n_b, lists, bucket_base, list_slot_base, kept_all, nodes, P, 0, S,
+                     s, info);
       return;
     }
+  }
+  if (info) {   // how the stage decomposed (the caller sizes the next windows with it)
+    info->replayed = n_work;
+    VSG_HIP(hipMemcpyAsync(&info->components, S.num_segs, sizeof(int), hipMemcpyDeviceToHost, s));
+    VSG_HIP(hipStreamSynchronize(s));
+  }
+  if (rle && n_work < n_active) {
+    hipLaunchKernelGGL(k_resolve_followers, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, lead,
+                       S.lead_pos, S.a_gpos, S.l_gpos, kept_all);
   }
   clear_marks();
   VSG_HIP(hipGetLastError());

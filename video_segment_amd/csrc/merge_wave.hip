@@ -563,6 +563,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
                                                  : TentativeViolated(o1, o2, s2, s2);
             if (v) *violation = 1;
           }
+          if (stat == 4 && T.rle) *violation = 1;
           n_forced += (stat == 1);
           n_regular += (stat == 2);
           n_small += (stat == 3);
@@ -595,20 +596,45 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           const float ca = (float)P.sz * denom;
           const float cb = (float)S * denom;
           const float t0 = ca * P.d0, t1 = ca * P.d1, t2 = ca * P.d2;
-          float h0 = Hs.d0, h1 = Hs.d1, h2 = Hs.d2;
-          float r0 = 0.f, r1 = 0.f, r2 = 0.f;   // hot mean before this lane's merge
+          // The recurrence  h <- t + cb * h  as a systolic chain over the lanes: every step each
+          // lane takes the mean its left neighbour holds (v_mul_f32_dpp wave_shr:1) and applies its
+          // own merge; lanes that do not merge pass the value on (0 + 1 * h is exact).  After step
+          // k the lanes 0..k hold the mean after their edge, so the chain is done after as many
+          // steps as its last merging lane; further steps change nothing.  Same two roundings per
+          // channel and merge as MergeStates, in the same order.
           const unsigned long long merging_mask = __ballot(merging);
-          for (unsigned long long mm = merging_mask; mm; mm &= mm - 1) {
-            const int k = (int)__builtin_ctzll(mm);
-            if (lane == k) {
-              r0 = h0;
-              r1 = h1;
-              r2 = h2;
+          float r0 = Hs.d0, r1 = Hs.d1, r2 = Hs.d2;   // hot mean before this lane's merge
+          float h0 = Hs.d0, h1 = Hs.d1, h2 = Hs.d2;
+          if (merging_mask) {
+            float c = merging ? cb : 1.0f;
+            float u0 = merging ? t0 : 0.0f, u1 = merging ? t1 : 0.0f, u2 = merging ? t2 : 0.0f;
+            if (lane == 0) {   // lane 0 starts from the hot region's mean and ignores what is shifted in
+              u0 = u0 + c * Hs.d0;
+              u1 = u1 + c * Hs.d1;
+              u2 = u2 + c * Hs.d2;
+              c = 0.0f;
             }
-            const float cbk = ReadLaneF(cb, k);
-            h0 = ReadLaneF(t0, k) + cbk * h0;
-            h1 = ReadLaneF(t1, k) + cbk * h1;
-            h2 = ReadLaneF(t2, k) + cbk * h2;
+            h0 = u0;
+            h1 = u1;
+            h2 = u2;
+            const int steps = 64 - (int)__builtin_clzll(merging_mask);   // index of the last merging lane + 1
+            for (int s8 = 0; s8 < steps; s8 += 8) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                h0 = u0 + c * DppWaveShr1Zero(h0);
+                h1 = u1 + c * DppWaveShr1Zero(h1);
+                h2 = u2 + c * DppWaveShr1Zero(h2);
+              }
+            }
+            r0 = DppWaveShr1Old(h0, Hs.d0);
+            r1 = DppWaveShr1Old(h1, Hs.d1);
+            r2 = DppWaveShr1Old(h2, Hs.d2);
+            // every lane behind the last merging one would need more steps: take the final mean
+            // from that lane
+            const int last = steps - 1;
+            h0 = ReadLaneF(h0, last);
+            h1 = ReadLaneF(h1, last);
+            h2 = ReadLaneF(h2, last);
           }
           unsigned long long fail = 0;
           {

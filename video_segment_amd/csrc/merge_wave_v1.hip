@@ -155,6 +155,7 @@ __global__ __launch_bounds__(64) void k_merge_wave_v1(const int32_t* __restrict_
                                                : TentativeViolated(o1, o2, s2, s2);
           if (v && lane == 0) *violation = 1;
         }
+        if (stat == 4 && T.rle) *violation = 1;
         n_forced += (stat == 1);
         n_regular += (stat == 2);
         n_small += (stat == 3);
