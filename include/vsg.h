@@ -9,7 +9,7 @@
  *       called by DenseSegmentationUnit::ProcessFrame/PostProcess, segmentation_unit.cpp:118-161
  *
  *   vsg_graph_*   <->  segmentation::DenseSegGraphInterface       (seam 3)
- *       segmentation/dense_seg_graph_interface.h:107-159 (13 pure virtuals)
+ *       segmentation/dense_seg_graph_interface.h:107-159 (13 pure virtuals, all mirrored)
  *       obtained through DenseSegmentation::CreateDenseSegGraph, dense_segmentation.cpp:253-266
  *
  * Results cross the boundary as serialized segmentation.proto `SegmentationDesc` messages
@@ -56,6 +56,7 @@ typedef struct vsg_options {
   int enforce_spatial_connectedness;  /* 1                                                  */
   int color_distance;                 /* 0 COLOR_DISTANCE_L1, 1 COLOR_DISTANCE_L2 (default) */
   int device;                         /* HIP device ordinal, -1 = current device            */
+  int two_stage_oversegment;          /* 0 (default); 1 = SegmentGraphSpatially first         */
 } vsg_options;
 
 /* Per-stage device time of the last segmented chunk, milliseconds (HIP events on the handle's
@@ -147,6 +148,10 @@ int vsg_graph_add_virtual_frame(vsg_graph* g, const int32_t* constraint_ids, int
 int vsg_graph_add_temporal(vsg_graph* g, const float* flow, int is_virtual, int mem);
 /* FinishBuildingGraph (h:135): waits for the asynchronous build kernels. */
 int vsg_graph_finish_building(vsg_graph* g);
+/* SegmentGraphSpatially(), h:138: merges along the spatial edges only (min_region_size 0, no
+ * constraint merge).  Optional; the segment call that follows then only sees the spatial edges
+ * this pass kept (two_stage_segmentation, segmentation/segmentation.cpp:280-283). */
+int vsg_graph_segment_spatially(vsg_graph* g);
 /* SegmentFullGraph(min_region_size, force_constraints), h:141. */
 int vsg_graph_segment(vsg_graph* g, int min_region_size, int force_constraints);
 /* ObtainResults(..., flows, false, enforce_n4, enforce_spatial_connectedness) followed by

@@ -843,17 +843,39 @@ class DenseGraph {
     }
   }
 
-  // FastSegmentationGraph::SegmentGraph, segmentation_graph.h:339-463 (all bucket lists).
-  void SegmentGraph(int min_region_size, bool force_constraints) {
+  // DenseSegmentationGraph::SegmentGraphSpatially, dense_segmentation_graph.h:406-416: the spatial
+  // bucket lists (2 t) only, min_region_size 0, no constraint merge.  Edges that are not kept
+  // leave their bucket list (segmentation_graph.h:442), so the full pass that follows
+  // (two_stage_segmentation, segmentation.cpp:280-283) only sees what this pass kept.
+  void SegmentGraphSpatially() {
+    std::vector<int> spatial_lists;
+    for (int i = 0; i < num_frames_; ++i) spatial_lists.push_back(2 * i);
+    SegmentGraph(0, false, &spatial_lists, true);
+  }
+
+  // FastSegmentationGraph::SegmentGraph, segmentation_graph.h:339-463.  bucket_list_ids: the
+  // bucket lists to walk (null: all).  The merge statistics add up over the calls on one graph
+  // unless reset_stats is set.
+  void SegmentGraph(int min_region_size, bool force_constraints,
+                    const std::vector<int>* bucket_list_ids = nullptr, bool reset_stats = false) {
     const float inv_scale = (float)(1.0 / (double)scale_);
-    num_forced_merges_ = num_regular_merges_ = num_small_region_merges_ = 0;
+    if (reset_stats || !segmented_once_) {
+      num_forced_merges_ = num_regular_merges_ = num_small_region_merges_ = 0;
+    }
+    segmented_once_ = true;
+    std::vector<int> all_lists;
+    if (!bucket_list_ids) {
+      for (size_t bl = 0; bl < bucket_lists_.size(); ++bl) all_lists.push_back((int)bl);
+      bucket_list_ids = &all_lists;
+    }
     const float merge_thr = 0.05f;   // pixel_distance.h:471
     const float split_thr = 0.15f;   // pixel_distance.h:472
     for (int bucket_idx = 0; bucket_idx < num_buckets_; ++bucket_idx) {
       const float weight = (float)bucket_idx * inv_scale;
       BucketCensus& cs = census_[bucket_idx];
       cs = BucketCensus();
-      for (size_t bl = 0; bl < bucket_lists_.size(); ++bl) {
+      for (int bl : *bucket_list_ids) {
+        if (bl >= (int)bucket_lists_.size()) continue;
         EdgeList remaining;
         EdgeList& edges = bucket_lists_[bl][bucket_idx];
         cs.edges += (int64_t)edges.size();
@@ -1425,6 +1447,7 @@ class DenseGraph {
   bool flattened_ = false;
   int max_region_id_ = 0;
   int64_t num_forced_merges_ = 0, num_regular_merges_ = 0, num_small_region_merges_ = 0;
+  bool segmented_once_ = false;
   std::vector<BucketCensus> census_;
 };
 
@@ -1443,6 +1466,7 @@ static void SegmentationDescToIdImage(const SegmentationDesc& seg, int W, int32_
 // ------------------------------------------------------------------------------------------
 struct SegOptions {
   int min_region_size = 200;
+  bool two_stage_segmentation = false;   // segmentation.h:53-55
   bool enforce_n4_connectivity = true;
   bool enforce_spatial_connectedness = true;
 };
@@ -1457,6 +1481,7 @@ class Segmentation {
   // segmentation.cpp:272-303
   void RunOverSegmentation(const std::vector<const float*>* flows) {
     region_infos_.reset(new RegionInfoList());
+    if (options_.two_stage_segmentation) graph_->SegmentGraphSpatially();   // segmentation.cpp:280-283
     graph_->SegmentGraph(options_.min_region_size, true);
     graph_->MergeStats(merge_stats_);
     RegionInfoPtrMap map;
@@ -1676,6 +1701,7 @@ class DenseSegmentation {
                                options_.frac_min_region_size * (float)H_ * (float)options_.chunk_size);
     so.enforce_n4_connectivity = options_.enforce_n4_connectivity != 0;
     so.enforce_spatial_connectedness = options_.enforce_spatial_connectedness != 0;
+    so.two_stage_segmentation = options_.two_stage_oversegment != 0;   // dense_segmentation.cpp:274
     seg_.reset(new Segmentation(so, W_, H_, chunk_id_, max_frames, options_.color_distance == 0));
   }
 
@@ -1815,6 +1841,7 @@ void vso_default_options(vso_options* o) {
   o->enforce_n4_connectivity = 1;
   o->enforce_spatial_connectedness = 1;
   o->color_distance = 1;
+  o->two_stage_oversegment = 0;
 }
 
 vso_stream* vso_stream_create(const vso_options* o, int width, int height) {
@@ -1969,6 +1996,7 @@ void vso_graph_add_temporal(vso_graph* g, const float* cur, const float* prev, c
                             int is_virtual) {
   g->g->AddTemporal(cur, prev, flow, is_virtual != 0);
 }
+void vso_graph_segment_spatially(vso_graph* g) { g->g->SegmentGraphSpatially(); }
 void vso_graph_segment(vso_graph* g, int min_region_size, int force_constraints) {
   g->g->SegmentGraph(min_region_size, force_constraints != 0);
 }

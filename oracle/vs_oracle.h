@@ -39,6 +39,7 @@ typedef struct vso_options {
   int enforce_n4_connectivity;  /* 1 */
   int enforce_spatial_connectedness; /* 1 */
   int color_distance;           /* 0 = L1, 1 = L2 */
+  int two_stage_oversegment;    /* 0; 1 = SegmentGraphSpatially before SegmentFullGraph */
 } vso_options;
 
 void vso_default_options(vso_options* o);
@@ -99,6 +100,8 @@ void vso_graph_add_virtual_frame(vso_graph* g, const int32_t* constraint_ids);
 /* Connects the last two added slices.  flow NULL = straight; is_virtual = weight 1e10. */
 void vso_graph_add_temporal(vso_graph* g, const float* cur, const float* prev, const float* flow,
                             int is_virtual);
+/* SegmentGraphSpatially (dense_seg_graph_interface.h:138): spatial lists only, before segment. */
+void vso_graph_segment_spatially(vso_graph* g);
 void vso_graph_segment(vso_graph* g, int min_region_size, int force_constraints);
 /* ObtainResults + DetermineNeighborIds.  flows: NULL or array of num_frames pointers. */
 void vso_graph_obtain_results(vso_graph* g, const float* const* flows, int enforce_n4,

@@ -24,6 +24,7 @@ class VsoOptions(C.Structure):
         ("enforce_n4_connectivity", C.c_int),
         ("enforce_spatial_connectedness", C.c_int),
         ("color_distance", C.c_int),
+        ("two_stage_oversegment", C.c_int),
     ]
 
 
@@ -80,6 +81,7 @@ def lib():
     L.vso_graph_add_frame.argtypes = [vp, vp, vp]
     L.vso_graph_add_virtual_frame.argtypes = [vp, vp]
     L.vso_graph_add_temporal.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.vso_graph_segment_spatially.argtypes = [vp]
     L.vso_graph_segment.argtypes = [vp, C.c_int, C.c_int]
     L.vso_graph_obtain_results.argtypes = [vp, vp, C.c_int, C.c_int]
     L.vso_graph_num_regions.restype = C.c_int
@@ -259,6 +261,9 @@ class OracleGraph:
             flow = np.ascontiguousarray(flow, np.float32)
             self._keep.append(flow)
         lib().vso_graph_add_temporal(self.h, _ptr(cur), _ptr(prev), _ptr(flow), int(is_virtual))
+
+    def segment_spatially(self):
+        lib().vso_graph_segment_spatially(self.h)
 
     def segment(self, min_region_size, force_constraints):
         lib().vso_graph_segment(self.h, min_region_size, int(force_constraints))

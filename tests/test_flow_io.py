@@ -100,7 +100,7 @@ def test_host_flow_reader_unit_feeds_the_hip_path():
     base = ["--width", str(W), "--height", str(H), "--frames", str(N), "--flow", "1"]
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, "probe.flow")
-        a = subprocess.run([exe] + base + ["--save_flow", p], capture_output=True, text=True, timeout=300)
+        a = subprocess.run([exe] + base + ["--flow_output_file", p], capture_output=True, text=True, timeout=300)
         assert a.returncode == 0, a.stderr
         assert os.path.getsize(p) == 12 + (N - 1) * W * H * 8
         r = flow_io.DenseFlowReader(p)

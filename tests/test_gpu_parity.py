@@ -247,3 +247,61 @@ def test_chain_protocol_on_gpu(vsg):
         want += [o.result_bytes(i) for i in range(n)]
     assert [k for k, _ in got] == list(range(N))
     assert [b for _, b in got] == want
+
+
+def test_two_stage_oversegment_stream_and_graph(vsg):
+    """two_stage_oversegment (dense_segmentation.h:71): SegmentGraphSpatially before
+    SegmentFullGraph -- through the stream option and through the graph seam
+    (vsg_graph_segment_spatially, dense_seg_graph_interface.h:138)."""
+    for (W, H, N, kind, chunk) in [(96, 64, 26, "smooth", 10), (128, 96, 30, "bench", 12)]:
+        g = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, two_stage_oversegment=1),
+                                  has_flow=True)
+        o = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk, two_stage_oversegment=1),
+                            has_flow=True)
+        plain = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
+        rng = np.random.default_rng(3)
+        fl = synth.const_flow(W, H)
+        differs = False
+        for k in range(N):
+            frame = synth.bench_frame(W, H, k) if kind == "bench" else rand_frame(rng, W, H, kind)
+            f = fl if k > 0 else None
+            last = k == N - 1
+            ng, no, npl = g.process_frame(frame, f, flush=last), o.process_frame(frame, f, flush=last), \
+                plain.process_frame(frame, f, flush=last)
+            assert ng == no == npl
+            if ng:
+                assert np.array_equal(g.last_merge_stats(), o.last_merge_stats())
+            for i in range(ng):
+                assert g.result_bytes(i) == o.result_bytes(i), (k, i)
+                differs = differs or o.result_bytes(i) != plain.result_bytes(i)
+        g.close()
+        o.close()
+        plain.close()
+        assert differs, "the two-stage option had no effect on this input"
+    # graph seam
+    W, H, F = 96, 64, 5
+    g = vsg.DenseSegGraph(W, H, F)
+    o = ol.OracleGraph(W, H, F)
+    feats = []
+    for k in range(F):
+        frame = synth.bench_frame(W, H, k)
+        feat = ol.preprocess(frame)
+        feats.append(feat)
+        g.add_frame_bgr(frame)
+        o.add_frame(feat)
+        if k > 0:
+            g.add_temporal(None, False)
+            o.add_temporal(feats[k], feats[k - 1], None, False)
+    g.finish_building()
+    g.segment_spatially()
+    o.segment_spatially()
+    assert np.array_equal(g.merge_stats(), o.merge_stats())
+    g.segment(50, False)
+    o.segment(50, False)
+    assert np.array_equal(g.merge_stats(), o.merge_stats())
+    g.obtain_results(use_flows=False)
+    o.obtain_results(None, True, True)
+    assert g.num_regions() == o.num_regions()
+    assert g.num_neighbor_links() == o.num_neighbor_links()
+    for t in range(F):
+        assert np.array_equal(g.index_image(t), o.index_image(t))

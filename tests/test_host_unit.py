@@ -30,6 +30,12 @@ def test_host_driver_builds_and_fails_loudly_without_gpu():
 @pytest.mark.parametrize("args,frames,first,total,lhash", [
     (["--width", "64", "--height", "48", "--frames", "8", "--flow", "0"], 8, 264, 2222, "39aeeabb"),
     (["--width", "64", "--height", "48", "--frames", "45", "--flow", "1"], 45, 240, 12385, "5ef008e2"),
+    # the reference's flag spellings (gflags): single threaded tree, and the threaded pipeline
+    # (reader | GPU unit | sink on three threads, seg_tree.cpp:155-163, 211-217, 339-364)
+    (["--width=64", "--height=48", "--frames=45", "--flow", "--nouse_pipeline"], 45, 240, 12385, "5ef008e2"),
+    (["--width=64", "--height=48", "--frames=45", "--flow=true", "--use_pipeline", "--over_segment",
+      "--dense_smoothing=bilateral", "--dense_color_dist=l2", "--dense_min_region_size=0.01"],
+     45, 240, 12385, "5ef008e2"),
 ])
 def test_host_unit_reproduces_reference_pins(args, frames, first, total, lhash):
     build()
@@ -42,3 +48,67 @@ def test_host_unit_reproduces_reference_pins(args, frames, first, total, lhash):
     assert (int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4)) == (frames, first, total, lhash)
     assert "__STREAMING_SIZE__: %d" % frames in p.stderr
     assert "__SEGMENTATION_FINISHED__" in p.stderr
+    if "--nouse_pipeline" in args:
+        assert "pipeline=0" in p.stdout
+    else:
+        assert "pipeline=1" in p.stdout   # the default, as in the reference
+
+
+def test_pipeline_restatement_runs_segments_on_threads(tmp_path):
+    """video_pipeline.h on its own (no GPU): a source unit, a sink/source cut and a consumer that
+    records the thread it runs on; frames arrive complete, in order, on another thread, and the end
+    of the stream passes through the cut."""
+    build()
+    src = tmp_path / "pipe_test.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <thread>
+#include "video_pipeline.h"
+using namespace video_framework;
+struct Producer : VideoUnit {
+  int k = 0;
+  bool OpenStreams(StreamSet* set) override {
+    set->push_back(std::shared_ptr<DataStream>(new VideoStream(4, 2, 12)));
+    return true;
+  }
+  bool PostProcess(std::list<FrameSetPtr>* append) override {
+    if (k >= 50) return false;
+    FrameSetPtr fs(new FrameSet);
+    fs->push_back(std::shared_ptr<Frame>(new VideoFrame(4, 2, 3, 12, k)));
+    append->push_back(fs);
+    ++k;
+    return true;
+  }
+};
+struct Consumer : VideoUnit {
+  std::thread::id tid;
+  long sum = 0; int n = 0, last = -1; bool ordered = true, finished = false;
+  void ProcessFrame(FrameSetPtr in, std::list<FrameSetPtr>* out) override {
+    tid = std::this_thread::get_id();
+    const int pts = (int)in->at(0)->pts();
+    ordered = ordered && pts == last + 1;
+    last = pts; sum += pts; ++n;
+    out->push_back(in);
+  }
+  bool PostProcess(std::list<FrameSetPtr>*) override { finished = true; return false; }
+};
+int main() {
+  Producer p; VideoPipelineSink sink; sink.AttachTo(&p);
+  VideoPipelineSource source(&sink); Consumer c; c.AttachTo(&source);
+  if (!p.PrepareProcessing()) return 1;
+  VideoPipelineInvoker inv;
+  inv.RunRoot(&p);
+  inv.RunPipelineSource(&source);
+  inv.WaitUntilPipelineFinished();
+  const bool other_thread = c.tid != std::this_thread::get_id();
+  std::printf("n=%d sum=%ld ordered=%d finished=%d other_thread=%d queue=%d rate_ok=%d\n", c.n, c.sum,
+              (int)c.ordered, (int)c.finished, (int)other_thread, sink.GetQueueSize(),
+              (int)(p.MinTreeRate() > 0));
+  return 0;
+}
+''')
+    exe = tmp_path / "pipe_test"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", HOST, "-o", str(exe), str(src)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert "n=50 sum=1225 ordered=1 finished=1 other_thread=1 queue=0 rate_ok=1" in out.stdout

@@ -82,7 +82,7 @@ def test_host_writer_unit_matches_python_writer():
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, "hip.pb")
         r = subprocess.run([os.path.join(HOST, "seg_tree_synth"), "--width", str(W), "--height", str(H),
-                            "--frames", str(N), "--flow", "1", "--write_to_file", p],
+                            "--frames", str(N), "--flow", "1", "--output_file", p],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         assert "label_fnv1a32=5ef008e2" in r.stdout

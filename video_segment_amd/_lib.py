@@ -28,6 +28,7 @@ class VsgOptions(C.Structure):
         ("enforce_spatial_connectedness", C.c_int),
         ("color_distance", C.c_int),
         ("device", C.c_int),
+        ("two_stage_oversegment", C.c_int),
     ]
 
 
@@ -61,7 +62,7 @@ EXPORTED_SYMBOLS = [
     "vsg_stream_import_halo",
     "vsg_graph_create", "vsg_graph_destroy", "vsg_graph_add_frame_bgr",
     "vsg_graph_add_frame_features", "vsg_graph_add_virtual_frame", "vsg_graph_add_temporal",
-    "vsg_graph_finish_building", "vsg_graph_segment", "vsg_graph_obtain_results",
+    "vsg_graph_finish_building", "vsg_graph_segment_spatially", "vsg_graph_segment", "vsg_graph_obtain_results",
     "vsg_graph_num_frames", "vsg_graph_num_regions", "vsg_graph_num_neighbor_links",
     "vsg_graph_region_sizes", "vsg_graph_index_image", "vsg_graph_smoothed",
     "vsg_graph_spatial_buckets", "vsg_graph_temporal_buckets", "vsg_graph_node_roots",
@@ -122,6 +123,7 @@ def lib():
     L.vsg_graph_add_virtual_frame.argtypes = [vp, vp, C.c_int]
     L.vsg_graph_add_temporal.argtypes = [vp, vp, C.c_int, C.c_int]
     L.vsg_graph_finish_building.argtypes = [vp]
+    L.vsg_graph_segment_spatially.argtypes = [vp]
     L.vsg_graph_segment.argtypes = [vp, C.c_int, C.c_int]
     L.vsg_graph_obtain_results.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.vsg_graph_num_frames.argtypes = [vp]

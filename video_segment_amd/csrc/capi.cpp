@@ -114,6 +114,7 @@ void vsg_default_options(vsg_options* o) {
   o->enforce_spatial_connectedness = 1;
   o->color_distance = 1;
   o->device = -1;
+  o->two_stage_oversegment = 0;
 }
 
 int vsg_device_count(void) {
@@ -376,6 +377,14 @@ int vsg_graph_finish_building(vsg_graph* g) {
     VSG_REQUIRE(g, VSG_ERR_INVALID, "null argument");
     DeviceGuard dg(g->device);
     g->g->FinishBuilding();
+  });
+}
+
+int vsg_graph_segment_spatially(vsg_graph* g) {
+  return Guard([&] {
+    VSG_REQUIRE(g, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(g->device);
+    g->g->SegmentSpatially();
   });
 }
 

@@ -75,6 +75,7 @@ void DenseGraphHip::Reset(int max_frames) {
   has_constraints_ = false;
   virtual_slices_.clear();
   flattened_ = false;
+  spatial_pass_done_ = false;
   for (auto& lb : lists_) lb.used = false;
   regions_.clear();
   key_to_region_.clear();
@@ -173,7 +174,7 @@ void DenseGraphHip::EnsureScratch(size_t n) {
 // ---------------------------------------------------------------------------------------------
 // SegmentFullGraph
 // ---------------------------------------------------------------------------------------------
-void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
+void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, int pass) {
   VSG_REQUIRE(num_frames_ >= 1, -3, "no frames");
   min_region_size_ = min_region_size;
   const int L = (int)lists_.size();
@@ -192,7 +193,8 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
       d.slots = lb.slots.get();
       d.kept = kept_all_.get() + acc;
       d.prev_idx = lb.type == 1 ? lb.prev_idx.get() : nullptr;
-      d.offsets = lb.offsets.get();
+      // a spatial-only pass does not see the temporal lists (their positions in kept_all stay)
+      d.offsets = (pass == 1 && lb.type == 1) ? nullptr : lb.offsets.get();
       d.type = lb.type;
       d.base_a = lb.base_a;
       d.base_b = lb.base_b;
@@ -204,6 +206,13 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   list_slot_base_[L] = acc;
   H2D(list_desc_dev_.get(), desc.data(), (size_t)L, stream_);
   H2D(list_slot_base_dev_.get(), list_slot_base_.data(), (size_t)L + 1, stream_);
+  if (pass == 2) {
+    // Edges of the spatial lists that the spatial pass did not keep are gone
+    // (segmentation_graph.h:442: the kept edges replace the bucket's contents).
+    kept_spatial_pass_.ensure(kept_all_.size());
+    VSG_HIP(hipMemcpyAsync(kept_spatial_pass_.get(), kept_all_.get(), acc, hipMemcpyDeviceToDevice,
+                           stream_));
+  }
   VSG_HIP(hipMemsetAsync(kept_all_.get(), 0, acc, stream_));
   LaunchBuildBucketTable(list_desc_dev_.get(), L, bucket_base_dev_.get(), stream_);
   bucket_base_host_.resize((size_t)(kNumBuckets + 1) * (L + 1));
@@ -268,6 +277,7 @@ void DenseGraphHip::Segment(int min_region_size, bool force_constraints) {
   S.ev_used = &ev_used_;
 
   MergeParams P;
+  P.spatial_survivors = pass == 2 ? kept_spatial_pass_.get() : nullptr;
   P.W = W_;
   P.H = H_;
   P.num_lists = L;

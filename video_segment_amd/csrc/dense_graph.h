@@ -46,7 +46,16 @@ class DenseGraphHip {
   void AddTemporal(const float* cur_dev, const float* prev_dev, const float* flow_dev,
                    bool is_virtual);
   void FinishBuilding();
-  void Segment(int min_region_size, bool force_constraints);
+  void Segment(int min_region_size, bool force_constraints) {
+    SegmentLists(min_region_size, force_constraints, spatial_pass_done_ ? 2 : 0);
+  }
+  // SegmentGraphSpatially (dense_segmentation_graph.h:406-416): the spatial bucket lists only,
+  // min_region_size 0, no constraint merge; the Segment() call that follows only sees the
+  // spatial edges this pass kept (two_stage_oversegment).
+  void SegmentSpatially() {
+    SegmentLists(0, false, 1);
+    spatial_pass_done_ = true;
+  }
   // ObtainResults + DetermineNeighborIds.  host_flows: per slice W*H*2 f32 host pointers (may
   // contain nullptr) or null.
   void ObtainResults(const std::vector<const float*>* host_flows, bool enforce_n4,
@@ -104,6 +113,10 @@ class DenseGraphHip {
   DevBuf<uint32_t> list_slot_base_dev_;
   std::vector<uint32_t> list_slot_base_;
   DevBuf<uint8_t> kept_all_;
+  DevBuf<uint8_t> kept_spatial_pass_;   // two-stage: what SegmentSpatially kept
+  bool spatial_pass_done_ = false;
+  // pass: 0 all lists, 1 spatial lists only, 2 all lists after a spatial pass
+  void SegmentLists(int min_region_size, bool force_constraints, int pass);
   DevBuf<int32_t> bucket_base_dev_;
   std::vector<int32_t> bucket_base_host_;
   // temporaries for edge generation / sorting

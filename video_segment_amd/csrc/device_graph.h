@@ -52,6 +52,9 @@ struct MergeParams {
   // Squared-distance thresholds (see merge_common.h): largest float s with
   // sqrtf(s) < 0.05f, (double)sqrtf(s) < 0.2 and sqrtf(s) <= 0.15f respectively.
   float s_lt_005, s_lt_02, s_le_015;
+  // Two-stage over-segmentation, full pass: per edge position, 1 = the spatial pass kept the
+  // edge.  Spatial edges it did not keep no longer exist.  Null otherwise.
+  const uint8_t* spatial_survivors;
 };
 
 // ---- build_kernels.hip ----------------------------------------------------------------

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int j0, int n_b,
     const int rb = FindCompress(nodes.parent, b);
     const uint32_t gpos = list_slot_base[l] + (uint32_t)pos;
     int active = 0;
-    if (ra != rb) {
+    const bool gone = P.spatial_survivors && L.type == 0 && !P.spatial_survivors[gpos];
+    if (ra != rb && !gone) {
       bool inert = false;
       if (inert_mode != 0) {
         const int f1 = nodes.flags[ra], f2 = nodes.flags[rb];

@@ -290,6 +290,7 @@ void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
   }
   // RunOverSegmentation (segmentation.cpp:272-303)
   graph_->FinishBuilding();
+  if (options_.two_stage_oversegment) graph_->SegmentSpatially();   // segmentation.cpp:280-283
   graph_->Segment(MinRegionSize(), true);
   graph_->ObtainResults(have_flows ? &flows : nullptr, options_.enforce_n4_connectivity != 0,
                         options_.enforce_spatial_connectedness != 0);

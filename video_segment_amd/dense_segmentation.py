@@ -29,15 +29,35 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
-def _ptr_mem(x):
-    """Returns (pointer, mem kind) of a numpy array or torch tensor (None -> (None, host))."""
+_DTYPE_NAMES = {"uint8": ("uint8",), "float32": ("float32",), "int32": ("int32",)}
+
+
+def _ptr_mem(x, dtype=None, strided_rows=False):
+    """Returns (pointer, mem kind) of a numpy array or torch tensor (None -> (None, host)).
+
+    dtype: required element type ("uint8", "float32", "int32").  The array has to be contiguous;
+    strided_rows allows an H x W x 3 frame whose rows are `stride` bytes apart (a view of a wider
+    buffer, like the reference's padded VideoFrames)."""
     if x is None:
         return None, _lib.VSG_MEM_HOST
+    name = str(x.dtype).replace("torch.", "")
+    if dtype is not None and name != dtype:
+        raise TypeError("expected %s, got %s" % (dtype, name))
     if _is_torch(x):
-        assert x.is_contiguous() or x.dim() == 3
+        if not (x.is_contiguous() or (strided_rows and x.dim() == 3 and x.stride(2) == 1
+                                       and x.stride(1) == x.shape[2])):
+            raise ValueError("tensor has to be contiguous")
         mem = _lib.VSG_MEM_DEVICE if x.is_cuda else _lib.VSG_MEM_HOST
         return C.c_void_p(x.data_ptr()), mem
+    if not (x.flags["C_CONTIGUOUS"] or (strided_rows and x.ndim == 3 and x.strides[2] == x.itemsize
+                                         and x.strides[1] == x.shape[2] * x.itemsize)):
+        raise ValueError("array has to be C-contiguous")
     return x.ctypes.data_as(C.c_void_p), _lib.VSG_MEM_HOST
+
+
+def _same_mem(mem_a, mem_b, what):
+    if mem_a != mem_b:
+        raise ValueError("%s has to live in the same memory kind (host / device) as the frame" % what)
 
 
 def _row_stride(bgr):
@@ -77,13 +97,16 @@ class DenseSegmentation:
         if bgr is not None:
             assert tuple(bgr.shape) == (self.H, self.W, 3)
             stride = _row_stride(bgr)
-        p_bgr, mem = _ptr_mem(bgr)
+        p_bgr, mem = _ptr_mem(bgr, "uint8", strided_rows=True)
         if flow is not None:
             assert tuple(flow.shape) == (self.H, self.W, 2)
             if not _is_torch(flow):
                 flow = np.ascontiguousarray(flow, dtype=np.float32)
-            p_flow, mem_f = _ptr_mem(flow)
-            assert bgr is None or mem_f == mem, "frame and flow must live in the same memory kind"
+            p_flow, mem_f = _ptr_mem(flow, "float32")
+            if bgr is not None:
+                _same_mem(mem_f, mem, "the flow field")
+            else:
+                mem = mem_f
         else:
             p_flow = None
         n = C.c_int()
@@ -127,9 +150,13 @@ class DenseSegmentation:
         return a.value, b.value, s
 
     def import_halo(self, labels_virtual, labels_constrained, scalars):
-        pa, mem = _ptr_mem(labels_virtual)
-        pb, mem_b = _ptr_mem(labels_constrained)
-        assert mem == mem_b
+        n = self.W * self.H
+        for a in (labels_virtual, labels_constrained):
+            if int(np.prod(tuple(a.shape))) != n:
+                raise ValueError("label planes have to hold W*H int32")
+        pa, mem = _ptr_mem(labels_virtual, "int32")
+        pb, mem_b = _ptr_mem(labels_constrained, "int32")
+        _same_mem(mem_b, mem, "the second label plane")
         s = np.ascontiguousarray(scalars, dtype=np.int64)
         check(lib().vsg_stream_import_halo(self.h, pa, pb, mem, s.ctypes.data_as(C.c_void_p)))
 
@@ -153,35 +180,44 @@ class DenseSegGraph:
         self.close()
 
     def add_frame_bgr(self, bgr, presmoothing=2, constraint_ids=None):
-        p, mem = _ptr_mem(bgr)
+        assert tuple(bgr.shape) == (self.H, self.W, 3)
+        p, mem = _ptr_mem(bgr, "uint8", strided_rows=True)
         if constraint_ids is not None and not _is_torch(constraint_ids):
             constraint_ids = np.ascontiguousarray(constraint_ids, np.int32)
-        pc, _ = _ptr_mem(constraint_ids)
+        pc, mem_c = _ptr_mem(constraint_ids, "int32")
+        if constraint_ids is not None:
+            _same_mem(mem_c, mem, "constraint_ids")
         check(lib().vsg_graph_add_frame_bgr(self.h, p, _row_stride(bgr), presmoothing, pc, mem))
 
     def add_frame_features(self, feat, constraint_ids=None):
         if not _is_torch(feat):
             feat = np.ascontiguousarray(feat, np.float32)
-        p, mem = _ptr_mem(feat)
+        assert tuple(feat.shape) == (self.H, self.W, 3)
+        p, mem = _ptr_mem(feat, "float32")
         if constraint_ids is not None and not _is_torch(constraint_ids):
             constraint_ids = np.ascontiguousarray(constraint_ids, np.int32)
-        pc, _ = _ptr_mem(constraint_ids)
+        pc, mem_c = _ptr_mem(constraint_ids, "int32")
+        if constraint_ids is not None:
+            _same_mem(mem_c, mem, "constraint_ids")
         check(lib().vsg_graph_add_frame_features(self.h, p, pc, mem))
 
     def add_virtual_frame(self, constraint_ids):
         if not _is_torch(constraint_ids):
             constraint_ids = np.ascontiguousarray(constraint_ids, np.int32)
-        p, mem = _ptr_mem(constraint_ids)
+        p, mem = _ptr_mem(constraint_ids, "int32")
         check(lib().vsg_graph_add_virtual_frame(self.h, p, mem))
 
     def add_temporal(self, flow=None, is_virtual=False):
         if flow is not None and not _is_torch(flow):
             flow = np.ascontiguousarray(flow, np.float32)
-        p, mem = _ptr_mem(flow)
+        p, mem = _ptr_mem(flow, "float32")
         check(lib().vsg_graph_add_temporal(self.h, p, int(is_virtual), mem))
 
     def finish_building(self):
         check(lib().vsg_graph_finish_building(self.h))
+
+    def segment_spatially(self):
+        check(lib().vsg_graph_segment_spatially(self.h))
 
     def segment(self, min_region_size, force_constraints):
         check(lib().vsg_graph_segment(self.h, int(min_region_size), int(force_constraints)))

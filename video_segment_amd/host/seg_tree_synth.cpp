@@ -1,9 +1,9 @@
 // seg_tree_synth.cpp -- the caller of the hot path, mirroring seg_tree_sample's over-segmentation
 // wiring (seg_tree_sample/seg_tree.cpp:85-367): root unit -> [flow] -> DenseSegmentationUnit ->
-// sink, run single threaded.  The H.264 reader and the .flow reader of the reference are replaced
+// sink, as a threaded pipeline (--use_pipeline, the default as in the reference) or single threaded.  The H.264 reader and the .flow reader of the reference are replaced
 // by an in-process synthetic source (no codec is available in this image).
 //
-//   seg_tree_synth --width 64 --height 48 --frames 45 --flow 1 --input probe
+//   seg_tree_synth --width 64 --height 48 --frames 45 --flow --input probe [--nouse_pipeline]
 // prints the number of over-segmented frames, Region2D counts and the FNV-1a-32 hash of all region
 // id images (the quantity pinned in SURVEY.md App. B), then __SEGMENTATION_FINISHED__.
 #include <chrono>
@@ -17,6 +17,7 @@
 #include "raw_video_reader.h"
 #include "segmentation_io.h"
 #include "segmentation_unit.h"
+#include "video_pipeline.h"
 
 using namespace video_framework;
 using namespace segmentation;
@@ -181,85 +182,211 @@ int ReadBack(const std::string& file) {
   return 0;
 }
 
-int main(int argc, char** argv) {
-  int width = 64, height = 48, frames = 45, chunk = 20, flow = 1, device = -1;
-  std::string input = "probe", write_to_file, flow_file, save_flow, input_file, read_pb;
-  for (int i = 1; i + 1 < argc; i += 2) {
-    const std::string k = argv[i];
-    const char* v = argv[i + 1];
-    if (k == "--width") width = atoi(v);
-    else if (k == "--height") height = atoi(v);
-    else if (k == "--frames") frames = atoi(v);
-    else if (k == "--chunk_size") chunk = atoi(v);
-    else if (k == "--flow") flow = atoi(v);
-    else if (k == "--input") input = v;
-    else if (k == "--device") device = atoi(v);
-    else if (k == "--write_to_file") write_to_file = v;   // seg_tree.cpp:65
-    else if (k == "--flow_file") flow_file = v;           // <input>.flow, seg_tree.cpp:121-125
-    else if (k == "--save_flow") save_flow = v;           // seg_tree.cpp:67, 177-179
-    else if (k == "--input_file") input_file = v;         // raw BGR24 video, seg_tree.cpp:45
-    else if (k == "--read_pb") read_pb = v;
+// Flags: the reference's names where it has them (seg_tree.cpp:52-72, dense_segmentation.cpp:39-46),
+// gflags syntax (--flag=value, --flag value, --flag / --noflag for booleans).
+struct Flags {
+  // seg_tree_sample
+  bool flow = true;
+  std::string input_file;
+  bool use_pipeline = true;
+  bool over_segment = true;        // this driver stops after the dense over-segmentation
+  bool write_to_file = false;      // writes <input_file>.pb (or --output_file)
+  bool save_flow = false;          // writes <input base>.flow from the synthetic source
+  // dense_segmentation.cpp
+  std::string dense_smoothing = "bilateral";   // none | bilateral
+  std::string dense_color_dist = "l2";         // l1 | l2
+  double dense_min_region_size = 0.01;         // frac_min_region_size
+  // this driver only
+  int width = 64, height = 48, frames = 45, chunk_size = 20, device = -1;
+  std::string input = "probe";     // synthetic generator: probe | bench
+  std::string output_file, flow_file, read_pb;
+  std::string flow_output_file;    // DenseFlowOptions::flow_output_file: explicit path for --save_flow
+  double pipeline_max_rate = 0;    // seg_tree.cpp:349 uses 20 frames/s for its root
+  bool two_stage_oversegment = false;
+};
+
+bool ParseFlags(int argc, char** argv, Flags* f) {
+  auto as_bool = [](const std::string& v) { return !(v == "0" || v == "false" || v == "no"); };
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a.rfind("--", 0) != 0) {
+      std::fprintf(stderr, "unexpected argument %s\n", a.c_str());
+      return false;
+    }
+    a = a.substr(2);
+    std::string v;
+    bool has_v = false;
+    const size_t eq = a.find('=');
+    if (eq != std::string::npos) {
+      v = a.substr(eq + 1);
+      a = a.substr(0, eq);
+      has_v = true;
+    }
+    static const char* kBools[] = {"flow", "use_pipeline", "over_segment", "write_to_file", "save_flow",
+                                   "two_stage_oversegment"};
+    bool is_bool = false, negated = false;
+    for (const char* b : kBools) {
+      if (a == b) is_bool = true;
+      if (a == std::string("no") + b) {
+        is_bool = negated = true;
+        a = b;
+      }
+    }
+    if (!has_v && !(is_bool && (i + 1 >= argc || std::string(argv[i + 1]).rfind("--", 0) == 0)) &&
+        !negated) {
+      if (i + 1 >= argc) {
+        std::fprintf(stderr, "flag --%s needs a value\n", a.c_str());
+        return false;
+      }
+      v = argv[++i];
+      has_v = true;
+    }
+    const bool bv = negated ? false : (has_v ? as_bool(v) : true);
+    if (a == "flow") f->flow = bv;
+    else if (a == "use_pipeline") f->use_pipeline = bv;
+    else if (a == "over_segment") f->over_segment = bv;
+    else if (a == "write_to_file") f->write_to_file = bv;
+    else if (a == "save_flow") f->save_flow = bv;
+    else if (a == "two_stage_oversegment") f->two_stage_oversegment = bv;
+    else if (a == "input_file") f->input_file = v;
+    else if (a == "dense_smoothing") f->dense_smoothing = v;
+    else if (a == "dense_color_dist") f->dense_color_dist = v;
+    else if (a == "dense_min_region_size") f->dense_min_region_size = atof(v.c_str());
+    else if (a == "width") f->width = atoi(v.c_str());
+    else if (a == "height") f->height = atoi(v.c_str());
+    else if (a == "frames") f->frames = atoi(v.c_str());
+    else if (a == "chunk_size") f->chunk_size = atoi(v.c_str());
+    else if (a == "device") f->device = atoi(v.c_str());
+    else if (a == "input") f->input = v;
+    else if (a == "output_file") f->output_file = v;
+    else if (a == "flow_file") f->flow_file = v;
+    else if (a == "flow_output_file") f->flow_output_file = v;
+    else if (a == "read_pb") f->read_pb = v;
+    else if (a == "pipeline_max_rate") f->pipeline_max_rate = atof(v.c_str());
     else {
-      std::fprintf(stderr, "unknown flag %s\n", k.c_str());
-      return 2;
+      std::fprintf(stderr, "unknown flag --%s\n", a.c_str());
+      return false;
     }
   }
-  if (!read_pb.empty()) return ReadBack(read_pb);
-  // With --input_file the video comes from a raw BGR24 file and, as in seg_tree.cpp:120-126, the
-  // flow from "<input base>.flow" when that file exists.
+  return true;
+}
+
+int main(int argc, char** argv) {
+  Flags FLAGS;
+  if (!ParseFlags(argc, argv, &FLAGS)) return 2;
+  if (!FLAGS.read_pb.empty()) return ReadBack(FLAGS.read_pb);
+  if (!FLAGS.over_segment) {
+    std::fprintf(stderr, "ERROR: only the dense over-segmentation is built here (--over_segment)\n");
+    return 2;
+  }
+  bool use_flow = FLAGS.flow;
+  int frames = FLAGS.frames;
+  std::string flow_file = FLAGS.flow_file;
+  const std::string input_base = FLAGS.input_file.substr(0, FLAGS.input_file.find_last_of("."));
+
+  // Root: a raw BGR24 file (--input_file) or the synthetic source; with --input_file the flow
+  // comes from "<input base>.flow" when that file exists (seg_tree.cpp:120-126).
   std::unique_ptr<RawVideoReaderUnit> raw_reader;
-  if (!input_file.empty()) {
+  if (!FLAGS.input_file.empty()) {
     RawVideoReaderOptions ro;
     ro.trim_frames = 0;
-    raw_reader.reset(new RawVideoReaderUnit(ro, input_file));
-    if (flow && flow_file.empty()) {
-      const std::string candidate = input_file.substr(0, input_file.find_last_of(".")) + ".flow";
+    raw_reader.reset(new RawVideoReaderUnit(ro, FLAGS.input_file));
+    if (use_flow && flow_file.empty()) {
+      const std::string candidate = input_base + ".flow";
       if (std::ifstream(candidate.c_str()).good()) flow_file = candidate;
-      else flow = 0;   // no flow unit in this build: segment without temporal displacement
+      else use_flow = false;   // no flow unit in this build: segment without temporal displacement
     }
   }
-  // With --flow_file the flow comes from DenseFlowReaderUnit instead of the source
-  // (seg_tree.cpp:164-169).
-  const bool flow_from_file = flow != 0 && !flow_file.empty();
-  SyntheticVideoUnit source(width, height, frames, flow != 0 && !flow_from_file, input == "bench",
-                            save_flow);
+  const bool flow_from_file = use_flow && !flow_file.empty();
+  const std::string save_flow =
+      !FLAGS.flow_output_file.empty() ? FLAGS.flow_output_file
+      : FLAGS.save_flow ? (FLAGS.input_file.empty() ? std::string("synth.flow") : input_base + ".flow")
+                        : std::string();
+  SyntheticVideoUnit source(FLAGS.width, FLAGS.height, frames, use_flow && !flow_from_file,
+                            FLAGS.input == "bench", save_flow);
+  VideoUnit* root = raw_reader ? static_cast<VideoUnit*>(raw_reader.get()) : &source;
+  VideoUnit* input = root;
+
+  // Pipeline segments as in seg_tree.cpp:155-163, 211-217: reader | [flow reader] dense
+  // segmentation | sink + writer, each on its own thread.
+  std::vector<std::unique_ptr<VideoPipelineSource>> sources;
+  std::vector<std::unique_ptr<VideoPipelineSink>> sinks;
+  auto cut = [&]() {
+    sinks.emplace_back(new VideoPipelineSink());
+    sinks.back()->AttachTo(input);
+    sources.emplace_back(new VideoPipelineSource(sinks.back().get()));
+    input = sources.back().get();
+  };
+  if (FLAGS.use_pipeline) cut();
+
   std::unique_ptr<DenseFlowReaderUnit> flow_reader;
-  VideoUnit* root_unit = raw_reader ? static_cast<VideoUnit*>(raw_reader.get()) : &source;
-  VideoUnit* input_unit = root_unit;
-  if (flow_from_file) {
+  if (flow_from_file) {   // seg_tree.cpp:164-169
     flow_reader.reset(new DenseFlowReaderUnit(DenseFlowReaderOptions(), flow_file));
-    flow_reader->AttachTo(input_unit);
-    input_unit = flow_reader.get();
-  }
-  DenseSegmentationUnitOptions unit_options;
-  if (!flow) unit_options.flow_stream_name.clear();   // seg_tree.cpp:195-198
-  unit_options.device = device;
-  DenseSegmentationOptions seg_options;
-  seg_options.chunk_size = chunk;
-  DenseSegmentationUnit dense_unit(unit_options, &seg_options);
-  HashSinkUnit sink;
-  dense_unit.AttachTo(input_unit);
-  sink.AttachTo(&dense_unit);
-  std::unique_ptr<SegmentationWriterUnit> writer;
-  if (!write_to_file.empty()) {   // seg_tree.cpp:296-312
-    SegmentationWriterUnitOptions wo;
-    wo.filename = write_to_file;
-    writer.reset(new SegmentationWriterUnit(wo));
-    writer->AttachTo(&sink);
+    flow_reader->AttachTo(input);
+    input = flow_reader.get();
   }
 
-  if (!root_unit->PrepareProcessing()) {
-    std::fprintf(stderr, "ERROR: setup failed\n");
+  DenseSegmentationUnitOptions unit_options;
+  if (!use_flow) unit_options.flow_stream_name.clear();   // seg_tree.cpp:195-198
+  unit_options.device = FLAGS.device;
+  DenseSegmentationOptions seg_options;
+  seg_options.chunk_size = FLAGS.chunk_size;
+  seg_options.two_stage_oversegment = FLAGS.two_stage_oversegment;
+  // dense_segmentation.cpp:79-101: the flags override the options.
+  seg_options.frac_min_region_size = (float)FLAGS.dense_min_region_size;
+  if (FLAGS.dense_smoothing == "none") seg_options.presmoothing = DenseSegmentationOptions::PRESMOOTH_NONE;
+  else if (FLAGS.dense_smoothing == "bilateral") seg_options.presmoothing = DenseSegmentationOptions::PRESMOOTH_BILATERAL;
+  else {
+    std::fprintf(stderr, "ERROR: --dense_smoothing %s is not supported (none | bilateral)\n",
+                 FLAGS.dense_smoothing.c_str());
+    return 2;
+  }
+  if (FLAGS.dense_color_dist == "l1") seg_options.color_distance = DenseSegmentationOptions::COLOR_DISTANCE_L1;
+  else if (FLAGS.dense_color_dist == "l2") seg_options.color_distance = DenseSegmentationOptions::COLOR_DISTANCE_L2;
+  else {
+    std::fprintf(stderr, "ERROR: unknown --dense_color_dist %s (l1 | l2)\n", FLAGS.dense_color_dist.c_str());
+    return 2;
+  }
+  DenseSegmentationUnit dense_unit(unit_options, &seg_options);
+  dense_unit.AttachTo(input);
+  input = &dense_unit;
+  if (FLAGS.use_pipeline) cut();
+
+  HashSinkUnit sink;
+  sink.AttachTo(input);
+  input = &sink;
+  std::unique_ptr<SegmentationWriterUnit> writer;
+  if (FLAGS.write_to_file || !FLAGS.output_file.empty()) {   // seg_tree.cpp:296-312
+    SegmentationWriterUnitOptions wo;
+    wo.filename = !FLAGS.output_file.empty() ? FLAGS.output_file
+                  : (FLAGS.input_file.empty() ? std::string("synth.pb") : FLAGS.input_file + ".pb");
+    writer.reset(new SegmentationWriterUnit(wo));
+    writer->AttachTo(input);
+    input = writer.get();
+  }
+
+  if (!root->PrepareProcessing()) {
+    std::fprintf(stderr, "ERROR: Setup failed.\n");
     return 1;
   }
   const auto t0 = std::chrono::steady_clock::now();
-  root_unit->Run();
+  if (!FLAGS.use_pipeline) {
+    root->Run();
+  } else {   // seg_tree.cpp:339-364
+    VideoPipelineInvoker invoker;
+    RatePolicy pipeline_policy;
+    pipeline_policy.max_rate = (float)FLAGS.pipeline_max_rate;
+    invoker.RunRootRateLimited(pipeline_policy, root);
+    for (size_t k = 0; k + 1 < sources.size(); ++k) invoker.RunPipelineSource(sources[k].get());
+    sources.back()->Run();   // the last segment runs on the main thread
+    invoker.WaitUntilPipelineFinished();
+  }
   if (raw_reader) frames = raw_reader->num_frames();
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::printf("frames=%d first_frame_regions=%d total_regions=%ld label_fnv1a32=%08x bytes=%zu "
-              "seconds=%.3f fps=%.2f\n",
+              "seconds=%.3f fps=%.2f pipeline=%d\n",
               sink.frames(), sink.first_regions(), sink.total_regions(), sink.hash(), sink.bytes(),
-              dt, sink.frames() / dt);
+              dt, sink.frames() / dt, FLAGS.use_pipeline ? 1 : 0);
   std::fprintf(stderr, "__SEGMENTATION_FINISHED__\n");
   return sink.frames() == frames ? 0 : 3;
 }

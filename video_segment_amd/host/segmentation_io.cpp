@@ -184,4 +184,42 @@ bool SegmentationReader::SegmentationResolution(int* width, int* height) {
   return ok;
 }
 
+// ---- SegmentationReaderUnit -----------------------------------------------------------------
+bool SegmentationReaderUnit::OpenStreams(StreamSet* set) {
+  const bool res = reader_.OpenFileAndReadHeaders();
+  if (res) reader_.SegmentationResolution(&frame_width_, &frame_height_);
+  set->push_back(std::shared_ptr<DataStream>(
+      new SegmentationStream(frame_width_, frame_height_, options_.segment_stream_name)));
+  seg_stream_index_ = (int)set->size() - 1;
+  return res;
+}
+
+void SegmentationReaderUnit::ProcessFrame(FrameSetPtr input, std::list<FrameSetPtr>* output) {
+  ReadNextFrame(input);
+  output->push_back(input);
+}
+
+bool SegmentationReaderUnit::PostProcess(std::list<FrameSetPtr>* append) {
+  if (reader_.RemainingFrames() > 0) {   // the reader is the source of the tree
+    VF_CHECK(seg_stream_index_ == 0, "Reader encountered remaining frames but not used as source.");
+    FrameSetPtr input(new FrameSet);
+    ReadNextFrame(input);
+    append->push_back(input);
+    return true;
+  }
+  return false;
+}
+
+void SegmentationReaderUnit::ReadNextFrame(FrameSetPtr input) {
+  const int frame = reader_.NumFrames() - reader_.RemainingFrames();
+  std::unique_ptr<SegmentationDesc> segmentation(new SegmentationDesc());
+  if (!reader_.ReadNextFrame(segmentation.get())) {
+    std::fprintf(stderr, "ERROR: Could not read from segmentation.\n");
+    return;
+  }
+  const int64_t pts = frame < (int)reader_.TimeStamps().size() ? reader_.TimeStamps()[(size_t)frame] : 0;
+  input->push_back(std::shared_ptr<Frame>(
+      new PointerFrame<SegmentationDesc>(std::move(segmentation), pts)));
+}
+
 }  // namespace segmentation

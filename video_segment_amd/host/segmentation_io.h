@@ -86,6 +86,31 @@ class SegmentationWriterUnit : public VideoUnit {
   int frame_number_ = 0;
 };
 
+struct SegmentationReaderUnitOptions {
+  std::string filename;
+  std::string segment_stream_name = "SegmentationStream";
+};
+
+// Adds the frames of a segmentation container to the FrameSets passing through, or -- used as the
+// root of a tree -- produces one FrameSet per stored frame (segmentation_unit.cpp:417-476).
+class SegmentationReaderUnit : public VideoUnit {
+ public:
+  explicit SegmentationReaderUnit(const SegmentationReaderUnitOptions& options)
+      : options_(options), reader_(options.filename) {}
+  bool OpenStreams(StreamSet* set) override;
+  void ProcessFrame(FrameSetPtr input, std::list<FrameSetPtr>* output) override;
+  bool PostProcess(std::list<FrameSetPtr>* append) override;
+
+ protected:
+  void ReadNextFrame(FrameSetPtr input);
+
+ private:
+  SegmentationReaderUnitOptions options_;
+  SegmentationReader reader_;
+  int seg_stream_index_ = -1;
+  int frame_width_ = 0, frame_height_ = 0;
+};
+
 }  // namespace segmentation
 
 #endif  // VSG_HOST_SEGMENTATION_IO_H_

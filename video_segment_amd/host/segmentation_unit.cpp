@@ -121,6 +121,71 @@ bool SegmentationDesc::FrameSize(int* width, int* height) const {
   return top.ok && seen == 3;
 }
 
+// ---- DenseSegmentation (host class over the C ABI) -----------------------------------------------
+DenseSegmentation::DenseSegmentation(const DenseSegmentationOptions& options, int frame_width,
+                                     int frame_height, int device)
+    : options_(options), frame_width_(frame_width), frame_height_(frame_height) {
+  // What the HIP path does not implement is rejected loudly (the reference would run it).
+  VF_CHECK(!options_.thin_structure_suppression,
+           "thin_structure_suppression is not supported by the HIP over-segmentation path");
+  vsg_options o;
+  vsg_default_options(&o);
+  o.presmoothing = (int)options_.presmoothing;
+  o.frac_min_region_size = options_.frac_min_region_size;
+  o.chunk_size = options_.chunk_size;
+  o.chunk_overlap_ratio = options_.chunk_overlap_ratio;
+  o.num_constraint_frames = options_.num_constraint_frames;
+  o.enforce_n4_connectivity = options_.enforce_n4_connectivity ? 1 : 0;
+  o.enforce_spatial_connectedness = options_.enforce_spatial_connectedness ? 1 : 0;
+  o.color_distance = (int)options_.color_distance;
+  o.two_stage_oversegment = options_.two_stage_oversegment ? 1 : 0;
+  o.device = device;
+  if (vsg_stream_create(&o, frame_width_, frame_height_, &stream_) != VSG_OK) stream_ = nullptr;
+}
+
+DenseSegmentation::~DenseSegmentation() {
+  if (stream_) vsg_stream_destroy(stream_);
+}
+
+int DenseSegmentation::ProcessFrame(bool flush, const std::vector<MatView>* features,
+                                    const MatView* flow,
+                                    std::vector<std::unique_ptr<SegmentationDesc>>* results) {
+  VF_CHECK(stream_ != nullptr, "DenseSegmentation was not created");
+  VF_CHECK(results != nullptr, "results");
+  const uint8_t* bgr = nullptr;
+  size_t stride = 0;
+  if (features) {
+    VF_CHECK(features->size() == 1 && (*features)[0].type == MatView::TYPE_8UC3,
+             "Expecting one BGR24 feature frame.");
+    const MatView& f = (*features)[0];
+    VF_CHECK(f.cols == frame_width_ && f.rows == frame_height_, "feature size differs from the stream's");
+    bgr = static_cast<const uint8_t*>(f.data);
+    stride = f.step;
+  } else {
+    VF_CHECK(flush, "features may only be omitted when flushing");
+  }
+  const float* flow_ptr = nullptr;
+  if (flow && !flow->empty()) {
+    VF_CHECK(flow->type == MatView::TYPE_32FC2 && flow->cols == frame_width_ &&
+                 flow->rows == frame_height_ && flow->step == (size_t)frame_width_ * 2 * sizeof(float),
+             "Expecting a dense W x H x 2 float flow field.");
+    flow_ptr = static_cast<const float*>(flow->data);
+  }
+  int num_results = 0;
+  const int rc = vsg_stream_process_frame(stream_, flush ? 1 : 0, bgr, stride, flow_ptr,
+                                          flow != nullptr ? 1 : 0, VSG_MEM_HOST, &num_results);
+  VF_CHECK(rc == VSG_OK, vsg_last_error());
+  for (int k = 0; k < num_results; ++k) {
+    const uint8_t* data = nullptr;
+    size_t len = 0;
+    VF_CHECK(vsg_stream_result_bytes(stream_, k, &data, &len) == VSG_OK, vsg_last_error());
+    std::unique_ptr<SegmentationDesc> desc(new SegmentationDesc);
+    desc->wire.assign(reinterpret_cast<const char*>(data), len);
+    results->push_back(std::move(desc));
+  }
+  return num_results;
+}
+
 // ---- DenseSegmentationUnit ------------------------------------------------------------------
 DenseSegmentationUnit::DenseSegmentationUnit(const DenseSegmentationUnitOptions& options,
                                              const DenseSegmentationOptions* dense_seg_options)
@@ -128,9 +193,7 @@ DenseSegmentationUnit::DenseSegmentationUnit(const DenseSegmentationUnitOptions&
   if (dense_seg_options) dense_seg_options_ = *dense_seg_options;
 }
 
-DenseSegmentationUnit::~DenseSegmentationUnit() {
-  if (dense_seg_) vsg_stream_destroy(dense_seg_);
-}
+DenseSegmentationUnit::~DenseSegmentationUnit() {}
 
 bool DenseSegmentationUnit::OpenStreams(StreamSet* set) {
   video_stream_idx_ = FindStreamIdx(options_.video_stream_name, set);
@@ -156,71 +219,78 @@ bool DenseSegmentationUnit::OpenStreams(StreamSet* set) {
   }
   set->push_back(std::shared_ptr<DataStream>(
       new SegmentationStream(frame_width_, frame_height_, options_.segment_stream_name)));
-
-  // CreateDenseSegmentation(): the MI355X implementation behind the C ABI.
-  VF_CHECK(!dense_seg_options_.two_stage_oversegment && !dense_seg_options_.thin_structure_suppression &&
-               !dense_seg_options_.compute_vectorization,
-           "option not supported by the HIP over-segmentation path");
-  vsg_options o;
-  vsg_default_options(&o);
-  o.presmoothing = (int)dense_seg_options_.presmoothing;
-  o.frac_min_region_size = dense_seg_options_.frac_min_region_size;
-  o.chunk_size = dense_seg_options_.chunk_size;
-  o.chunk_overlap_ratio = dense_seg_options_.chunk_overlap_ratio;
-  o.num_constraint_frames = dense_seg_options_.num_constraint_frames;
-  o.enforce_n4_connectivity = dense_seg_options_.enforce_n4_connectivity ? 1 : 0;
-  o.enforce_spatial_connectedness = dense_seg_options_.enforce_spatial_connectedness ? 1 : 0;
-  o.color_distance = (int)dense_seg_options_.color_distance;
-  o.device = options_.device;
-  if (vsg_stream_create(&o, frame_width_, frame_height_, &dense_seg_) != VSG_OK) {
+  if (!OpenFeatureStreams(set)) {
+    std::fprintf(stderr, "ERROR: Could not open feature streams.\n");
+    return false;
+  }
+  dense_seg_ = CreateDenseSegmentation();
+  if (!dense_seg_ || !dense_seg_->ok()) {
     std::fprintf(stderr, "ERROR: could not create HIP dense segmentation: %s\n", vsg_last_error());
     return false;
   }
-  SetRateBufferSize(vsg_stream_chunk_size(dense_seg_) * 3);
+  SetRateBufferSize(dense_seg_->ChunkSize() * 3);
   return true;
 }
 
-void DenseSegmentationUnit::ProcessFrame(FrameSetPtr input, std::list<FrameSetPtr>* output) {
+bool DenseSegmentationUnit::OpenFeatureStreams(StreamSet*) { return true; }
+
+std::unique_ptr<DenseSegmentation> DenseSegmentationUnit::CreateDenseSegmentation() {
+  return std::unique_ptr<DenseSegmentation>(
+      new DenseSegmentation(dense_seg_options_, frame_width_, frame_height_, options_.device));
+}
+
+void DenseSegmentationUnit::ExtractFrameSetFeatures(FrameSetPtr input,
+                                                    std::vector<MatView>* features) {
+  VF_CHECK(features != nullptr, "features");
   const VideoFrame& video_frame = input->at(video_stream_idx_)->As<VideoFrame>();
-  const float* flow = nullptr;
+  MatView view;   // appearance only
+  view.data = video_frame.data();
+  view.rows = video_frame.height();
+  view.cols = video_frame.width();
+  view.step = (size_t)video_frame.width_step();
+  view.type = MatView::TYPE_8UC3;
+  features->push_back(view);
+}
+
+void DenseSegmentationUnit::ProcessFrame(FrameSetPtr input, std::list<FrameSetPtr>* output) {
+  std::vector<MatView> features;
+  ExtractFrameSetFeatures(input, &features);
+  MatView flow;   // stays empty for the first frame (segmentation_unit.cpp:124-130)
+  flow.type = MatView::TYPE_32FC2;
   if (input_frames_ > 0 && flow_stream_idx_ >= 0) {
     const DenseFlowFrame& flow_frame = input->at(flow_stream_idx_)->As<DenseFlowFrame>();
-    VF_CHECK(flow_frame.width() == frame_width_ && flow_frame.height() == frame_height_,
-             "flow dimensions differ from the video stream");
-    flow = flow_frame.flow();
+    flow.data = flow_frame.flow();
+    flow.rows = flow_frame.height();
+    flow.cols = flow_frame.width();
+    flow.step = (size_t)flow_frame.width() * 2 * sizeof(float);
   }
   frame_set_buffer_.push_back(input);
   ++input_frames_;
-  int num_results = 0;
-  const int rc = vsg_stream_process_frame(dense_seg_, 0, video_frame.data(),
-                                          (size_t)video_frame.width_step(), flow,
-                                          flow_stream_idx_ >= 0 ? 1 : 0, VSG_MEM_HOST, &num_results);
-  VF_CHECK(rc == VSG_OK, vsg_last_error());
-  if (num_results > 0) OutputSegmentation(num_results, output);
+  std::vector<std::unique_ptr<SegmentationDesc>> results;
+  if (dense_seg_->ProcessFrame(false, &features, flow_stream_idx_ >= 0 ? &flow : nullptr, &results) > 0) {
+    OutputSegmentation(&results, output);
+  }
 }
 
 bool DenseSegmentationUnit::PostProcess(std::list<FrameSetPtr>* append) {
   if (!dense_seg_ || input_frames_ == 0) return false;
-  int num_results = 0;
-  const int rc = vsg_stream_process_frame(dense_seg_, 1, nullptr, 0, nullptr,
-                                          flow_stream_idx_ >= 0 ? 1 : 0, VSG_MEM_HOST, &num_results);
-  VF_CHECK(rc == VSG_OK, vsg_last_error());
-  if (num_results > 0) OutputSegmentation(num_results, append);
+  std::vector<std::unique_ptr<SegmentationDesc>> results;
+  MatView no_flow;
+  if (dense_seg_->ProcessFrame(true, nullptr, flow_stream_idx_ >= 0 ? &no_flow : nullptr, &results) > 0) {
+    OutputSegmentation(&results, append);
+  }
   return false;
 }
 
-void DenseSegmentationUnit::OutputSegmentation(int num_results, std::list<FrameSetPtr>* output) {
-  for (int k = 0; k < num_results; ++k) {
+void DenseSegmentationUnit::OutputSegmentation(
+    std::vector<std::unique_ptr<SegmentationDesc>>* results, std::list<FrameSetPtr>* output) {
+  for (size_t k = 0; k < results->size(); ++k) {
     VF_CHECK(!frame_set_buffer_.empty(), "more results than buffered frame sets");
     FrameSetPtr frame_set = frame_set_buffer_.front();
     frame_set_buffer_.pop_front();
     const int64_t pts = frame_set->at(video_stream_idx_)->pts();
-    const uint8_t* data = nullptr;
-    size_t len = 0;
-    VF_CHECK(vsg_stream_result_bytes(dense_seg_, k, &data, &len) == VSG_OK, vsg_last_error());
-    std::unique_ptr<SegmentationDesc> desc(new SegmentationDesc);
-    desc->wire.assign(reinterpret_cast<const char*>(data), len);
-    frame_set->push_back(std::shared_ptr<Frame>(new PointerFrame<SegmentationDesc>(std::move(desc), pts)));
+    frame_set->push_back(std::shared_ptr<Frame>(
+        new PointerFrame<SegmentationDesc>(std::move((*results)[k]), pts)));
     output->push_back(frame_set);
     ++output_frames_;
   }

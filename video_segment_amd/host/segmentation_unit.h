@@ -50,6 +50,51 @@ struct DenseSegmentationOptions {
   bool compute_vectorization = false;
 };
 
+// Non-owning view of image memory, standing in for the cv::Mat views the reference hands around
+// (VideoFrame::MatView, DenseFlowFrame::MatViewInterleaved; video_unit.cpp:75-78,
+// flow_reader.cpp:55-61).  type: 0 = 8UC3 (BGR24), 1 = 32FC2 (interleaved flow).
+struct MatView {
+  enum Type { TYPE_8UC3 = 0, TYPE_32FC2 = 1 };
+  const void* data = nullptr;
+  int rows = 0, cols = 0;
+  size_t step = 0;   // bytes between rows
+  Type type = TYPE_8UC3;
+  bool empty() const { return data == nullptr; }
+};
+
+// Host-side drop-in for segmentation::DenseSegmentation (dense_segmentation.h:112-186): same
+// ProcessFrame / ChunkSize contract, executed by the MI355X library behind the C ABI
+// (vsg_stream_*, include/vsg.h).  Results are owned by the caller like the reference's
+// std::unique_ptr<SegmentationDesc>.
+class DenseSegmentation {
+ public:
+  // device: HIP device ordinal (-1: the caller's current device).
+  DenseSegmentation(const DenseSegmentationOptions& options, int frame_width, int frame_height,
+                    int device = -1);
+  virtual ~DenseSegmentation();
+  DenseSegmentation(const DenseSegmentation&) = delete;
+  DenseSegmentation& operator=(const DenseSegmentation&) = delete;
+
+  // features: {BGR24 frame} (null only together with flush); flow: null when the unit has no
+  // flow stream at all, an empty view for the first frame.  Returns the number of results.
+  int ProcessFrame(bool flush, const std::vector<MatView>* features, const MatView* flow,
+                   std::vector<std::unique_ptr<SegmentationDesc>>* results);
+  int ChunkSize() const { return options_.chunk_size; }
+  // False when the library could not create the stream (no HIP device, bad options); the
+  // message is in vsg_last_error().
+  bool ok() const { return stream_ != nullptr; }
+
+ protected:
+  const DenseSegmentationOptions& options() const { return options_; }
+  int frame_width() const { return frame_width_; }
+  int frame_height() const { return frame_height_; }
+
+ private:
+  DenseSegmentationOptions options_;
+  int frame_width_, frame_height_;
+  vsg_stream* stream_ = nullptr;
+};
+
 struct DenseSegmentationUnitOptions {
   std::string video_stream_name = "VideoStream";
   std::string flow_stream_name = "BackwardFlowStream";
@@ -57,6 +102,7 @@ struct DenseSegmentationUnitOptions {
   int device = -1;   // HIP device ordinal (-1: current)
 };
 
+// Derive to redefine the features handed to the segmentation (segmentation_unit.h:63-124).
 class DenseSegmentationUnit : public VideoUnit {
  public:
   DenseSegmentationUnit(const DenseSegmentationUnitOptions& options,
@@ -70,13 +116,25 @@ class DenseSegmentationUnit : public VideoUnit {
   int output_frames() const { return output_frames_; }
 
  protected:
+  // The reference's extension points (segmentation_unit.h:79-88).
+  // Override to look up feature specific streams; called during OpenStreams.
+  virtual bool OpenFeatureStreams(StreamSet* set);
+  // Extracts the features of a FrameSet (default: the BGR24 video frame); they are passed to
+  // DenseSegmentation::ProcessFrame.
+  virtual void ExtractFrameSetFeatures(FrameSetPtr input, std::vector<MatView>* features);
+  // Returns the DenseSegmentation to use; called during OpenStreams after OpenFeatureStreams.
+  virtual std::unique_ptr<DenseSegmentation> CreateDenseSegmentation();
+
   int video_stream_idx() const { return video_stream_idx_; }
-  int flow_stream_idx() const { return flow_stream_idx_; }
+  int flow_stream_idx() const { return flow_stream_idx_; }   // -1: no flow
   int frame_width() const { return frame_width_; }
   int frame_height() const { return frame_height_; }
+  const DenseSegmentationUnitOptions& options() const { return options_; }
+  const DenseSegmentationOptions& dense_seg_options() const { return dense_seg_options_; }
 
  private:
-  void OutputSegmentation(int num_results, std::list<FrameSetPtr>* output);
+  void OutputSegmentation(std::vector<std::unique_ptr<SegmentationDesc>>* results,
+                          std::list<FrameSetPtr>* output);
 
   int video_stream_idx_ = -1;
   int flow_stream_idx_ = -1;
@@ -84,7 +142,7 @@ class DenseSegmentationUnit : public VideoUnit {
   DenseSegmentationOptions dense_seg_options_;
   int frame_width_ = 0, frame_height_ = 0;
   int input_frames_ = 0, output_frames_ = 0;
-  vsg_stream* dense_seg_ = nullptr;
+  std::unique_ptr<DenseSegmentation> dense_seg_;
   std::list<FrameSetPtr> frame_set_buffer_;
 };
 

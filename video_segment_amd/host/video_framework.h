@@ -4,13 +4,20 @@
 // video_framework/video_unit.cpp:149-179, 317-483; video_framework/flow_reader.h:46-72).
 //
 // Only what the dense over-segmentation path touches is restated: typed frames and streams,
-// FrameSet / StreamSet, and the VideoUnit tree with OpenStreams / ProcessFrame / PostProcess.
-// Rate limiting, seeking, pools and the threaded pipeline stay out of scope.
+// FrameSet / StreamSet, and the VideoUnit tree with OpenStreams / ProcessFrame / PostProcess,
+// its sender decorators, period statistics and the root's rate policy.  The threaded pipeline
+// (VideoPipelineSink / Source / Invoker) is in video_pipeline.h.  Seeking and VideoPool stay out
+// of scope.
 #ifndef VSG_HOST_VIDEO_FRAMEWORK_H_
 #define VSG_HOST_VIDEO_FRAMEWORK_H_
 
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdint>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <list>
@@ -184,8 +191,24 @@ typedef std::vector<std::shared_ptr<Frame>> FrameSet;
 typedef std::vector<std::shared_ptr<DataStream>> StreamSet;
 typedef std::shared_ptr<FrameSet> FrameSetPtr;
 
-// VideoUnit tree (video_unit.h:343-510).  Single threaded: PrepareProcessing() opens the streams
-// down the tree, Run() pulls frames from the root's PostProcess until it returns false.
+// Rate policy of a root unit (video_unit.h:296-340): a fixed ceiling (max_rate) and/or a ceiling
+// that follows the slowest unit of the tree (dynamic_rate), throttled when pipeline queues fill up.
+struct RatePolicy {
+  float max_rate = 0;               // frames / s, 0 = as fast as possible
+  bool dynamic_rate = false;
+  float dynamic_rate_scale = 1.0f;
+  int startup_frames = 0;
+  float update_interval = 0;        // seconds
+  int queue_throttle_threshold = 8;
+  int num_throttle_frames = 4;
+  float min_throttle_rate = 0.2f;
+};
+
+// VideoUnit tree (video_unit.h:343-510, video_unit.cpp:100-483): OpenStreams / ProcessFrame /
+// PostProcess with their *FromSender decorators, PrepareProcessing + Run (or NextFrame) on the
+// root, per-unit period statistics, rate limiting of the root.  A unit is driven by one thread
+// at a time; units in different pipeline segments (video_pipeline.h) run on different threads and
+// only share immutable FrameSets and the period statistics (guarded by a mutex).
 class VideoUnit {
  public:
   VideoUnit() {}
@@ -197,11 +220,46 @@ class VideoUnit {
   }
   virtual bool PostProcess(std::list<FrameSetPtr>* append) { return false; }
 
+  // Decorators that name the calling unit (units with several inputs); by default every sender
+  // is treated alike.
+  virtual bool OpenStreamsFromSender(StreamSet* set, const VideoUnit* sender) {
+    return OpenStreams(set);
+  }
+  virtual void ProcessFrameFromSender(FrameSetPtr input, std::list<FrameSetPtr>* output,
+                                      const VideoUnit* sender) {
+    ProcessFrame(input, output);
+  }
+  virtual bool PostProcessFromSender(std::list<FrameSetPtr>* append, const VideoUnit* sender) {
+    return PostProcess(append);
+  }
+
+  // Rate management runs downstream from the root; only extensions such as pipeline sources
+  // react (LimitRateImpl).
+  void LimitRate(float fps) {
+    LimitRateImpl(fps);
+    for (VideoUnit* c : children_) c->LimitRate(fps);
+  }
+
   void AddChild(VideoUnit* child) {
-    child->parent_ = this;
+    RemoveChild(child);
     children_.push_back(child);
+    child->parent_ = this;
   }
   void AttachTo(VideoUnit* parent) { parent->AddChild(this); }
+  void RemoveChild(VideoUnit* child) {
+    for (size_t i = 0; i < children_.size(); ++i) {
+      if (children_[i] == child) {
+        child->parent_ = nullptr;
+        children_.erase(children_.begin() + (long)i);
+        return;
+      }
+    }
+  }
+  void RemoveFrom(VideoUnit* parent) { parent->RemoveChild(this); }
+  bool HasChild(VideoUnit* child) const {
+    for (VideoUnit* c : children_) if (c == child) return true;
+    return false;
+  }
   VideoUnit* ParentUnit() const { return parent_; }
   VideoUnit* RootUnit() {
     VideoUnit* u = this;
@@ -209,20 +267,72 @@ class VideoUnit {
     return u;
   }
 
-  // video_unit.cpp:168-179, 317-346
   bool PrepareProcessing() {
+    VF_CHECK(this == RootUnit(), "Only root unit can initiate setup.");
     StreamSet set;
-    return OpenStreamsImpl(&set);
+    if (!OpenStreamsImpl(&set, nullptr)) return false;
+    initialized_ = true;
+    return true;
   }
-  // video_unit.cpp:149-166, 389-483 (no rate policy)
-  bool Run() {
-    PostProcessImpl();
+  virtual bool Run() {
+    if (!initialized_) {
+      std::fprintf(stderr, "ERROR: Unit is not initialized, call PrepareProcessing first.\n");
+      return false;
+    }
+    PostProcessImpl(nullptr);
+    return true;
+  }
+  virtual bool RunRateLimited(const RatePolicy& rate_policy) {
+    VF_CHECK(this == RootUnit(), "Only root unit can enforce rate policy.");
+    rate_policy_ = rate_policy;
+    rate_policy_updated_ = std::chrono::steady_clock::now();
+    PostProcessImpl(nullptr);
     return true;
   }
   bool PrepareAndRun() { return PrepareProcessing() && Run(); }
 
-  float UnitPeriod() const { return frames_ ? (float)(seconds_ / frames_) : 0.f; }
-  float UnitRate() const { return seconds_ > 0 ? (float)(frames_ / seconds_) : 0.f; }
+  // Frame based processing: one PostProcess call of the root per NextFrame; false at the end.
+  bool NextFrame() {
+    if (!initialized_) {
+      std::fprintf(stderr, "ERROR: Unit is not initialized, call PrepareProcessing first.\n");
+      return false;
+    }
+    std::list<FrameSetPtr> append;
+    const bool end_of_stream = NextFrameImpl(nullptr, &append);
+    for (const FrameSetPtr& fs : append) {
+      for (VideoUnit* c : children_) c->ProcessFrameImpl(fs, this);
+    }
+    if (end_of_stream) {
+      for (VideoUnit* c : children_) c->PostProcessImpl(this);
+      return false;
+    }
+    return true;
+  }
+
+  // Mean time spent in ProcessFrame (seconds) over the last SetRateBufferSize calls, its inverse,
+  // the slowest unit of the subtree and the fullest pipeline queue of the subtree.
+  float UnitPeriod() const {
+    std::lock_guard<std::mutex> lock(buffer_mutex_);
+    if (period_buffer_.empty()) return 0.f;
+    double total = 0;
+    for (float v : period_buffer_) total += v;
+    return total > 0 ? (float)(total / (double)period_buffer_.size()) : 0.f;
+  }
+  float UnitRate() const {
+    const float period = UnitPeriod();
+    return period > 0 ? 1.0f / period : 1e3f;
+  }
+  float MinTreeRate() const {
+    float r = UnitRate();
+    for (const VideoUnit* c : children_) r = std::min(r, c->MinTreeRate());
+    return r;
+  }
+  virtual int GetQueueSize() const { return 0; }
+  int MaxTreeQueueSize() const {
+    int q = GetQueueSize();
+    for (const VideoUnit* c : children_) q = std::max(q, c->MaxTreeQueueSize());
+    return q;
+  }
 
  protected:
   int FindStreamIdx(const std::string& stream_name, const StreamSet* set) {
@@ -231,51 +341,140 @@ class VideoUnit {
     }
     return -1;
   }
-  void SetRateBufferSize(int) {}
+  void SetRateBufferSize(int buffer_size) {
+    std::lock_guard<std::mutex> lock(buffer_mutex_);
+    period_capacity_ = (size_t)std::max(1, buffer_size);
+    while (period_buffer_.size() > period_capacity_) period_buffer_.pop_front();
+  }
+  virtual void LimitRateImpl(float fps) {}
+  // Units that hand their frames to another thread (pipeline sinks) do not pass the end of the
+  // stream on themselves.
+  virtual bool PostProcessingPassToChildren() { return true; }
 
-  bool OpenStreamsImpl(StreamSet* set) {
-    if (!OpenStreams(set)) return false;
+  virtual bool OpenStreamsImpl(StreamSet* set, const VideoUnit* sender) {
+    const int prev_stream_sz = (int)set->size();
+    if (!OpenStreamsFromSender(set, sender)) return false;
     stream_sz_ = (int)set->size();
+    for (int i = prev_stream_sz; i < stream_sz_; ++i) {   // duplicate names break FindStreamIdx
+      const std::string name = (*set)[(size_t)i]->stream_name();
+      if (FindStreamIdx(name, set) < i) {
+        std::fprintf(stderr, "ERROR: Duplicate stream found: %s\n", name.c_str());
+        return false;
+      }
+    }
+    // The stream set is handed down the tree: a unit sees every stream its ancestors created.
     for (VideoUnit* c : children_) {
-      StreamSet child_set(*set);
-      if (!c->OpenStreamsImpl(&child_set)) return false;
+      if (!c->OpenStreamsImpl(set, this)) return false;
     }
     return true;
   }
 
-  // video_unit.cpp:348-387
-  void ProcessFrameImpl(const FrameSetPtr& frame_set) {
+  virtual void ProcessFrameImpl(const FrameSetPtr frame_set, const VideoUnit* sender) {
     std::list<FrameSetPtr> output;
     const auto t0 = std::chrono::steady_clock::now();
-    ProcessFrame(frame_set, &output);
-    seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    ++frames_;
-    Forward(output);
+    ProcessFrameFromSender(frame_set, &output, sender);
+    for (const FrameSetPtr& fs : output) {
+      VF_CHECK((int)fs->size() == stream_sz_,
+               "Number of streams set in OpenStreams not consistent with returned FrameSet.");
+    }
+    PushPeriod((float)std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), 1);
+    for (const FrameSetPtr& fs : output) {
+      for (VideoUnit* c : children_) c->ProcessFrameImpl(fs, this);
+    }
   }
 
-  void PostProcessImpl() {
+  // One PostProcess call of this unit; true at the end of the stream.
+  bool NextFrameImpl(const VideoUnit* sender, std::list<FrameSetPtr>* output) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool end_of_stream = !PostProcessFromSender(output, nullptr);
+    if (!output->empty()) {
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      PushPeriod((float)(dt / (double)output->size()), (int)output->size());
+      for (const FrameSetPtr& fs : *output) {
+        VF_CHECK((int)fs->size() == stream_sz_,
+                 "Number of streams set in PostProcessImpl not consistent with returned FrameSet.");
+      }
+    }
+    return end_of_stream;
+  }
+
+  virtual void PostProcessImpl(const VideoUnit* sender) {
     for (;;) {
       std::list<FrameSetPtr> append;
-      const bool more = PostProcess(&append);
-      Forward(append);
-      if (!more) break;
+      const bool end_of_stream = NextFrameImpl(sender, &append);
+      if (rate_policy_.max_rate > 0) {   // only the root carries a policy
+        VF_CHECK(this == RootUnit(), "Expected root unit.");
+        const float target = 1.0f / rate_policy_.max_rate;
+        float last = 0;
+        {
+          std::lock_guard<std::mutex> lock(buffer_mutex_);
+          if (!period_buffer_.empty()) last = period_buffer_.back();
+        }
+        const int wait_us = (int)((target - last) * 1e6f);
+        if (wait_us > 100) std::this_thread::sleep_for(std::chrono::microseconds(wait_us));
+      }
+      if (rate_policy_.dynamic_rate) UpdateDynamicRate();
+      for (const FrameSetPtr& fs : append) {
+        for (VideoUnit* c : children_) c->ProcessFrameImpl(fs, this);
+      }
+      if (end_of_stream) break;
+      if (append.empty()) std::this_thread::sleep_for(std::chrono::microseconds(500));
     }
-    for (VideoUnit* c : children_) c->PostProcessImpl();
+    if (PostProcessingPassToChildren()) {
+      for (VideoUnit* c : children_) c->PostProcessImpl(this);
+    }
   }
 
-  void Forward(const std::list<FrameSetPtr>& frames) {
-    for (const FrameSetPtr& fs : frames) {
-      VF_CHECK((int)fs->size() == stream_sz_, "FrameSet size differs from the unit's stream set");
-      for (VideoUnit* c : children_) c->ProcessFrameImpl(fs);
-    }
-  }
+  const std::vector<VideoUnit*>& children() const { return children_; }
 
  private:
+  void PushPeriod(float seconds, int times) {
+    std::lock_guard<std::mutex> lock(buffer_mutex_);
+    for (int i = 0; i < times; ++i) {
+      period_buffer_.push_back(seconds);
+      if (period_buffer_.size() > period_capacity_) period_buffer_.pop_front();
+    }
+  }
+  // Dynamic ceiling of the root (video_unit.cpp:417-456): after the start-up frames, once per
+  // update interval, max_rate follows the slowest unit of the tree; full queues halve it for
+  // every num_throttle_frames above the threshold (never below min_throttle_rate).
+  void UpdateDynamicRate() {
+    VF_CHECK(this == RootUnit(), "Rate policy can only be adapted by root unit");
+    size_t have;
+    {
+      std::lock_guard<std::mutex> lock(buffer_mutex_);
+      have = period_buffer_.size();
+      if ((size_t)rate_policy_.startup_frames >= period_capacity_) return;   // policy not enforceable
+    }
+    if ((size_t)rate_policy_.startup_frames >= have) return;
+    const auto now = std::chrono::steady_clock::now();
+    if (std::chrono::duration<float>(now - rate_policy_updated_).count() <= rate_policy_.update_interval) {
+      return;
+    }
+    const float min_rate = MinTreeRate();
+    float rate_scale = 1.0f;
+    const int max_queue = MaxTreeQueueSize();
+    if (max_queue > rate_policy_.queue_throttle_threshold) {
+      rate_scale *= std::pow(0.5f, (float)(max_queue - rate_policy_.queue_throttle_threshold) /
+                                       (float)rate_policy_.num_throttle_frames);
+      rate_scale = std::max(rate_scale, rate_policy_.min_throttle_rate);
+    }
+    rate_policy_.max_rate = min_rate * rate_scale * rate_policy_.dynamic_rate_scale;
+    LimitRate(min_rate);
+    rate_policy_updated_ = now;
+  }
+
   std::vector<VideoUnit*> children_;
   VideoUnit* parent_ = nullptr;
   int stream_sz_ = 0;
-  double seconds_ = 0;
-  long frames_ = 0;
+  bool initialized_ = false;
+  std::deque<float> period_buffer_;
+  size_t period_capacity_ = 64;
+  mutable std::mutex buffer_mutex_;
+  RatePolicy rate_policy_;
+  std::chrono::steady_clock::time_point rate_policy_updated_;
+
+  friend class VideoPipelineSource;
 };
 
 }  // namespace video_framework

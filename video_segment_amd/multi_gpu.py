@@ -99,6 +99,10 @@ def run_chain(engine_factory, get_frame, get_flow, num_frames, chunk, width, hei
                 next_frame_out = base + n
         if c + 1 < len(plan):
             halo = from_engine_halo(eng) if from_engine_halo is not None else eng.export_halo()
+            if isinstance(halo[0], int):
+                # DenseSegmentation.export_halo() hands out library-owned device pointers that die
+                # with the engine: they have to be copied before eng.close() (product_halo does).
+                raise TypeError("product engine: pass from_engine_halo=lambda e: product_halo(e, W, H, dev)")
             dst = (c + 1) % world
             if dst == rank:
                 pending_local = halo  # noqa: F841
