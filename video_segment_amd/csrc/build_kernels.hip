@@ -4,9 +4,7 @@
 //   K1  k_bilateral          u8 BGR -> f32 * (1/255) -> 49-tap LUT bilateral -> planar f32
 //       k_convert_planar     PRESMOOTH_NONE variant
 //   K2  k_init_nodes / k_init_virtual_nodes
-//   K3  k_spatial_edges      4 spatial edges per pixel -> u16 bucket keys + slot ids
-//   K4  k_temporal_edges     <=9 (flow displaced) temporal edges per pixel
-//   K5  k_bucket_offsets     start of every bucket in a key-sorted list
+//   (K3 / K4 / K5 -- edge keys and the stable bucket sort -- are in edge_sort.hip)
 //
 // Reference behaviour restated (paths relative to the reference root):
 //   imagefilter/image_filter.cpp:130-167, 184-277        (bilateral)
@@ -29,35 +27,75 @@ void UploadSpaceWeights(const float* w49, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K0: min / max over all bytes of the frame.
+// K0: min / max over all bytes of the frame (HBM bound: 3 B per pixel read once).
+// One wavefront-wide 16-byte load per lane and step; rows may be padded (stride > 3 W), so a row
+// is walked as [unaligned head bytes | 16-byte words | tail bytes].
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_minmax_u8(const uint8_t* __restrict__ bgr, size_t stride,
-                                                    int row_bytes, int H, int* __restrict__ mm) {
-  int lo = 255, hi = 0;
-  const int total_threads = gridDim.x * blockDim.x;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const long long n = (long long)row_bytes * H;
-  for (long long i = tid; i < n; i += total_threads) {
-    const int y = (int)(i / row_bytes);
-    const int x = (int)(i - (long long)y * row_bytes);
-    const int v = bgr[(size_t)y * stride + x];
+__device__ __forceinline__ void MinMaxWord(uint32_t w, int& lo, int& hi) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int v = (int)((w >> (8 * k)) & 0xffu);
     lo = min(lo, v);
     hi = max(hi, v);
   }
+}
+
+__global__ __launch_bounds__(256) void k_minmax_u8(const uint8_t* __restrict__ bgr, size_t stride,
+                                                    int row_bytes, int H, int* __restrict__ mm) {
+  int lo = 255, hi = 0;
+  // blockIdx.y walks the rows, the threads of blockIdx.x the 16-byte words of a row
+  for (int y = blockIdx.y; y < H; y += gridDim.y) {
+    const uint8_t* row = bgr + (size_t)y * stride;
+    const int head = (int)((16 - ((uintptr_t)row & 15)) & 15);          // bytes before alignment
+    const int head_n = min(head, row_bytes);
+    const int words = (row_bytes - head_n) >> 4;
+    const int tail0 = head_n + (words << 4);
+    const uint4* w16 = reinterpret_cast<const uint4*>(row + head_n);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < words; i += gridDim.x * 256) {
+      const uint4 v = w16[i];
+      MinMaxWord(v.x, lo, hi);
+      MinMaxWord(v.y, lo, hi);
+      MinMaxWord(v.z, lo, hi);
+      MinMaxWord(v.w, lo, hi);
+    }
+    if (blockIdx.x == 0) {
+      const int t = threadIdx.x;
+      if (t < head_n) {
+        const int v = row[t];
+        lo = min(lo, v);
+        hi = max(hi, v);
+      }
+      if (tail0 + t < row_bytes && t < 16) {
+        const int v = row[tail0 + t];
+        lo = min(lo, v);
+        hi = max(hi, v);
+      }
+    }
+  }
+  // one pair of atomics per workgroup (same-address atomics serialise in L2)
+  __shared__ int red[2][4];
   for (int off = 32; off > 0; off >>= 1) {
     lo = min(lo, __shfl_down(lo, off));
     hi = max(hi, __shfl_down(hi, off));
   }
   if ((threadIdx.x & 63) == 0) {
-    atomicMin(&mm[0], lo);
-    atomicMax(&mm[1], hi);
+    red[0][threadIdx.x >> 6] = lo;
+    red[1][threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMin(&mm[0], min(min(red[0][0], red[0][1]), min(red[0][2], red[0][3])));
+    atomicMax(&mm[1], max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3])));
   }
 }
 
 void LaunchMinMax(const uint8_t* bgr, size_t stride, int W, int H, int* mm, hipStream_t s) {
   const int init[2] = {255, 0};
   VSG_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_minmax_u8, dim3(1024), dim3(256), 0, s, bgr, stride, W * 3, H, mm);
+  const int row_bytes = W * 3;
+  const int gx = max(1, min(8, (row_bytes / 16 + 255) / 256));
+  const int gy = max(1, min(H, 512 / gx));
+  hipLaunchKernelGGL(k_minmax_u8, dim3(gx, gy), dim3(256), 0, s, bgr, stride, row_bytes, H, mm);
   VSG_HIP(hipGetLastError());
 }
 
@@ -217,155 +255,6 @@ void LaunchInterleavedToPlanar(const float* in, size_t n, float* planes, hipStre
 void LaunchPlanarToInterleaved(const float* planes, size_t n, float* out, hipStream_t s) {
   hipLaunchKernelGGL(k_planar_to_interleaved, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                      planes, n, out);
-  VSG_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------------------------------
-// Edge weights -> bucket keys.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float ColorDist(float ab, float ag, float ar, float bb, float bg,
-                                           float br, int l1) {
-  const float d1 = ab - bb, d2 = ag - bg, d3 = ar - br;
-  if (l1) {
-    // (fabs(d1)+fabs(d2)+fabs(d3)) * (1.0f/3.0f) evaluated in double (double fabs overloads).
-    return (float)((fabs((double)d1) + fabs((double)d2) + fabs((double)d3)) *
-                   (double)(1.0f / 3.0f));
-  }
-  return sqrtf((d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 3.0f));
-}
-
-__device__ __forceinline__ uint16_t BucketOf(float w) {
-  const float scale = 2048.0f / (1.0f + 1e-6f);   // segmentation_graph.h:336
-  return (uint16_t)(int)fminf(2048.0f, w * scale);
-}
-
-// K3: slot = pix * 4 + k, k = 0 right, 1 bottom, 2 bottom-left, 3 bottom-right
-// (AddSpatialEdgesImpl order, dense_segmentation_graph.h:971-996).
-__global__ __launch_bounds__(256) void k_spatial_edges(const float* __restrict__ feat, int W, int H,
-                                                        int l1, ushort4* __restrict__ keys,
-                                                        uint4* __restrict__ vals) {
-  const size_t n = (size_t)W * H;
-  const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (pix >= n) return;
-  const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
-  const float* fb = feat;
-  const float* fg = feat + n;
-  const float* fr = feat + 2 * n;
-  const float ab = fb[pix], ag = fg[pix], ar = fr[pix];
-  ushort4 k4 = make_ushort4(kInvalidKey, kInvalidKey, kInvalidKey, kInvalidKey);
-  const bool has_r = x < W - 1, has_b = y < H - 1, has_l = x > 0;
-  if (has_r) {
-    const size_t q = pix + 1;
-    k4.x = BucketOf(ColorDist(ab, ag, ar, fb[q], fg[q], fr[q], l1));
-  }
-  if (has_b) {
-    size_t q = pix + W;
-    k4.y = BucketOf(ColorDist(ab, ag, ar, fb[q], fg[q], fr[q], l1));
-    if (has_l) {
-      q = pix + W - 1;
-      k4.z = BucketOf(ColorDist(ab, ag, ar, fb[q], fg[q], fr[q], l1));
-    }
-    if (has_r) {
-      q = pix + W + 1;
-      k4.w = BucketOf(ColorDist(ab, ag, ar, fb[q], fg[q], fr[q], l1));
-    }
-  }
-  keys[pix] = k4;
-  const unsigned s0 = (unsigned)pix * 4u;
-  vals[pix] = make_uint4(s0, s0 + 1, s0 + 2, s0 + 3);
-}
-
-void LaunchSpatialEdges(const float* feat, int W, int H, int l1, uint16_t* keys, uint32_t* vals,
-                        hipStream_t s) {
-  const size_t n = (size_t)W * H;
-  hipLaunchKernelGGL(k_spatial_edges, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, feat, W,
-                     H, l1, reinterpret_cast<ushort4*>(keys), reinterpret_cast<uint4*>(vals));
-  VSG_HIP(hipGetLastError());
-}
-
-// x86 cvttss2si semantics for int(float): out of range / NaN -> INT_MIN.
-__device__ __forceinline__ int TruncToIntX86(float v) {
-  if (!(v < 2147483648.0f && v >= -2147483648.0f)) return (int)0x80000000;
-  return (int)v;
-}
-
-// K4: slot = pix * 9 + (dy+1)*3 + (dx+1) around the (flow displaced) location in the previous
-// slice (GetLocalEdges order TL,T,TR,L,C,R,BL,B,BR; dense_segmentation_graph.h:1011-1065,
-// 1126-1135).  is_virtual: weight 1e10 -> bucket 2048 for every existing edge.
-__global__ __launch_bounds__(256) void k_temporal_edges(const float* __restrict__ cur,
-                                                         const float* __restrict__ prev,
-                                                         const float* __restrict__ flow, int W,
-                                                         int H, int l1, int is_virtual,
-                                                         uint16_t* __restrict__ keys,
-                                                         uint32_t* __restrict__ vals,
-                                                         int32_t* __restrict__ prev_idx) {
-  const size_t n = (size_t)W * H;
-  const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (pix >= n) return;
-  const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
-  int px = x, py = y;
-  if (flow) {
-    const float2 f = reinterpret_cast<const float2*>(flow)[pix];
-    px = TruncToIntX86((float)x + f.x);
-    py = TruncToIntX86((float)y + f.y);
-    px = max(0, min(W - 1, px));
-    py = max(0, min(H - 1, py));
-  }
-  prev_idx[pix] = py * W + px;
-  float ab = 0, ag = 0, ar = 0;
-  if (!is_virtual) {
-    ab = cur[pix];
-    ag = cur[n + pix];
-    ar = cur[2 * n + pix];
-  }
-  uint16_t* kp = keys + pix * 9;
-  uint32_t* vp = vals + pix * 9;
-  int k = 0;
-#pragma unroll
-  for (int dy = -1; dy <= 1; ++dy) {
-#pragma unroll
-    for (int dx = -1; dx <= 1; ++dx, ++k) {
-      uint16_t key = kInvalidKey;
-      const int qy = py + dy, qx = px + dx;
-      if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
-        if (is_virtual) {
-          key = (uint16_t)kNumBuckets;
-        } else {
-          const size_t q = (size_t)qy * W + qx;
-          key = BucketOf(ColorDist(ab, ag, ar, prev[q], prev[n + q], prev[2 * n + q], l1));
-        }
-      }
-      kp[k] = key;
-      vp[k] = (uint32_t)pix * 9u + (uint32_t)k;
-    }
-  }
-}
-
-void LaunchTemporalEdges(const float* cur, const float* prev, const float* flow, int W, int H,
-                         int l1, int is_virtual, uint16_t* keys, uint32_t* vals,
-                         int32_t* prev_idx, hipStream_t s) {
-  const size_t n = (size_t)W * H;
-  hipLaunchKernelGGL(k_temporal_edges, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cur,
-                     prev, flow, W, H, l1, is_virtual, keys, vals, prev_idx);
-  VSG_HIP(hipGetLastError());
-}
-
-// K5: offsets[b] = first position in the key-sorted list with key >= b, b = 0..kBucketSlots-1.
-__global__ __launch_bounds__(256) void k_bucket_offsets(const uint16_t* __restrict__ sorted_keys,
-                                                         int n, int* __restrict__ offsets) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= kBucketSlots) return;
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if ((int)sorted_keys[mid] < b) lo = mid + 1; else hi = mid;
-  }
-  offsets[b] = lo;
-}
-
-void LaunchBucketOffsets(const uint16_t* sorted_keys, int n, int* offsets, hipStream_t s) {
-  hipLaunchKernelGGL(k_bucket_offsets, dim3((kBucketSlots + 255) / 256), dim3(256), 0, s,
-                     sorted_keys, n, offsets);
   VSG_HIP(hipGetLastError());
 }
 

@@ -53,13 +53,12 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   const size_t total_slots = (size_t)(4 * max_frames + 9 * (max_frames - 1)) * wh_;
   kept_all_.alloc(total_slots);
   bucket_base_dev_.alloc((size_t)(kNumBuckets + 1) * (lists_.size() + 1));
-  keys_tmp_.alloc(9 * wh_);
-  keys_sorted_tmp_.alloc(9 * wh_);
-  vals_tmp_.alloc(9 * wh_);
+  keys_tmp_.alloc(9 * wh_ + 8);
+  hist_tmp_.alloc(EdgeSortHistInts(wh_));
+  hist_sums_.alloc(EdgeSortSumInts(wh_) + 1);
   scalars_.alloc(16);
   stats_.alloc(64);
-  size_t temp = SortPairsU16TempBytes((int)(9 * wh_));
-  temp = std::max(temp, ScanTempBytes((int)N));
+  size_t temp = ScanTempBytes((int)N);
   cub_temp_.alloc(temp);
   Reset(max_frames);
 }
@@ -84,12 +83,12 @@ void DenseGraphHip::Reset(int max_frames) {
   timings_ = GraphTimings();
 }
 
-void DenseGraphHip::SortList(ListBuf& lb, int n) {
+void DenseGraphHip::SortList(ListBuf& lb, int per_px) {
+  const int n = (int)(per_px * wh_);
   lb.slots.ensure((size_t)n);
   lb.offsets.ensure(kBucketSlots);
-  SortPairsU16(cub_temp_.get(), cub_temp_.size(), keys_tmp_.get(), keys_sorted_tmp_.get(),
-               vals_tmp_.get(), lb.slots.get(), n, stream_);
-  LaunchBucketOffsets(keys_sorted_tmp_.get(), n, lb.offsets.get(), stream_);
+  LaunchBucketSort(keys_tmp_.get(), wh_, per_px, hist_tmp_.get(), hist_sums_.get(),
+                   lb.offsets.get(), lb.slots.get(), stream_);
   lb.n = n;
   lb.used = true;
 }
@@ -103,8 +102,8 @@ void DenseGraphHip::AddFrame(const float* feat, const int32_t* cons_dev) {
   lb.type = 0;
   lb.base_a = base;
   lb.base_b = base;
-  LaunchSpatialEdges(feat, W_, H_, l1_ ? 1 : 0, keys_tmp_.get(), vals_tmp_.get(), stream_);
-  SortList(lb, (int)(4 * wh_));
+  LaunchSpatialKeys(feat, W_, H_, l1_ ? 1 : 0, keys_tmp_.get(), hist_tmp_.get(), stream_);
+  SortList(lb, 4);
   if (cons_dev) has_constraints_ = true;
   ++num_frames_;
 }
@@ -130,9 +129,9 @@ void DenseGraphHip::AddTemporal(const float* cur, const float* prev, const float
   lb.base_a = (int)(wh_ * t);
   lb.base_b = (int)(wh_ * (t - 1));
   lb.prev_idx.ensure(wh_);
-  LaunchTemporalEdges(cur, prev, flow, W_, H_, l1_ ? 1 : 0, is_virtual ? 1 : 0, keys_tmp_.get(),
-                      vals_tmp_.get(), lb.prev_idx.get(), stream_);
-  SortList(lb, (int)(9 * wh_));
+  LaunchTemporalKeys(cur, prev, flow, W_, H_, l1_ ? 1 : 0, is_virtual ? 1 : 0, keys_tmp_.get(),
+                     lb.prev_idx.get(), hist_tmp_.get(), stream_);
+  SortList(lb, 9);
 }
 
 void DenseGraphHip::FinishBuilding() { VSG_HIP(hipStreamSynchronize(stream_)); }

@@ -84,7 +84,7 @@ class DenseGraphHip {
 
   void EnsureScratch(size_t n_edges_max);
   void DebugHash(const char* where);
-  void SortList(ListBuf& lb, int n);
+  void SortList(ListBuf& lb, int per_px);
   void MergeConstrainedHostAssisted();
   NodeArrays nodes() {
     return NodeArrays{parent_.get(), desc_sz_.get(), cons_.get(), flags_.get()};
@@ -120,8 +120,8 @@ class DenseGraphHip {
   DevBuf<int32_t> bucket_base_dev_;
   std::vector<int32_t> bucket_base_host_;
   // temporaries for edge generation / sorting
-  DevBuf<uint16_t> keys_tmp_, keys_sorted_tmp_;
-  DevBuf<uint32_t> vals_tmp_;
+  DevBuf<uint16_t> keys_tmp_;
+  DevBuf<int32_t> hist_tmp_, hist_sums_;   // edge_sort.hip scratch
   DevBuf<int32_t> first_label_scratch_;
   // merge scratch
   DevBuf<int32_t> e_ra_, e_rb_, e_active_, e_apos_, a_ra_, a_rb_, seg_cnt_, seg_off_;

@@ -66,21 +66,26 @@ void LaunchConvertPlanar(const uint8_t* bgr, size_t stride, int W, int H, float*
                          hipStream_t s);
 void LaunchInterleavedToPlanar(const float* in, size_t n, float* planes, hipStream_t s);
 void LaunchPlanarToInterleaved(const float* planes, size_t n, float* out, hipStream_t s);
-void LaunchSpatialEdges(const float* feat, int W, int H, int l1, uint16_t* keys, uint32_t* vals,
+// ---- edge_sort.hip: edge keys + stable bucket (counting) sort of the edge slots -----------------
+// keys: u16 per slot (slot = pix*4+k / pix*9+k); hist: bin-major tile histograms (scratch of
+// EdgeSortHistInts ints, sums: EdgeSortSumInts ints).
+size_t EdgeSortHistInts(size_t n_px);
+size_t EdgeSortSumInts(size_t n_px);
+void LaunchSpatialKeys(const float* feat, int W, int H, int l1, uint16_t* keys, int32_t* hist,
+                       hipStream_t s);
+void LaunchTemporalKeys(const float* cur, const float* prev, const float* flow, int W, int H,
+                        int l1, int is_virtual, uint16_t* keys, int32_t* prev_idx, int32_t* hist,
                         hipStream_t s);
-void LaunchTemporalEdges(const float* cur, const float* prev, const float* flow, int W, int H,
-                         int l1, int is_virtual, uint16_t* keys, uint32_t* vals,
-                         int32_t* prev_idx, hipStream_t s);
-void LaunchBucketOffsets(const uint16_t* sorted_keys, int n, int* offsets, hipStream_t s);
+// offsets[kBucketSlots]: start of every bucket; slots_out: slot ids of the existing edges, stably
+// sorted by bucket.
+void LaunchBucketSort(const uint16_t* keys, size_t n_px, int per_px, int32_t* hist, int32_t* sums,
+                      int32_t* offsets, uint32_t* slots_out, hipStream_t s);
 void LaunchInitNodes(const float* feat, size_t n, int base, const int32_t* cons_in,
                      NodeArrays nodes, hipStream_t s);
 void LaunchInitVirtualNodes(const int32_t* labels, size_t n, int base, int num_labels,
                             int32_t* first_scratch, NodeArrays nodes, hipStream_t s);
 
 // ---- sort_scan.hip (hipCUB wrappers) --------------------------------------------------
-size_t SortPairsU16TempBytes(int n);
-void SortPairsU16(void* temp, size_t temp_bytes, const uint16_t* keys_in, uint16_t* keys_out,
-                  const uint32_t* vals_in, uint32_t* vals_out, int n, hipStream_t s);
 size_t SortPairsU32TempBytes(int n);
 void SortPairsU32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
                   const uint32_t* vals_in, uint32_t* vals_out, int n, int end_bit, hipStream_t s);

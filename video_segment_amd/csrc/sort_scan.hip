@@ -3,29 +3,12 @@
 // Only generic building blocks (stable LSD radix sort, exclusive scan, run-length encode,
 // unique) come from the library; every kernel that encodes the segmentation algorithm itself
 // is hand-written in build_kernels.hip / merge_*.hip / readout_kernels.hip.
-// The stable radix sort is what realises the reference's implicit counting sort: edges are
-// generated in (scan order, neighbour order) and pushed back into per-bucket vectors
-// (segmentation_graph.h:158-162), i.e. a stable sort by bucket index.
+// (The bucket sort of the edge slots is hand-written: edge_sort.hip.)
 #include <hipcub/hipcub.hpp>
 
 #include "device_graph.h"
 
 namespace vsg {
-
-size_t SortPairsU16TempBytes(int n) {
-  size_t bytes = 0;
-  VSG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint16_t*)nullptr,
-                                             (uint16_t*)nullptr, (const uint32_t*)nullptr,
-                                             (uint32_t*)nullptr, n, 0, 12));
-  return bytes;
-}
-
-void SortPairsU16(void* temp, size_t temp_bytes, const uint16_t* keys_in, uint16_t* keys_out,
-                  const uint32_t* vals_in, uint32_t* vals_out, int n, hipStream_t s) {
-  // 12 key bits: buckets 0..2047, 2048 (virtual edges), 0xFFF (non-existent border edges).
-  VSG_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in,
-                                             vals_out, n, 0, 12, s));
-}
 
 size_t SortPairsU32TempBytes(int n) {
   size_t bytes = 0;
