@@ -98,7 +98,10 @@ void vsg_stream_destroy(vsg_stream* s);
  *   flow   : backward flow, W*H interleaved (x,y) f32 (DenseFlowFrame::MatViewInterleaved), or
  *            NULL.  has_flow_stream says whether the unit has a flow stream at all; the flow of
  *            the first frame is ignored (segmentation_unit.cpp:124-130).
- *   mem    : VSG_MEM_HOST or VSG_MEM_DEVICE for both pointers.
+ *   mem    : VSG_MEM_HOST or VSG_MEM_DEVICE for both pointers.  Device buffers are read on the
+ *            handle's own (non-blocking) HIP stream: whatever produced them has to be complete
+ *            before the call (synchronise the producing stream or event first); they are only
+ *            read during the call.
  * *num_results = number of SegmentationDesc now available (0: frame buffered). */
 int vsg_stream_process_frame(vsg_stream* s, int flush, const uint8_t* bgr, size_t stride,
                              const float* flow, int has_flow_stream, int mem, int* num_results);

@@ -85,11 +85,10 @@ struct vsg_graph {
   std::unique_ptr<vsg::DenseGraphHip> g;
   std::unique_ptr<vsg::Preprocessor> pre;
   std::vector<std::shared_ptr<vsg::DevBuf<float>>> feats;     // per slice (null for virtual)
-  std::vector<std::shared_ptr<std::vector<float>>> flows_host;   // per slice
+  std::vector<std::shared_ptr<vsg::DevBuf<float>>> flows_dev;   // per slice (null: no flow)
   vsg::DevBuf<uint8_t> staging_bgr;
   vsg::DevBuf<float> staging_f32;
   vsg::DevBuf<int32_t> staging_ids;
-  vsg::DevBuf<float> flow_dev;
   vsg_timings timings;
   ~vsg_graph() {
     if (stream) (void)hipStreamSynchronize(stream);
@@ -256,7 +255,7 @@ void vsg_graph_destroy(vsg_graph* g) {
     g->staging_bgr.release();
     g->staging_f32.release();
     g->staging_ids.release();
-    g->flow_dev.release();
+    g->flows_dev.clear();
     if (g->stream) (void)hipStreamDestroy(g->stream);
     g->stream = nullptr;
   });
@@ -294,7 +293,7 @@ int vsg_graph_add_frame_bgr(vsg_graph* g, const uint8_t* bgr, size_t stride, int
     g->g->AddFrame(feat->get(), ids);
     VSG_HIP(hipStreamSynchronize(g->stream));
     g->feats.push_back(feat);
-    g->flows_host.push_back(nullptr);
+    g->flows_dev.push_back(nullptr);
   });
 }
 
@@ -316,7 +315,7 @@ int vsg_graph_add_frame_features(vsg_graph* g, const float* feat_in, const int32
     g->g->AddFrame(feat->get(), ids);
     VSG_HIP(hipStreamSynchronize(g->stream));
     g->feats.push_back(feat);
-    g->flows_host.push_back(nullptr);
+    g->flows_dev.push_back(nullptr);
   });
 }
 
@@ -337,7 +336,7 @@ int vsg_graph_add_virtual_frame(vsg_graph* g, const int32_t* constraint_ids, int
     g->g->AddVirtualFrame(ids, std::max(max_label, 1));
     VSG_HIP(hipStreamSynchronize(g->stream));
     g->feats.push_back(nullptr);
-    g->flows_host.push_back(nullptr);
+    g->flows_dev.push_back(nullptr);
   });
 }
 
@@ -349,20 +348,12 @@ int vsg_graph_add_temporal(vsg_graph* g, const float* flow, int is_virtual, int 
     VSG_REQUIRE(nf >= 2, VSG_ERR_STATE, "temporal edges need two slices");
     const float* fdev = nullptr;
     if (flow) {
-      auto fh = std::make_shared<std::vector<float>>(2 * g->wh);
-      g->flow_dev.ensure(2 * g->wh);
-      if (mem == VSG_MEM_HOST) {
-        std::memcpy(fh->data(), flow, 2 * g->wh * sizeof(float));
-        VSG_HIP(hipMemcpyAsync(g->flow_dev.get(), flow, 2 * g->wh * sizeof(float),
-                               hipMemcpyHostToDevice, g->stream));
-      } else {
-        VSG_HIP(hipMemcpyAsync(g->flow_dev.get(), flow, 2 * g->wh * sizeof(float),
-                               hipMemcpyDeviceToDevice, g->stream));
-        VSG_HIP(hipMemcpyAsync(fh->data(), flow, 2 * g->wh * sizeof(float), hipMemcpyDeviceToHost,
-                               g->stream));
-      }
-      g->flows_host[nf - 1] = fh;
-      fdev = g->flow_dev.get();
+      auto fd = std::make_shared<vsg::DevBuf<float>>(2 * g->wh);
+      VSG_HIP(hipMemcpyAsync(fd->get(), flow, 2 * g->wh * sizeof(float),
+                             mem == VSG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                             g->stream));
+      g->flows_dev[nf - 1] = fd;
+      fdev = fd->get();
     }
     const float* cur = g->feats[nf - 1] ? g->feats[nf - 1]->get() : nullptr;
     const float* prev = g->feats[nf - 2] ? g->feats[nf - 2]->get() : nullptr;
@@ -403,7 +394,7 @@ int vsg_graph_obtain_results(vsg_graph* g, int use_flows, int enforce_n4,
     DeviceGuard dg(g->device);
     std::vector<const float*> flows;
     if (use_flows) {
-      for (auto& f : g->flows_host) flows.push_back(f ? f->data() : nullptr);
+      for (auto& f : g->flows_dev) flows.push_back(f ? f->get() : nullptr);
     }
     g->g->ObtainResults(use_flows ? &flows : nullptr, enforce_n4 != 0,
                         enforce_spatial_connectedness != 0);

@@ -11,6 +11,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <functional>
+#include <thread>
 #include <unordered_set>
 
 namespace vsg {
@@ -380,7 +383,10 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   unsigned long long st[48] = {0};
   D2H(st, stats_.get(), 48, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
-  if (st[23] != 0) std::fprintf(stderr, "[vsg] chain self check: %llu mismatches\n", st[23]);
+  if (st[23] != 0) {
+    std::fprintf(stderr, "[vsg] chain self check: %llu mismatches\n", st[23]);
+    throw Error(-4 /* VSG_ERR_INTERNAL */, "merge worker: the chain self check found mismatches");
+  }
   if (st[22] != 0) throw Error(-4 /* VSG_ERR_INTERNAL */, "merge worker: a batch did not converge");
   if (getenv("VSG_DEBUG_STATS")) {
     std::fprintf(stderr, "[vsg] wave: edges %llu batches %llu rounds %llu generic %llu (solo %llu) chain %llu "
@@ -739,11 +745,28 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
 // ---------------------------------------------------------------------------------------------
 // ObtainResults + DetermineNeighborIds
 // ---------------------------------------------------------------------------------------------
-void DenseGraphHip::ObtainResults(const std::vector<const float*>* host_flows, bool enforce_n4,
+void DenseGraphHip::SampleFlows(const std::vector<FlowRequest>& req,
+                                const std::vector<const float*>& dev_flows,
+                                std::vector<float>* samples) {
+  const int n = (int)req.size();
+  samples->assign(2 * (size_t)n, 0.f);
+  if (n == 0) return;
+  static_assert(sizeof(FlowRequest) == 3 * sizeof(int32_t), "FlowRequest is three ints");
+  flow_req_dev_.ensure(3 * (size_t)n);
+  flow_samples_dev_.ensure((size_t)n);
+  flow_ptrs_dev_.ensure(dev_flows.size());
+  H2D(flow_req_dev_.get(), reinterpret_cast<const int32_t*>(req.data()), 3 * (size_t)n, stream_);
+  H2D(flow_ptrs_dev_.get(), dev_flows.data(), dev_flows.size(), stream_);
+  LaunchGatherFlow(flow_req_dev_.get(), n, flow_ptrs_dev_.get(), W_, flow_samples_dev_.get(), stream_);
+  D2H(reinterpret_cast<float2*>(samples->data()), flow_samples_dev_.get(), (size_t)n, stream_);
+  VSG_HIP(hipStreamSynchronize(stream_));
+}
+
+void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bool enforce_n4,
                                   bool enforce_spatial_connectedness) {
   const double t_start = NowMs();
   const size_t N = wh_ * (size_t)num_frames_;
-  if (host_flows) VSG_REQUIRE((int)host_flows->size() == num_frames_, -1, "one flow per frame");
+  if (dev_flows) VSG_REQUIRE((int)dev_flows->size() == num_frames_, -1, "one flow per frame");
 
   // 1. representative key per node (FlattenUnionFind).
   LaunchFlatten(nodes(), N, label_uf_.get(), stream_);
@@ -884,26 +907,64 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* host_flows, b
   std::vector<int32_t> rl_lx, rl_rx, rl_new;
   int next_new_key = (int)N;
   if (enforce_spatial_connectedness) {
-    std::vector<const float*> flows;
-    const bool have_flows = host_flows != nullptr;
-    if (have_flows) flows = *host_flows;
+    const bool have_flows = dev_flows != nullptr;
     const int num_regions = (int)regions_.size();
-    // Phase A (pure host, per region): split into tubes.  Only regions that really split need
-    // the representative of their tubes' first pixel, so those few node labels are gathered from
-    // the device afterwards instead of copying the whole label volume.
+    // Phase A (host, one task per region): components and shapes of every slice, the list of
+    // flow samples the matching will read; one gather on the device; then the matching.  Only
+    // regions that really split need the representative of their tubes' first pixel, so those
+    // few node labels are gathered from the device afterwards instead of copying the whole
+    // label volume.
     std::vector<std::pair<int, TubeResult>> split;
     {
-      TubeResult tr;
+      std::vector<TubeSplitter> splitters((size_t)num_regions);
+      std::vector<std::vector<FlowRequest>> reqs((size_t)num_regions);
+      auto parallel_regions = [&](const std::function<void(int)>& fn) {
+        std::atomic<int> next(0);
+        auto work = [&]() {
+          for (int r = next.fetch_add(1); r < num_regions; r = next.fetch_add(1)) fn(r);
+        };
+        const int hw = (int)std::thread::hardware_concurrency();
+        const int nt = std::max(1, std::min({num_regions / 64, hw > 0 ? hw : 1, 16}));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread& t : pool) t.join();
+      };
+      parallel_regions([&](int r) {
+        if (regions_[r].has_raster) splitters[r].Prepare(regions_[r].raster, have_flows ? &reqs[r] : nullptr);
+      });
+      std::vector<size_t> req_off((size_t)num_regions + 1, 0);
+      for (int r = 0; r < num_regions; ++r) req_off[r + 1] = req_off[r] + reqs[r].size();
+      std::vector<float> samples;
+      if (have_flows) {
+        std::vector<FlowRequest> all;
+        all.reserve(req_off[num_regions]);
+        for (int r = 0; r < num_regions; ++r) all.insert(all.end(), reqs[r].begin(), reqs[r].end());
+        SampleFlows(all, *dev_flows, &samples);
+      }
+      std::vector<TubeResult> results((size_t)num_regions);
+      parallel_regions([&](int r) {
+        if (!regions_[r].has_raster || !splitters[r].MaySplit()) return;
+        splitters[r].Finish(W_, H_, have_flows ? samples.data() + 2 * req_off[r] : nullptr, &results[r]);
+      });
       for (int r = 0; r < num_regions; ++r) {
-        if (!regions_[r].has_raster) continue;
-        SplitRegionIntoTubes(regions_[r].raster, W_, H_, flows, have_flows, &tr);
-        if (tr.tubes.size() <= 1) continue;
+        if (results[r].tubes.size() <= 1) continue;
         split.emplace_back(r, TubeResult());
-        split.back().second.tubes.swap(tr.tubes);
-        split.back().second.areas.swap(tr.areas);
-        split.back().second.tube_to_keep = tr.tube_to_keep;
+        split.back().second.tubes.swap(results[r].tubes);
+        split.back().second.areas.swap(results[r].areas);
+        split.back().second.tube_to_keep = results[r].tube_to_keep;
       }
     }
+    // A region whose rasterization was replaced by an earlier one's tube (see phase B) is split
+    // again at its turn, with its own small gather.
+    auto split_again = [&](const Raster3D& raster, TubeResult* out) {
+      TubeSplitter ts;
+      std::vector<FlowRequest> req;
+      ts.Prepare(raster, have_flows ? &req : nullptr);
+      std::vector<float> samples;
+      if (have_flows) SampleFlows(req, *dev_flows, &samples);
+      ts.Finish(W_, H_, have_flows ? samples.data() : nullptr, out);
+    };
     auto first_node_of = [&](const Raster3D& tube) {
       const RasterSlice& s0 = tube[0];
       return (int32_t)((size_t)s0.frame * wh_ + (size_t)s0.raster[0].y * W_ + s0.raster[0].lx);
@@ -940,7 +1001,7 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* host_flows, b
       if (dirty[r]) {
         if (cached) ++si;
         if (!regions_[r].has_raster) continue;
-        SplitRegionIntoTubes(regions_[r].raster, W_, H_, flows, have_flows, &local);
+        split_again(regions_[r].raster, &local);
         if (local.tubes.size() <= 1) continue;
         std::vector<int32_t> nodes_needed;
         for (auto& tube : local.tubes) nodes_needed.push_back(first_node_of(tube));

@@ -56,9 +56,10 @@ class DenseGraphHip {
     SegmentLists(0, false, 1);
     spatial_pass_done_ = true;
   }
-  // ObtainResults + DetermineNeighborIds.  host_flows: per slice W*H*2 f32 host pointers (may
-  // contain nullptr) or null.
-  void ObtainResults(const std::vector<const float*>* host_flows, bool enforce_n4,
+  // ObtainResults + DetermineNeighborIds.  flows: per slice W*H*2 f32 *device* pointers (may be
+  // null for slices without flow) or null: the tube analysis samples them at a few thousand
+  // points (FindPreviousTube), so the fields never leave the device.
+  void ObtainResults(const std::vector<const float*>* dev_flows, bool enforce_n4,
                      bool enforce_spatial_connectedness);
 
   std::vector<RegionInfo>& regions() { return regions_; }
@@ -135,6 +136,12 @@ class DenseGraphHip {
   DevBuf<unsigned long long> stats_;
   DevBuf<uint8_t> cub_temp_;
   size_t scratch_edges_ = 0;
+  // flow sampling for the tube analysis
+  DevBuf<int32_t> flow_req_dev_;
+  DevBuf<float2> flow_samples_dev_;
+  DevBuf<const float*> flow_ptrs_dev_;
+  void SampleFlows(const std::vector<FlowRequest>& req, const std::vector<const float*>& dev_flows,
+                   std::vector<float>* samples);
   // readout scratch
   DevBuf<int32_t> row_counts_, row_offsets_;
   DevBuf<int32_t> iv_label_, iv_lx_, iv_rx_;

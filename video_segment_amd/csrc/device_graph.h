@@ -208,6 +208,10 @@ void LaunchConstrainedRoots(NodeArrays nodes, int begin, int end, int32_t* flag_
 void LaunchCompactI32(const int32_t* flags, const int32_t* offsets, const int32_t* values, int n,
                       int32_t* out, hipStream_t s);
 void LaunchGatherI32(const int32_t* src, const int32_t* idx, int n, int32_t* out, hipStream_t s);
+// out[i] = flows[req[3i]][req[3i+1] * W + req[3i+2]] (interleaved x, y); flows: device array of
+// per-slice device pointers (null: no flow for the slice).
+void LaunchGatherFlow(const int32_t* req, int n, const float* const* flows, int W, float2* out,
+                      hipStream_t s);
 
 void LaunchNonzeroFlags(const int32_t* a, int n, int32_t* flags, hipStream_t s);
 void LaunchCompactIndexValue(const int32_t* flags, const int32_t* offsets, const int32_t* values,

@@ -9,6 +9,7 @@
 #define VSG_HOST_MODEL_H_
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -77,6 +78,26 @@ struct TubeResult {
   std::vector<float> areas;
   int tube_to_keep = -1;
 };
+// One point where the matching reads the backward flow: flow[frame](y, x).
+struct FlowRequest {
+  int frame, y, x;
+};
+// The analysis in two steps (see postprocess.cpp): Prepare lists the flow samples it needs,
+// Finish takes them (2 floats per request, in request order; null: no flow).
+class TubeSplitter {
+ public:
+  TubeSplitter();
+  ~TubeSplitter();
+  TubeSplitter(TubeSplitter&&) noexcept;
+  void Prepare(const Raster3D& raster, std::vector<FlowRequest>* requests);
+  bool MaySplit() const;
+  void Finish(int W, int H, const float* flow_xy, TubeResult* out);
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+};
+// Both steps with host-resident flow fields (flows[frame] = W*H*2 f32).
 void SplitRegionIntoTubes(const Raster3D& raster, int W, int H,
                           const std::vector<const float*>& flows, bool have_flows,
                           TubeResult* out);

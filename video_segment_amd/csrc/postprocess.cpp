@@ -366,26 +366,56 @@ int ClosestTube(const Tube& t, const std::vector<Tube>& all, int skip) {   // .c
 
 }  // namespace
 
-// dense_segmentation_graph.h:666-861
-void SplitRegionIntoTubes(const Raster3D& raster, int W, int H,
-                          const std::vector<const float*>& flows, bool have_flows,
-                          TubeResult* out) {
+// dense_segmentation_graph.h:666-861, in two steps so that the backward flow can be sampled
+// where it lives (on the device): Prepare computes what does not depend on the flow -- the N4
+// components of every slice with their shape descriptors -- and lists the points the matching
+// will read (FindPreviousTube reads flow[frame](int(cy), int(cx)) for every component of every
+// slice after the region's first one, whatever the earlier decisions were); Finish does the
+// temporal matching with those samples.
+struct TubeSplitter::Impl {
+  std::vector<std::vector<TSlice>> slices;   // per raster slice: components, ordered by first interval
+};
+
+TubeSplitter::TubeSplitter() : impl_(new Impl) {}
+TubeSplitter::~TubeSplitter() {}
+TubeSplitter::TubeSplitter(TubeSplitter&& o) noexcept : impl_(std::move(o.impl_)) {}
+
+void TubeSplitter::Prepare(const Raster3D& raster, std::vector<FlowRequest>* requests) {
+  impl_->slices.clear();
+  impl_->slices.reserve(raster.size());
+  for (const RasterSlice& rs : raster) {
+    std::vector<Raster> comps;
+    SplitComponentsN4(rs.raster, &comps);
+    impl_->slices.emplace_back(comps.size());
+    std::vector<TSlice>& sl = impl_->slices.back();
+    for (size_t c = 0; c < comps.size(); ++c) {
+      sl[c].frame = rs.frame;
+      sl[c].raster.swap(comps[c]);
+      sl[c].Recompute();
+      if (impl_->slices.size() > 1 && requests) {
+        requests->push_back(FlowRequest{rs.frame, (int)sl[c].shape.center.y, (int)sl[c].shape.center.x});
+      }
+    }
+  }
+}
+
+bool TubeSplitter::MaySplit() const {
+  // One component per slice and consecutive frames can still split (a tube is only continued if
+  // sizes and centres agree), so every region with more than one slice component goes through
+  // Finish; a region with a single slice has exactly one tube.
+  return impl_->slices.size() > 1 || (impl_->slices.size() == 1 && impl_->slices[0].size() > 1);
+}
+
+void TubeSplitter::Finish(int W, int H, const float* flow_xy, TubeResult* out) {
   out->tubes.clear();
   out->areas.clear();
   out->tube_to_keep = -1;
   std::vector<Tube> done, active;
   const float inv_diam = (float)(1.0f / std::hypot((double)W, (double)H));
+  size_t sample = 0;
 
-  for (const RasterSlice& rs : raster) {
-    const int frame = rs.frame;
-    std::vector<Raster> comps;
-    SplitComponentsN4(rs.raster, &comps);
-    std::vector<TSlice> slices(comps.size());
-    for (size_t c = 0; c < comps.size(); ++c) {
-      slices[c].frame = frame;
-      slices[c].raster.swap(comps[c]);
-      slices[c].Recompute();
-    }
+  for (std::vector<TSlice>& slices : impl_->slices) {
+    const int frame = slices.empty() ? -1 : slices[0].frame;
     if (active.empty()) {
       for (TSlice& s : slices) active.push_back(Tube{std::move(s)});
       continue;
@@ -395,11 +425,11 @@ void SplitRegionIntoTubes(const Raster3D& raster, int W, int H,
     for (TSlice& s : slices) {
       // FindPreviousTube, dense_segmentation_graph.h:601-629
       V2 c = s.shape.center;
-      if (have_flows) {
-        const float* flow = flows[frame];
-        const float* fp = flow + ((size_t)(int)c.y * W) * 2 + 2 * (int)c.x;
+      if (flow_xy) {
+        const float* fp = flow_xy + 2 * sample;
         c = Add(c, V2{fp[0], fp[1]});
       }
+      ++sample;
       float best = std::numeric_limits<float>::max();
       float best_idx = -1;   // float in the reference
       for (int k = 0; k < (int)active.size(); ++k) {
@@ -497,6 +527,25 @@ void SplitRegionIntoTubes(const Raster3D& raster, int W, int H,
       out->tubes[k].back().raster.swap(s.raster);
     }
   }
+  impl_->slices.clear();
+}
+
+void SplitRegionIntoTubes(const Raster3D& raster, int W, int H,
+                          const std::vector<const float*>& flows, bool have_flows,
+                          TubeResult* out) {
+  TubeSplitter ts;
+  std::vector<FlowRequest> req;
+  ts.Prepare(raster, &req);
+  std::vector<float> samples;
+  if (have_flows) {
+    samples.resize(2 * req.size());
+    for (size_t i = 0; i < req.size(); ++i) {
+      const float* fp = flows[(size_t)req[i].frame] + ((size_t)req[i].y * W + req[i].x) * 2;
+      samples[2 * i] = fp[0];
+      samples[2 * i + 1] = fp[1];
+    }
+  }
+  ts.Finish(W, H, have_flows ? samples.data() : nullptr, out);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -344,6 +344,24 @@ void LaunchGatherI32(const int32_t* src, const int32_t* idx, int n, int32_t* out
   VSG_HIP(hipGetLastError());
 }
 
+// Backward flow at the points the tube analysis reads (one (frame, y, x) request each).
+__global__ __launch_bounds__(256) void k_gather_flow(const int32_t* __restrict__ req, int n,
+                                                      const float* const* __restrict__ flows, int W,
+                                                      float2* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int frame = req[3 * i], y = req[3 * i + 1], x = req[3 * i + 2];
+  const float* f = flows[frame];
+  out[i] = f ? reinterpret_cast<const float2*>(f)[(size_t)y * W + x] : make_float2(0.f, 0.f);
+}
+
+void LaunchGatherFlow(const int32_t* req, int n, const float* const* flows, int W, float2* out,
+                      hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather_flow, dim3((n + 255) / 256), dim3(256), 0, s, req, n, flows, W, out);
+  VSG_HIP(hipGetLastError());
+}
+
 // Small helpers for compacting sparse N-sized arrays.
 __global__ __launch_bounds__(256) void k_nonzero_flags(const int32_t* __restrict__ a, int n,
                                                         int32_t* __restrict__ flags) {

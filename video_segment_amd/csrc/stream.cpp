@@ -113,8 +113,6 @@ DenseSegmentationHip::DenseSegmentationHip(const vsg_options& o, int W, int H)
   constraint_frames_ = std::min(options_.num_constraint_frames, overlap_frames_ - 1);
   // The caller (capi.cpp) has bound this thread to the handle's device.
   VSG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-  VSG_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-  VSG_HIP(hipEventCreateWithFlags(&flow_ready_, hipEventDisableTiming));
   graph_.reset(new DenseGraphHip(W, H, options_.chunk_size + 1, options_.color_distance == 0, stream_));
   pre_.reset(new Preprocessor(W, H, stream_));
   std::memset(&last_timings_, 0, sizeof(last_timings_));
@@ -124,11 +122,8 @@ DenseSegmentationHip::DenseSegmentationHip(const vsg_options& o, int W, int H)
 DenseSegmentationHip::~DenseSegmentationHip() {
   if (stream_) {
     (void)hipStreamSynchronize(stream_);
-    if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
     graph_.reset();
     pre_.reset();
-    if (flow_ready_) (void)hipEventDestroy(flow_ready_);
-    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     (void)hipStreamDestroy(stream_);
   }
 }
@@ -171,26 +166,15 @@ int DenseSegmentationHip::ProcessFrame(bool flush, const uint8_t* bgr, size_t st
       flow_stream_seen_ = true;
       if (input_frames_ == 0 && !pending_import_) {
         flow_dev_buffer_.push_back(nullptr);
-        flow_host_buffer_.push_back(nullptr);
       } else {
         VSG_REQUIRE(flow != nullptr, -1, "Flow always has to be passed or be absent.");
+        // Deep copy (the caller's buffer is only valid during the call); the field stays on the
+        // device: the edge kernels read it, the tube analysis samples it there.
         DevPlane fd(new DevBuf<float>(2 * wh_));
-        HostFlow fh = AcquireHostFlow();
-        if (mem == VSG_MEM_HOST) {
-          std::memcpy(fh->data(), flow, 2 * wh_ * sizeof(float));
-          VSG_HIP(hipMemcpyAsync(fd->get(), flow, 2 * wh_ * sizeof(float), hipMemcpyHostToDevice,
-                                 stream_));
-        } else {
-          VSG_HIP(hipMemcpyAsync(fd->get(), flow, 2 * wh_ * sizeof(float),
-                                 hipMemcpyDeviceToDevice, stream_));
-          // host copy from our own device copy (the caller's buffer is only valid during the call)
-          VSG_HIP(hipEventRecord(flow_ready_, stream_));
-          VSG_HIP(hipStreamWaitEvent(copy_stream_, flow_ready_, 0));
-          VSG_HIP(hipMemcpyAsync(fh->data(), fd->get(), 2 * wh_ * sizeof(float),
-                                 hipMemcpyDeviceToHost, copy_stream_));
-        }
+        VSG_HIP(hipMemcpyAsync(fd->get(), flow, 2 * wh_ * sizeof(float),
+                               mem == VSG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                               stream_));
         flow_dev_buffer_.push_back(fd);
-        flow_host_buffer_.push_back(fh);
       }
     }
 
@@ -202,13 +186,9 @@ int DenseSegmentationHip::ProcessFrame(bool flush, const uint8_t* bgr, size_t st
       if (has_flow_stream) {
         // keep [empty, flow] layout like after a chunk boundary
         DevPlane fd = flow_dev_buffer_.back();
-        HostFlow fh = flow_host_buffer_.back();
         flow_dev_buffer_.clear();
-        flow_host_buffer_.clear();
         flow_dev_buffer_.push_back(nullptr);
-        flow_host_buffer_.push_back(nullptr);
         flow_dev_buffer_.push_back(fd);
-        flow_host_buffer_.push_back(fh);
       }
       curr_chunk_start_ = 1;
       StartConstrainedGraph(halo_ids_dev_[0].get(), halo_ids_dev_[1].get(), pending_max_label_);
@@ -269,24 +249,11 @@ void DenseSegmentationHip::ChunkBoundaryOutput(bool flush) {
   overlap_segmentations_.clear();
 }
 
-DenseSegmentationHip::HostFlow DenseSegmentationHip::AcquireHostFlow() {
-  std::unique_ptr<HostFlowBuf> b;
-  if (!flow_pool_.empty()) {
-    b = std::move(flow_pool_.back());
-    flow_pool_.pop_back();
-  } else {
-    b.reset(new HostFlowBuf());
-    b->buf.ensure(2 * wh_);
-  }
-  return HostFlow(b.release(), [this](HostFlowBuf* p) { flow_pool_.emplace_back(p); });
-}
-
 void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
-  VSG_HIP(hipStreamSynchronize(copy_stream_));   // host copies of the flow fields
-  std::vector<const float*> flows;
-  const bool have_flows = !flow_host_buffer_.empty();
+  std::vector<const float*> flows;   // device pointers, one per buffered slice
+  const bool have_flows = !flow_dev_buffer_.empty();
   if (have_flows) {
-    for (const auto& f : flow_host_buffer_) flows.push_back(f ? f->data() : nullptr);
+    for (const auto& f : flow_dev_buffer_) flows.push_back(f ? f->get() : nullptr);
   }
   // RunOverSegmentation (segmentation.cpp:272-303)
   graph_->FinishBuilding();
@@ -385,8 +352,6 @@ void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
   feature_buffer_.erase(feature_buffer_.begin(), feature_buffer_.begin() + last_output_frame);
   if (!flow_dev_buffer_.empty()) {
     flow_dev_buffer_.erase(flow_dev_buffer_.begin(), flow_dev_buffer_.begin() + last_output_frame);
-    flow_host_buffer_.erase(flow_host_buffer_.begin(),
-                            flow_host_buffer_.begin() + last_output_frame);
   }
   curr_chunk_start_ = flush ? 0 : 1;
   if (!flush) {
@@ -394,7 +359,6 @@ void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
     feature_buffer_[0].reset();
     if (!flow_dev_buffer_.empty()) {
       flow_dev_buffer_[0].reset();
-      flow_host_buffer_[0].reset();
     }
   }
   ++chunk_id_;

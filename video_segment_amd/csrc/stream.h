@@ -62,16 +62,6 @@ class DenseSegmentationHip {
 
  private:
   typedef std::shared_ptr<DevBuf<float>> DevPlane;
-  // Host copy of a flow field (the tube analysis samples it at component centres).  Pinned so that
-  // the device->host copy of device-resident flow runs at full PCIe rate and asynchronously;
-  // recycled through flow_pool_.
-  struct HostFlowBuf {
-    PinnedBuf<float> buf;
-    float* data() const { return buf.get(); }
-  };
-  typedef std::shared_ptr<HostFlowBuf> HostFlow;
-  HostFlow AcquireHostFlow();
-
   int MinRegionSize() const;
   void ChunkBoundaryOutput(bool flush);
   void SegmentAndOutputChunk(bool flush);
@@ -83,10 +73,6 @@ class DenseSegmentationHip {
   int W_, H_;
   size_t wh_;
   hipStream_t stream_ = nullptr;
-  // Device-resident flow is copied to the host (tube analysis) on its own stream, behind an event
-  // of the main stream; it is only waited for at the chunk boundary.
-  hipStream_t copy_stream_ = nullptr;
-  hipEvent_t flow_ready_ = nullptr;
   std::unique_ptr<DenseGraphHip> graph_;
   std::unique_ptr<Preprocessor> pre_;
   bool graph_open_ = false;
@@ -101,10 +87,8 @@ class DenseSegmentationHip {
   int curr_chunk_start_ = 0;
   bool assigned_constrained_ids_ = false;
 
-  std::vector<std::unique_ptr<HostFlowBuf>> flow_pool_;   // declared before its users
   std::vector<DevPlane> feature_buffer_;
-  std::vector<DevPlane> flow_dev_buffer_;     // W*H*2 f32, null = empty flow
-  std::vector<HostFlow> flow_host_buffer_;
+  std::vector<DevPlane> flow_dev_buffer_;     // W*H*2 f32 on the device, null = empty flow
   bool flow_stream_seen_ = false;
   int64_t frames_fed_ = 0;   // frames handed to this handle (has_flow_stream must not change)
 
