@@ -57,6 +57,9 @@ typedef struct vsg_options {
   int color_distance;                 /* 0 COLOR_DISTANCE_L1, 1 COLOR_DISTANCE_L2 (default) */
   int device;                         /* HIP device ordinal, -1 = current device            */
   int two_stage_oversegment;          /* 0 (default); 1 = SegmentGraphSpatially first         */
+  int compute_vectorization;          /* 0 (default); 1 = region boundaries as polygons over a
+                                         shared vector mesh in every SegmentationDesc
+                                         (segmentation.cpp:527-532, seg_tree --over_segment)   */
 } vsg_options;
 
 /* Per-stage device time of the last segmented chunk, milliseconds (HIP events on the handle's
@@ -87,6 +90,13 @@ int vsg_version(void);
 void vsg_default_options(vsg_options* o);
 /* Number of visible HIP devices (0 => every create call fails loudly). */
 int vsg_device_count(void);
+
+/* Host-only parity hook (no HIP device needed): the SegmentationDesc -- Region2D list sorted by id,
+ * boundaries vectorised as with compute_vectorization -- of a frame given as a W*H region-id image
+ * (ids >= 0, N4-connected regions).  BoundaryComputation::ComputeBoundary + ComputeVectorization,
+ * segmentation/boundary.cpp:121-244, 514-608.  *data stays valid until the thread's next call. */
+int vsg_vectorize_id_image(const int32_t* ids, int width, int height, const uint8_t** data,
+                           size_t* len);
 
 /* ---- seam 2: DenseSegmentation ------------------------------------------------------------ */
 /* DenseSegmentation::DenseSegmentation(options, frame_width, frame_height), cpp:50-106. */

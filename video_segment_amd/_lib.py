@@ -29,6 +29,7 @@ class VsgOptions(C.Structure):
         ("color_distance", C.c_int),
         ("device", C.c_int),
         ("two_stage_oversegment", C.c_int),
+        ("compute_vectorization", C.c_int),
     ]
 
 
@@ -56,6 +57,7 @@ class VsgTimings(C.Structure):
 # Every symbol include/vsg.h declares (checked by tests/test_capi_symbols.py).
 EXPORTED_SYMBOLS = [
     "vsg_last_error", "vsg_version", "vsg_default_options", "vsg_device_count",
+    "vsg_vectorize_id_image",
     "vsg_stream_create", "vsg_stream_destroy", "vsg_stream_process_frame", "vsg_stream_chunk_size",
     "vsg_stream_result_bytes", "vsg_stream_result_id_image", "vsg_stream_last_merge_stats",
     "vsg_stream_last_timings", "vsg_stream_last_smoothed", "vsg_stream_export_halo",
@@ -104,6 +106,7 @@ def lib():
     L.vsg_version.restype = C.c_int
     L.vsg_default_options.argtypes = [C.POINTER(VsgOptions)]
     L.vsg_device_count.restype = C.c_int
+    L.vsg_vectorize_id_image.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.vsg_stream_create.argtypes = [C.POINTER(VsgOptions), C.c_int, C.c_int, C.POINTER(vp)]
     L.vsg_stream_destroy.argtypes = [vp]
     L.vsg_stream_process_frame.argtypes = [vp, C.c_int, vp, C.c_size_t, vp, C.c_int, C.c_int,

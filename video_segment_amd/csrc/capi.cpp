@@ -1,4 +1,5 @@
 // capi.cpp -- extern "C" entry points declared in include/vsg.h.
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -114,12 +115,52 @@ void vsg_default_options(vsg_options* o) {
   o->color_distance = 1;
   o->device = -1;
   o->two_stage_oversegment = 0;
+  o->compute_vectorization = 0;
 }
 
 int vsg_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+// ---- host-only parity hook ---------------------------------------------------------------
+int vsg_vectorize_id_image(const int32_t* ids, int width, int height, const uint8_t** data,
+                           size_t* len) {
+  return Guard([&] {
+    VSG_REQUIRE(ids && data && len && width >= 1 && height >= 1, VSG_ERR_INVALID, "bad argument");
+    thread_local std::string wire;
+    // Region2D list sorted by id with scan-order rasterizations, as RetrieveSegmentation3D emits.
+    std::vector<std::pair<int32_t, vsg::Interval>> runs;
+    for (int y = 0; y < height; ++y) {
+      const int32_t* row = ids + (size_t)y * width;
+      for (int x = 0; x < width;) {
+        int x2 = x;
+        while (x2 + 1 < width && row[x2 + 1] == row[x]) ++x2;
+        VSG_REQUIRE(row[x] >= 0, VSG_ERR_INVALID, "negative region id");
+        runs.emplace_back(row[x], vsg::Interval{y, x, x2});
+        x = x2 + 1;
+      }
+    }
+    std::stable_sort(runs.begin(), runs.end(),
+                     [](const std::pair<int32_t, vsg::Interval>& a,
+                        const std::pair<int32_t, vsg::Interval>& b) { return a.first < b.first; });
+    vsg::SegDesc d;
+    d.frame_width = width;
+    d.frame_height = height;
+    for (const auto& r : runs) {
+      if (d.regions.empty() || d.regions.back().id != r.first) {
+        d.regions.emplace_back();
+        d.regions.back().id = r.first;
+      }
+      d.regions.back().raster.push_back(r.second);
+    }
+    for (auto& r : d.regions) vsg::MomentsFromRaster(r.raster, &r.moments);
+    vsg::ComputeFrameVectorization(&d);
+    wire = vsg::EncodeSegDesc(d);
+    *data = reinterpret_cast<const uint8_t*>(wire.data());
+    *len = wire.size();
+  });
 }
 
 // ---- stream ------------------------------------------------------------------------------

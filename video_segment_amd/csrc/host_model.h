@@ -42,10 +42,16 @@ struct RegionInfo {
   int region_id = -1;
 };
 
+struct PolygonOut {
+  std::vector<int> coord_idx;   // index of the point's x coordinate in SegDesc::vector_mesh
+  bool hole = false;
+};
+
 struct Region2DOut {
   int id = 0;
   Raster raster;
   Moments moments;
+  std::vector<PolygonOut> polygons;   // Region2D.vectorization (compute_vectorization)
 };
 
 struct CompoundOut {
@@ -61,7 +67,13 @@ struct SegDesc {
   int frame_width = 0, frame_height = 0;
   int chunk_size = 0, overlap_start = 0, chunk_id = -1, hierarchy_frame_idx = 0;
   int connectedness = 1;   // N4_CONNECT = 1, N8_CONNECT = 2
+  bool has_vector_mesh = false;
+  std::vector<float> vector_mesh;   // x, y pairs (SegmentationDesc.vector_mesh)
 };
+
+// Boundaries of all regions of a frame and their vectorization (boundary.cpp): fills
+// Region2DOut::polygons and SegDesc::vector_mesh.  Regions have to be sorted by id.
+void ComputeFrameVectorization(SegDesc* desc);
 
 // Raster utilities (postprocess.cpp).
 int RasterArea(const Raster& r);                                   // segmentation_util.cpp:644-650

@@ -608,6 +608,19 @@ std::string EncodeSegDesc(const SegDesc& d) {
     PutFloat(&tmp, 5, r.moments.xy);
     PutFloat(&tmp, 6, r.moments.yy);
     PutMsg(&region, 5, tmp);                        // Region2D.shape_moments = 5
+    if (!r.polygons.empty()) {                      // Region2D.vectorization = 6
+      std::string vec, poly, packed;
+      for (const PolygonOut& pg : r.polygons) {
+        poly.clear();
+        packed.clear();
+        for (int idx : pg.coord_idx) PutVarint(&packed, (uint64_t)(int64_t)idx);
+        if (!packed.empty()) PutMsg(&poly, 1, packed);   // Polygon.coord_idx = 1 [packed]
+        PutVarint(&poly, ((uint64_t)2 << 3) | 0);       // Polygon.hole = 2 (always set)
+        PutVarint(&poly, pg.hole ? 1 : 0);
+        PutMsg(&vec, 1, poly);                          // Vectorization.polygon = 1
+      }
+      PutMsg(&region, 6, vec);
+    }
     PutMsg(&out, 2, region);                        // SegmentationDesc.region = 2
   }
   if (d.has_hierarchy) {
@@ -629,6 +642,14 @@ std::string EncodeSegDesc(const SegDesc& d) {
   PutInt(&out, 7, d.overlap_start);
   PutInt(&out, 8, d.chunk_id);
   PutInt(&out, 9, d.hierarchy_frame_idx);
+  if (d.has_vector_mesh) {                          // SegmentationDesc.vector_mesh = 11
+    std::string mesh;
+    if (!d.vector_mesh.empty()) {                   // VectorMesh.coord = 1 [packed]
+      std::string packed((const char*)d.vector_mesh.data(), d.vector_mesh.size() * sizeof(float));
+      PutMsg(&mesh, 1, packed);
+    }
+    PutMsg(&out, 11, mesh);
+  }
   PutInt(&out, 12, d.connectedness);
   (void)VarintLen;
   return out;

@@ -425,6 +425,8 @@ void DenseSegmentationHip::Retrieve(int frame, bool output_hierarchy, SegDesc* d
                 [](const CompoundOut& a, const CompoundOut& b) { return a.id < b.id; });
     }
   }
+  // segmentation.cpp:527-532
+  if (options_.compute_vectorization) ComputeFrameVectorization(desc);
 }
 
 const std::string& DenseSegmentationHip::result_bytes(int i) {

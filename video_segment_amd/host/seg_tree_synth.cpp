@@ -189,7 +189,8 @@ struct Flags {
   bool flow = true;
   std::string input_file;
   bool use_pipeline = true;
-  bool over_segment = true;        // this driver stops after the dense over-segmentation
+  bool over_segment = false;       // as in the reference: also turns the vectorization on (this
+                                   // driver always stops after the dense over-segmentation)
   bool write_to_file = false;      // writes <input_file>.pb (or --output_file)
   bool save_flow = false;          // writes <input base>.flow from the synthetic source
   // dense_segmentation.cpp
@@ -275,10 +276,6 @@ int main(int argc, char** argv) {
   Flags FLAGS;
   if (!ParseFlags(argc, argv, &FLAGS)) return 2;
   if (!FLAGS.read_pb.empty()) return ReadBack(FLAGS.read_pb);
-  if (!FLAGS.over_segment) {
-    std::fprintf(stderr, "ERROR: only the dense over-segmentation is built here (--over_segment)\n");
-    return 2;
-  }
   bool use_flow = FLAGS.flow;
   int frames = FLAGS.frames;
   std::string flow_file = FLAGS.flow_file;
@@ -332,6 +329,7 @@ int main(int argc, char** argv) {
   DenseSegmentationOptions seg_options;
   seg_options.chunk_size = FLAGS.chunk_size;
   seg_options.two_stage_oversegment = FLAGS.two_stage_oversegment;
+  if (FLAGS.over_segment) seg_options.compute_vectorization = true;   // seg_tree.cpp:202-204
   // dense_segmentation.cpp:79-101: the flags override the options.
   seg_options.frac_min_region_size = (float)FLAGS.dense_min_region_size;
   if (FLAGS.dense_smoothing == "none") seg_options.presmoothing = DenseSegmentationOptions::PRESMOOTH_NONE;

@@ -139,6 +139,7 @@ DenseSegmentation::DenseSegmentation(const DenseSegmentationOptions& options, in
   o.enforce_spatial_connectedness = options_.enforce_spatial_connectedness ? 1 : 0;
   o.color_distance = (int)options_.color_distance;
   o.two_stage_oversegment = options_.two_stage_oversegment ? 1 : 0;
+  o.compute_vectorization = options_.compute_vectorization ? 1 : 0;
   o.device = device;
   if (vsg_stream_create(&o, frame_width_, frame_height_, &stream_) != VSG_OK) stream_ = nullptr;
 }
