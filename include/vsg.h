@@ -141,6 +141,29 @@ int vsg_stream_export_halo(vsg_stream* s, const int32_t** dev_labels_virtual,
 int vsg_stream_import_halo(vsg_stream* s, const int32_t* labels_virtual,
                            const int32_t* labels_constrained, int mem, const int64_t scalars[4]);
 
+/* Overlapped order for the chain: a fresh stream that will start in the middle of a video may be
+ * fed its frames (the constrained overlap frame first) BEFORE the halo exists -- features, edges
+ * and the bucket sort of the chunk do not depend on the previous chunk -- and receives the halo
+ * with vsg_stream_import_halo later, at the latest before the process_frame call that completes
+ * the chunk (that call fails with VSG_ERR_STATE otherwise). */
+int vsg_stream_expect_halo(vsg_stream* s);
+/* Puts the handle back into the state right after vsg_stream_create, keeping its device memory
+ * (one handle per GPU serves all the chunks the GPU owns). */
+int vsg_stream_restart(vsg_stream* s);
+
+/* Chunk hand-off between GPUs over RCCL (point-to-point ncclSend / ncclRecv over xGMI), for a
+ * host that shards ONE video chunk-wise over the GPUs of a node: one process per
+ * GPU, one vsg_chain per process.  id_file: a path all ranks can read; rank 0 creates it (the
+ * NCCL unique id), the others wait for it.  send_halo ships what vsg_stream_export_halo
+ * describes (two W*H int32 label planes + 4 counters) to rank dst; recv_halo receives it from
+ * rank src and imports it into the stream (vsg_stream_import_halo semantics, including the
+ * overlapped order above).  Both block until the transfer has completed. */
+typedef struct vsg_chain vsg_chain;
+int vsg_chain_create(int rank, int world, const char* id_file, int device, vsg_chain** out);
+void vsg_chain_destroy(vsg_chain* c);
+int vsg_chain_send_halo(vsg_chain* c, vsg_stream* from, int dst);
+int vsg_chain_recv_halo(vsg_chain* c, vsg_stream* into, int src);
+
 /* ---- seam 3: DenseSegGraphInterface ------------------------------------------------------- */
 /* CreateDenseSegGraph(frame_width, frame_height, max_frames) + InitializeGraph(),
  * dense_seg_graph_interface.h:46-48,112; l1 selects DistanceColorL1 (dense_segmentation.cpp:247-251). */

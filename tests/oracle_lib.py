@@ -126,8 +126,25 @@ class OracleStream:
     def __del__(self):
         self.close()
 
+    def expect_halo(self):
+        """Overlapped chain order (vsg_stream_expect_halo): the CPU restatement has nothing to
+        build ahead, so frames fed before the halo are held back and replayed after import_halo."""
+        self._held = []
+
+    def restart(self):
+        lib().vso_stream_destroy(self.h)
+        self.h = lib().vso_stream_create(C.byref(self.opts), self.W, self.H)
+        self._held = None
+
     def process_frame(self, bgr, flow=None, flush=False):
         """bgr: HxWx3 uint8 (any row stride) or None.  Returns number of results."""
+        if getattr(self, "_held", None) is not None:
+            self._held.append((None if bgr is None else np.array(bgr, copy=True),
+                               None if flow is None else np.array(flow, copy=True), flush))
+            return 0
+        return self._process_frame(bgr, flow, flush)
+
+    def _process_frame(self, bgr, flow=None, flush=False):
         if bgr is not None:
             assert bgr.dtype == np.uint8 and bgr.shape == (self.H, self.W, 3)
             assert bgr.strides[2] == 1 and bgr.strides[1] == 3
@@ -189,6 +206,10 @@ class OracleStream:
         b = np.ascontiguousarray(labels_constrained, np.int32)
         s = np.ascontiguousarray(scalars, np.int64)
         lib().vso_stream_import_halo(self.h, _ptr(a), _ptr(b), _ptr(s))
+        held, self._held = getattr(self, "_held", None), None
+        for (bgr, flow, flush) in held or []:
+            n = self._process_frame(bgr, flow, flush)
+            assert n == 0, "the frame that completes the chunk has to follow the halo"
 
 
 def preprocess(bgr, presmoothing=2):

@@ -52,6 +52,16 @@ def test_chain_single_process_matches_single_stream():
     assert [b for _, b in got] == want
 
 
+def test_chain_halo_first_order_matches_single_stream():
+    """The halo-then-frames order (vsg_stream_import_halo on a fresh stream) gives the same bytes."""
+    from video_segment_amd.multi_gpu import run_chain
+    fl = synth.const_flow(W, H)
+    got = run_chain(lambda: ol.OracleStream(W, H, ol.default_options(chunk_size=CHUNK), has_flow=True),
+                    lambda k: synth.bench_frame(W, H, k), lambda k: fl, N, CHUNK, W, H, 0, 1, None,
+                    overlapped=False)
+    assert [b for _, b in got] == single_stream()
+
+
 def _worker(rank, world, port, outfile):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)

@@ -61,7 +61,8 @@ EXPORTED_SYMBOLS = [
     "vsg_stream_create", "vsg_stream_destroy", "vsg_stream_process_frame", "vsg_stream_chunk_size",
     "vsg_stream_result_bytes", "vsg_stream_result_id_image", "vsg_stream_last_merge_stats",
     "vsg_stream_last_timings", "vsg_stream_last_smoothed", "vsg_stream_export_halo",
-    "vsg_stream_import_halo",
+    "vsg_stream_import_halo", "vsg_stream_expect_halo", "vsg_stream_restart",
+    "vsg_chain_create", "vsg_chain_destroy", "vsg_chain_send_halo", "vsg_chain_recv_halo",
     "vsg_graph_create", "vsg_graph_destroy", "vsg_graph_add_frame_bgr",
     "vsg_graph_add_frame_features", "vsg_graph_add_virtual_frame", "vsg_graph_add_temporal",
     "vsg_graph_finish_building", "vsg_graph_segment_spatially", "vsg_graph_segment", "vsg_graph_obtain_results",
@@ -119,6 +120,12 @@ def lib():
     L.vsg_stream_last_smoothed.argtypes = [vp, vp]
     L.vsg_stream_export_halo.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), vp]
     L.vsg_stream_import_halo.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.vsg_stream_expect_halo.argtypes = [vp]
+    L.vsg_stream_restart.argtypes = [vp]
+    L.vsg_chain_create.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.vsg_chain_destroy.argtypes = [vp]
+    L.vsg_chain_send_halo.argtypes = [vp, vp, C.c_int]
+    L.vsg_chain_recv_halo.argtypes = [vp, vp, C.c_int]
     L.vsg_graph_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.vsg_graph_destroy.argtypes = [vp]
     L.vsg_graph_add_frame_bgr.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_int]

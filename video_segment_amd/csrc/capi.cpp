@@ -5,6 +5,13 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <thread>
+
 #include "../../include/vsg.h"
 #include "stream.h"
 
@@ -255,12 +262,138 @@ int vsg_stream_export_halo(vsg_stream* s, const int32_t** virt, const int32_t** 
   });
 }
 
+int vsg_stream_expect_halo(vsg_stream* s) {
+  return Guard([&] {
+    VSG_REQUIRE(s, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(s->device);
+    s->impl->ExpectHalo();
+  });
+}
+
+int vsg_stream_restart(vsg_stream* s) {
+  return Guard([&] {
+    VSG_REQUIRE(s, VSG_ERR_INVALID, "null argument");
+    DeviceGuard dg(s->device);
+    s->impl->Restart();
+  });
+}
+
 int vsg_stream_import_halo(vsg_stream* s, const int32_t* virt, const int32_t* cons, int mem,
                            const int64_t scalars[4]) {
   return Guard([&] {
     VSG_REQUIRE(s && virt && cons && scalars, VSG_ERR_INVALID, "null argument");
     DeviceGuard dg(s->device);
     s->impl->ImportHalo(virt, cons, mem, scalars);
+  });
+}
+
+// ---- chunk chain over RCCL ------------------------------------------------------------------
+}  // extern "C" (reopened below)
+
+#define VSG_NCCL(call)                                                                      \
+  do {                                                                                      \
+    ncclResult_t r_ = (call);                                                               \
+    if (r_ != ncclSuccess) {                                                                \
+      vsg::Throw(VSG_ERR_DEVICE, std::string("RCCL: ") + ncclGetErrorString(r_) + " in " #call); \
+    }                                                                                       \
+  } while (0)
+
+struct vsg_chain {
+  int rank = 0, world = 1, device = 0;
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  vsg::DevBuf<int32_t> staging;   // [2 * W*H label planes | 4 int64 scalars as 8 int32]
+};
+
+extern "C" {
+
+int vsg_chain_create(int rank, int world, const char* id_file, int device, vsg_chain** out) {
+  return Guard([&] {
+    VSG_REQUIRE(out && id_file && world >= 1 && rank >= 0 && rank < world, VSG_ERR_INVALID,
+                "bad argument");
+    RequireDevice(device);
+    std::unique_ptr<vsg_chain> c(new vsg_chain);
+    c->rank = rank;
+    c->world = world;
+    c->device = ResolveDevice(device);
+    DeviceGuard dg(c->device);
+    // The communicator id travels through a file every rank can read: rank 0 writes it
+    // (temporary name + rename, so that a reader never sees half an id), the others poll.
+    ncclUniqueId id;
+    const std::string path(id_file);
+    if (rank == 0) {
+      VSG_NCCL(ncclGetUniqueId(&id));
+      const std::string tmp = path + ".tmp";
+      {
+        std::ofstream f(tmp.c_str(), std::ios::binary | std::ios::trunc);
+        f.write(reinterpret_cast<const char*>(&id), sizeof(id));
+        VSG_REQUIRE(f.good(), VSG_ERR_INVALID, "cannot write the communicator id file");
+      }
+      VSG_REQUIRE(std::rename(tmp.c_str(), path.c_str()) == 0, VSG_ERR_INVALID,
+                  "cannot publish the communicator id file");
+    } else {
+      bool got = false;
+      for (int attempt = 0; attempt < 1200 && !got; ++attempt) {   // up to two minutes
+        std::ifstream f(path.c_str(), std::ios::binary);
+        if (f.good()) {
+          f.read(reinterpret_cast<char*>(&id), sizeof(id));
+          got = f.gcount() == (std::streamsize)sizeof(id);
+        }
+        if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+      }
+      VSG_REQUIRE(got, VSG_ERR_STATE, "timed out waiting for the communicator id file");
+    }
+    VSG_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
+    VSG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c.release();
+  });
+}
+
+void vsg_chain_destroy(vsg_chain* c) {
+  if (!c) return;
+  (void)Guard([&] {
+    DeviceGuard dg(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    c->staging.release();
+  });
+  delete c;
+}
+
+int vsg_chain_send_halo(vsg_chain* c, vsg_stream* from, int dst) {
+  return Guard([&] {
+    VSG_REQUIRE(c && from && dst >= 0 && dst < c->world && dst != c->rank, VSG_ERR_INVALID,
+                "bad argument");
+    DeviceGuard dg(c->device);
+    const size_t wh = (size_t)from->impl->W() * from->impl->H();
+    const int32_t *virt = nullptr, *cons = nullptr;
+    int64_t scalars[4];
+    from->impl->ExportHalo(&virt, &cons, scalars);
+    c->staging.ensure(2 * wh + 8);
+    VSG_HIP(hipMemcpyAsync(c->staging.get(), virt, wh * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    VSG_HIP(hipMemcpyAsync(c->staging.get() + wh, cons, wh * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                           c->stream));
+    VSG_HIP(hipMemcpyAsync(c->staging.get() + 2 * wh, scalars, sizeof(scalars), hipMemcpyHostToDevice,
+                           c->stream));
+    VSG_NCCL(ncclSend(c->staging.get(), 2 * wh + 8, ncclInt32, dst, c->comm, c->stream));
+    VSG_HIP(hipStreamSynchronize(c->stream));
+  });
+}
+
+int vsg_chain_recv_halo(vsg_chain* c, vsg_stream* into, int src) {
+  return Guard([&] {
+    VSG_REQUIRE(c && into && src >= 0 && src < c->world && src != c->rank, VSG_ERR_INVALID,
+                "bad argument");
+    DeviceGuard dg(c->device);
+    const size_t wh = (size_t)into->impl->W() * into->impl->H();
+    c->staging.ensure(2 * wh + 8);
+    VSG_NCCL(ncclRecv(c->staging.get(), 2 * wh + 8, ncclInt32, src, c->comm, c->stream));
+    int64_t scalars[4];
+    VSG_HIP(hipMemcpyAsync(scalars, c->staging.get() + 2 * wh, sizeof(scalars), hipMemcpyDeviceToHost,
+                           c->stream));
+    VSG_HIP(hipStreamSynchronize(c->stream));
+    into->impl->ImportHalo(c->staging.get(), c->staging.get() + wh, VSG_MEM_DEVICE, scalars);
   });
 }
 

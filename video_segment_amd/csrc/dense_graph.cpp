@@ -78,6 +78,8 @@ void DenseGraphHip::Reset(int max_frames) {
   virtual_slices_.clear();
   flattened_ = false;
   spatial_pass_done_ = false;
+  halo_pending_ = false;
+  deferred_virtual_slice_ = deferred_constrained_slice_ = -1;
   for (auto& lb : lists_) lb.used = false;
   regions_.clear();
   key_to_region_.clear();
@@ -121,6 +123,31 @@ void DenseGraphHip::AddVirtualFrame(const int32_t* ids_dev, int max_label) {
   virtual_slices_.push_back(t);
   has_constraints_ = true;
   ++num_frames_;
+}
+
+void DenseGraphHip::AddVirtualFrameDeferred() {
+  VSG_REQUIRE(num_frames_ < max_frames_, -1, "more frames than max_frames (CHECK_LE)");
+  deferred_virtual_slice_ = num_frames_;
+  deferred_constrained_slice_ = num_frames_ + 1;
+  virtual_slices_.push_back(num_frames_);
+  has_constraints_ = true;
+  halo_pending_ = true;
+  ++num_frames_;
+}
+
+void DenseGraphHip::SetHaloLabels(const int32_t* virtual_ids_dev, const int32_t* constrained_ids_dev,
+                                  int max_label) {
+  VSG_REQUIRE(halo_pending_, -3, "no deferred virtual slice");
+  VSG_REQUIRE(num_frames_ > deferred_constrained_slice_, -3,
+              "the constrained slice has to be added before its labels");
+  VSG_REQUIRE(max_label >= 1, -1, "max_label must be positive");
+  first_label_scratch_.ensure((size_t)max_label);
+  LaunchInitVirtualNodes(virtual_ids_dev, wh_, (int)(wh_ * deferred_virtual_slice_), max_label,
+                         first_label_scratch_.get(), nodes(), stream_);
+  // the constrained slice keeps the features it was initialised with; only its labels arrive
+  VSG_HIP(hipMemcpyAsync(cons_.get() + wh_ * (size_t)deferred_constrained_slice_, constrained_ids_dev,
+                         wh_ * sizeof(int32_t), hipMemcpyDeviceToDevice, stream_));
+  halo_pending_ = false;
 }
 
 void DenseGraphHip::AddTemporal(const float* cur, const float* prev, const float* flow,
@@ -178,6 +205,7 @@ void DenseGraphHip::EnsureScratch(size_t n) {
 // ---------------------------------------------------------------------------------------------
 void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, int pass) {
   VSG_REQUIRE(num_frames_ >= 1, -3, "no frames");
+  VSG_REQUIRE(!halo_pending_, -3, "the labels of the previous chunk have not been imported");
   min_region_size_ = min_region_size;
   const int L = (int)lists_.size();
   const size_t N = wh_ * (size_t)num_frames_;

@@ -42,6 +42,15 @@ class DenseGraphHip {
   void AddFrame(const float* feat_planar_dev, const int32_t* cons_dev);
   // AddVirtualNodesConstrained.  max_label: upper bound (exclusive) of the ids in the image.
   void AddVirtualFrame(const int32_t* ids_dev, int max_label);
+  // The same with the label images still to come (multi-GPU chunk chain: the previous chunk is
+  // being segmented on another GPU while this graph is built).  The virtual slice is reserved
+  // and the next AddFrame is the constrained slice; nothing but the node initialisation of the
+  // two slices depends on the labels, so features, edges and the bucket sort proceed, and
+  // SetHaloLabels completes the two slices before Segment.
+  void AddVirtualFrameDeferred();
+  void SetHaloLabels(const int32_t* virtual_ids_dev, const int32_t* constrained_ids_dev,
+                     int max_label);
+  bool halo_pending() const { return halo_pending_; }
   // AddTemporal[Flow][Virtual]Edges: connects the last two slices.
   void AddTemporal(const float* cur_dev, const float* prev_dev, const float* flow_dev,
                    bool is_virtual);
@@ -116,6 +125,8 @@ class DenseGraphHip {
   DevBuf<uint8_t> kept_all_;
   DevBuf<uint8_t> kept_spatial_pass_;   // two-stage: what SegmentSpatially kept
   bool spatial_pass_done_ = false;
+  bool halo_pending_ = false;
+  int deferred_virtual_slice_ = -1, deferred_constrained_slice_ = -1;
   // pass: 0 all lists, 1 spatial lists only, 2 all lists after a spatial pass
   void SegmentLists(int min_region_size, bool force_constraints, int pass);
   DevBuf<int32_t> bucket_base_dev_;

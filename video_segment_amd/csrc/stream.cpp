@@ -164,7 +164,7 @@ int DenseSegmentationHip::ProcessFrame(bool flush, const uint8_t* bgr, size_t st
     ++frames_fed_;
     if (has_flow_stream) {
       flow_stream_seen_ = true;
-      if (input_frames_ == 0 && !pending_import_) {
+      if (frames_fed_ == 1 && !pending_import_) {
         flow_dev_buffer_.push_back(nullptr);
       } else {
         VSG_REQUIRE(flow != nullptr, -1, "Flow always has to be passed or be absent.");
@@ -191,7 +191,11 @@ int DenseSegmentationHip::ProcessFrame(bool flush, const uint8_t* bgr, size_t st
         flow_dev_buffer_.push_back(fd);
       }
       curr_chunk_start_ = 1;
-      StartConstrainedGraph(halo_ids_dev_[0].get(), halo_ids_dev_[1].get(), pending_max_label_);
+      if (halo_deferred_) {
+        StartConstrainedGraph(nullptr, nullptr, 0);   // the labels follow (ImportHalo)
+      } else {
+        StartConstrainedGraph(halo_ids_dev_[0].get(), halo_ids_dev_[1].get(), pending_max_label_);
+      }
       pending_import_ = false;
     } else {
       feature_buffer_.push_back(feat);
@@ -221,7 +225,11 @@ void DenseSegmentationHip::StartConstrainedGraph(const int32_t* virt_ids_dev,
   graph_->Reset(curr_chunk_start_ + options_.chunk_size);
   graph_open_ = true;
   seg_chunk_id_ = chunk_id_;
-  graph_->AddVirtualFrame(virt_ids_dev, std::max(max_label, 1));
+  if (virt_ids_dev) {
+    graph_->AddVirtualFrame(virt_ids_dev, std::max(max_label, 1));
+  } else {
+    graph_->AddVirtualFrameDeferred();
+  }
   graph_->AddFrame(feature_buffer_[1]->get(), cons_ids_dev);
   const float* fl = flow_dev_buffer_.empty() ? nullptr : flow_dev_buffer_[1]->get();
   graph_->AddTemporal(nullptr, nullptr, fl, true);
@@ -462,9 +470,16 @@ void DenseSegmentationHip::ExportHalo(const int32_t** virt, const int32_t** cons
   scalars[3] = input_frames_;
 }
 
+void DenseSegmentationHip::ExpectHalo() {
+  VSG_REQUIRE(frames_fed_ == 0 && !graph_open_ && !pending_import_, -3, "expect_halo needs a fresh stream");
+  pending_import_ = true;
+  halo_deferred_ = true;
+}
+
 void DenseSegmentationHip::ImportHalo(const int32_t* virt, const int32_t* cons, int mem,
                                       const int64_t scalars[4]) {
-  VSG_REQUIRE(input_frames_ == 0 && !graph_open_, -3, "import_halo needs a fresh stream");
+  const bool late = halo_deferred_ && !pending_import_;   // frames were fed before the halo
+  VSG_REQUIRE(late || (frames_fed_ == 0 && !graph_open_), -3, "import_halo needs a fresh stream");
   const hipMemcpyKind kind = mem == VSG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   halo_ids_dev_[0].ensure(wh_);
   halo_ids_dev_[1].ensure(wh_);
@@ -474,9 +489,41 @@ void DenseSegmentationHip::ImportHalo(const int32_t* virt, const int32_t* cons, 
   max_region_id_ = (int)scalars[0];
   chunk_id_ = (int)scalars[1];
   num_output_frames_ = (int)scalars[2];
-  input_frames_ = (int)scalars[3] - 1;   // the constrained frame is fed again
   pending_max_label_ = max_region_id_;
-  pending_import_ = true;
+  if (late) {
+    // input_frames_ counted the frames fed so far from zero; the constrained frame is fed again
+    input_frames_ += (int)scalars[3] - 1;
+    seg_chunk_id_ = chunk_id_;
+    graph_->SetHaloLabels(halo_ids_dev_[0].get(), halo_ids_dev_[1].get(), std::max(max_region_id_, 1));
+    halo_deferred_ = false;
+  } else {
+    input_frames_ = (int)scalars[3] - 1;   // the constrained frame is fed again
+    pending_import_ = true;
+    halo_deferred_ = false;
+  }
+}
+
+void DenseSegmentationHip::Restart() {
+  VSG_HIP(hipStreamSynchronize(stream_));
+  results_.clear();
+  encoded_.clear();
+  overlap_segmentations_.clear();
+  feature_buffer_.clear();
+  flow_dev_buffer_.clear();
+  graph_open_ = false;
+  input_frames_ = 0;
+  chunk_id_ = 0;
+  seg_chunk_id_ = 0;
+  max_region_id_ = 0;
+  num_output_frames_ = 0;
+  curr_chunk_start_ = 0;
+  assigned_constrained_ids_ = false;
+  pending_import_ = false;
+  halo_deferred_ = false;
+  halo_valid_ = false;
+  flow_stream_seen_ = false;
+  frames_fed_ = 0;
+  std::memset(&accum_, 0, sizeof(accum_));
 }
 
 }  // namespace vsg

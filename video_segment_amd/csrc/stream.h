@@ -57,6 +57,10 @@ class DenseSegmentationHip {
   int W() const { return W_; }
   int H() const { return H_; }
 
+  // Fresh stream in the middle of a video whose halo arrives later (see vsg.h).
+  void ExpectHalo();
+  // Back to the state right after construction, keeping every device allocation.
+  void Restart();
   void ExportHalo(const int32_t** virt, const int32_t** cons, int64_t scalars[4]);
   void ImportHalo(const int32_t* virt, const int32_t* cons, int mem, const int64_t scalars[4]);
 
@@ -89,6 +93,7 @@ class DenseSegmentationHip {
 
   std::vector<DevPlane> feature_buffer_;
   std::vector<DevPlane> flow_dev_buffer_;     // W*H*2 f32 on the device, null = empty flow
+  bool halo_deferred_ = false;    // ExpectHalo(): frames may precede ImportHalo()
   bool flow_stream_seen_ = false;
   int64_t frames_fed_ = 0;   // frames handed to this handle (has_flow_stream must not change)
 

@@ -149,6 +149,14 @@ class DenseSegmentation:
                                            s.ctypes.data_as(C.c_void_p)))
         return a.value, b.value, s
 
+    def expect_halo(self):
+        """Fresh stream in the middle of a video: frames may be fed before import_halo."""
+        check(lib().vsg_stream_expect_halo(self.h))
+
+    def restart(self):
+        """Back to the state right after construction (device memory is kept)."""
+        check(lib().vsg_stream_restart(self.h))
+
     def import_halo(self, labels_virtual, labels_constrained, scalars):
         n = self.W * self.H
         for a in (labels_virtual, labels_constrained):
@@ -159,6 +167,30 @@ class DenseSegmentation:
         _same_mem(mem_b, mem, "the second label plane")
         s = np.ascontiguousarray(scalars, dtype=np.int64)
         check(lib().vsg_stream_import_halo(self.h, pa, pb, mem, s.ctypes.data_as(C.c_void_p)))
+
+
+class ChunkChain:
+    """RCCL hand-off of the chunk halo between the GPUs of a node (vsg_chain_*, include/vsg.h)."""
+
+    def __init__(self, rank, world, id_file, device=-1):
+        h = C.c_void_p()
+        check(lib().vsg_chain_create(rank, world, id_file.encode(), device, C.byref(h)))
+        self.h = h
+        self._destroy = lib().vsg_chain_destroy
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def send_halo(self, stream, dst):
+        check(lib().vsg_chain_send_halo(self.h, stream.h, dst))
+
+    def recv_halo(self, stream, src):
+        check(lib().vsg_chain_recv_halo(self.h, stream.h, src))
 
 
 class DenseSegGraph:

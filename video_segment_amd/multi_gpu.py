@@ -59,25 +59,36 @@ class DistTransport:
 
 
 def run_chain(engine_factory, get_frame, get_flow, num_frames, chunk, width, height, rank, world,
-              transport, to_engine_labels=None, from_engine_halo=None):
+              transport, to_engine_labels=None, from_engine_halo=None, overlapped=True):
     """Segments the chunks owned by `rank` and returns [(frame_index, SegmentationDesc bytes)].
 
-    engine_factory(): fresh engine (has_flow must match get_flow).
+    engine_factory(): the rank's engine (has_flow must match get_flow); ONE engine serves all the
+    rank's chunks (engine.restart() between them).
     get_frame(k), get_flow(k): inputs of global frame k in the engine's memory kind (flow(0) unused).
     to_engine_labels(x): converts a received label plane to what engine.import_halo accepts.
     from_engine_halo(engine): returns (labels_virtual, labels_constrained, scalars) ready to send.
+    overlapped: the SURVEY 8(e) order -- the rank feeds the frames of its chunk first (features,
+    edges and the bucket sort do not depend on the previous chunk: all ranks build concurrently)
+    and only then blocks in the receive of the halo, right before the frame that completes the
+    chunk.  False: receive first (the halo-then-frames order of vsg_stream_import_halo).
     """
     import torch
     plan = chunk_plan(num_frames, chunk)
     out = []
+    eng = None
+    pending_local = None
     for c, (first, last) in enumerate(plan):
         if c % world != rank:
             continue
-        eng = engine_factory()
-        if c > 0:
+        if eng is None:
+            eng = engine_factory()
+        else:
+            eng.restart()
+
+        def take_halo():
             src = (c - 1) % world
             if src == rank:
-                virt, cons, scal = pending_local  # noqa: F821  (set below when world == 1)
+                virt, cons, scal = pending_local
             else:
                 virt, cons, scal = transport.recv(
                     src, c, [((height, width), torch.int32), ((height, width), torch.int32),
@@ -86,8 +97,16 @@ def run_chain(engine_factory, get_frame, get_flow, num_frames, chunk, width, hei
                 virt, cons = to_engine_labels(virt), to_engine_labels(cons)
             scal_np = scal.cpu().numpy() if torch.is_tensor(scal) else np.asarray(scal)
             eng.import_halo(virt, cons, scal_np)
+
+        if c > 0:
+            if overlapped:
+                eng.expect_halo()
+            else:
+                take_halo()
         next_frame_out = None
         for k in range(first, last + 1):
+            if c > 0 and overlapped and k == last:
+                take_halo()   # the merge needs the labels; everything before it did not
             flush = (k == num_frames - 1)
             flow = get_flow(k) if (get_flow is not None and k > 0) else None
             n = eng.process_frame(get_frame(k), flow, flush=flush)
@@ -101,13 +120,14 @@ def run_chain(engine_factory, get_frame, get_flow, num_frames, chunk, width, hei
             halo = from_engine_halo(eng) if from_engine_halo is not None else eng.export_halo()
             if isinstance(halo[0], int):
                 # DenseSegmentation.export_halo() hands out library-owned device pointers that die
-                # with the engine: they have to be copied before eng.close() (product_halo does).
+                # with the engine's next chunk: they have to be copied first (product_halo does).
                 raise TypeError("product engine: pass from_engine_halo=lambda e: product_halo(e, W, H, dev)")
             dst = (c + 1) % world
             if dst == rank:
-                pending_local = halo  # noqa: F841
+                pending_local = halo
             else:
                 transport.send(dst, c + 1, list(halo))
+    if eng is not None:
         eng.close()
     return out
 
@@ -146,19 +166,24 @@ def run_chain_bench(args, rank, world, local_rank):
                     frames[k] = torch.from_numpy(synth.bench_frame(W, H, k)).to(dev)
         return num_frames, plan, mine, frames
 
+    engine = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=local_rank),
+                                   has_flow=True)
+
     def run_video(video, record):
         num_frames, plan, mine, frames = video
         frames_out = 0
         for c in mine:
             first, last = plan[c]
-            eng = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=local_rank),
-                                        has_flow=True)
+            eng = engine
+            eng.restart()
             if c > 0:
-                virt, cons, scal = transport.recv((c - 1) % world, c,
-                                                  [((H, W), torch.int32), ((H, W), torch.int32),
-                                                   ((4,), torch.int64)])
-                eng.import_halo(virt, cons, scal.cpu().numpy())
+                eng.expect_halo()   # build first, receive the labels right before the merge
             for k in range(first, last + 1):
+                if c > 0 and k == last:
+                    virt, cons, scal = transport.recv((c - 1) % world, c,
+                                                      [((H, W), torch.int32), ((H, W), torch.int32),
+                                                       ((4,), torch.int64)])
+                    eng.import_halo(virt, cons, scal.cpu().numpy())
                 n = eng.process_frame(frames[k], flow if k > 0 else None, flush=(k == num_frames - 1))
                 if n:
                     fetched = sum(len(eng.result_bytes(i)) for i in range(n))   # consumer side
@@ -179,16 +204,8 @@ def run_chain_bench(args, rank, world, local_rank):
                     acc["edges_total"] += t.edges_total
                     acc["merges"] += t.merges
             if c + 1 < len(plan):
-                pa, pb, scal = eng.export_halo()
-                n_el = W * H
-                ta = torch.empty((H, W), dtype=torch.int32, device=dev)
-                tb = torch.empty((H, W), dtype=torch.int32, device=dev)
-                # device-to-device copies out of the library-owned planes
-                torch.cuda.synchronize()
-                ta.copy_(_wrap_device_int32(pa, n_el, dev).view(H, W))
-                tb.copy_(_wrap_device_int32(pb, n_el, dev).view(H, W))
-                transport.send((c + 1) % world, c + 1, [ta, tb, torch.from_numpy(scal).to(dev)])
-            eng.close()
+                ta, tb, scal = product_halo(eng, W, H, dev)
+                transport.send((c + 1) % world, c + 1, [ta, tb, scal.to(dev)])
         return frames_out
 
     warm = load(Wm * world) if Wm > 0 else None
@@ -206,9 +223,12 @@ def run_chain_bench(args, rank, world, local_rank):
     fo = torch.tensor([frames_out], dtype=torch.float64, device=dev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dist.all_reduce(fo, op=dist.ReduceOp.SUM)
+    engine.close()
     return {"dt": float(tt.item()), "frames": float(fo.item()), "acc": acc,
-            "parallelism": "one video, chunks round-robin over %d GPUs, label-plane halo over "
-                           "RCCL send/recv" % world}
+            "parallelism": "chain: ONE video, chunks round-robin over %d GPUs, every rank builds its "
+                           "chunk graph before it blocks in the receive of the label-plane halo "
+                           "(send/recv over the process group: RCCL on GPUs); a pipeline, not "
+                           "data parallel" % world}
 
 
 def _wrap_device_int32(ptr, n, dev):
