@@ -56,6 +56,11 @@ def parse():
                     help="concurrent independent 1080p streams per GPU (default 1 = the BASELINE "
                          "workload; >1 only quantifies how idle one stream leaves the GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="frames and flow are handed over as host buffers (the H2D copies are "
+                         "inside the timed region); reported as config.inputs, never the default")
+    ap.add_argument("--no-pcie-leg", action="store_true",
+                    help="skip the short extra leg that measures the PCIe-inclusive rate")
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 "
                          "control flow on a box with fewer GPUs than ranks, with --share-gpu)")
@@ -66,21 +71,39 @@ def parse():
 
 
 def cpu_baseline(W, H, chunk, n_frames, device):
-    """Times the CPU oracle (single thread) on the first n_frames frames of the same workload
-    (one flushed chunk), outside the timed region, and -- since the oracle's output is there
-    anyway -- compares it byte for byte with what the HIP path produces for the same frames
-    ("parity_checked").  Reported baseline only."""
+    """Times the CPU oracle on the first n_frames frames of the same workload (one flushed
+    chunk), outside the timed region: single threaded (the reported `cpu_baseline`) and with the
+    reference's default threading (one thread per Add*Edges call of the graph construction,
+    row-parallel bilateral filter; the merge is serial either way) -- SURVEY 8(d)(i)/(ii).  Since
+    the oracle's output is there anyway, it is compared byte for byte with what the HIP path
+    produces for the same frames ("parity_checked").  Reported baselines only."""
     import oracle_lib as ol
     import synth
     import video_segment_amd as vsg
-    s = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
     fl = synth.const_flow(W, H)
     frames = [synth.bench_frame(W, H, k) for k in range(n_frames)]
-    t0 = time.perf_counter()
-    out = 0
-    for k in range(n_frames):
-        out += s.process_frame(frames[k], fl if k > 0 else None, flush=(k == n_frames - 1))
-    dt = time.perf_counter() - t0
+
+    def run_oracle(threads):
+        ol.set_threads(threads)
+        st = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
+        t0_ = time.perf_counter()
+        n_ = 0
+        for k in range(n_frames):
+            n_ += st.process_frame(frames[k], fl if k > 0 else None, flush=(k == n_frames - 1))
+        return st, n_, time.perf_counter() - t0_
+
+    cores = max(1, min(os.cpu_count() or 1, 8))
+    threaded = None
+    if cores > 1:
+        st, n_t, dt_t = run_oracle(cores)
+        st.close()
+        threaded = {
+            "value": n_frames / dt_t, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "same sample, reference default threading (parallel graph construction: one "
+                      "thread per edge list; %d-way row-parallel bilateral; serial merge), %.1f s"
+                      % (cores, dt_t),
+        }
+    s, out, dt = run_oracle(1)
     assert out == n_frames
     g = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=device),
                               has_flow=True)
@@ -95,7 +118,7 @@ def cpu_baseline(W, H, chunk, n_frames, device):
         "value": n_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
         "sample": "first %d frames of the same %dx%d workload (flow, chunk %d) as one flushed "
                   "chunk, oracle/libvs_oracle.so, %.1f s" % (n_frames, W, H, chunk, dt),
-    }, parity
+    }, threaded, parity
 
 
 def main():
@@ -139,11 +162,13 @@ def main():
         # ---- independent stream per rank --------------------------------------------------
         n_frames = chunk + (chunk - 1) * (Wm + K - 1) if (Wm + K) > 0 else 0
         seed_shift = 1000 * rank
-        flow = torch.from_numpy(synth.const_flow(W, H)).to(dev)
-        frames = []
+        flow_host = synth.const_flow(W, H)
+        flow = flow_host if args.host_inputs else torch.from_numpy(flow_host).to(dev)
+        frames, frames_host = [], []
         for k in range(n_frames):
             f = synth.bench_frame(W, H, k + seed_shift) if rank else synth.bench_frame(W, H, k)
-            frames.append(torch.from_numpy(f).to(dev))
+            frames_host.append(f)
+            frames.append(f if args.host_inputs else torch.from_numpy(f).to(dev))
         import threading
         S = max(1, args.streams)
         streams = [vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=local_rank),
@@ -228,6 +253,31 @@ def main():
                   "parallelism": "%d independent 1080p stream(s) per GPU x %d GPU(s)" % (S, world)}
         for st_ in streams:
             st_.close()
+        # PCIe-inclusive leg (rank 0, one stream, not `value`): the same steady-state chunks with
+        # frames and flow handed over as host buffers, so that the H2D copies are timed as well.
+        result["pcie"] = None
+        if rank == 0 and not args.host_inputs and not args.no_pcie_leg and S == 1:
+            st_ = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=local_rank),
+                                        has_flow=True)
+            need = chunk + (chunk - 1) * 2
+            k = 0
+            t_start, got, steps_done = None, 0, 0
+            while k < min(need, n_frames):
+                n_ = st_.process_frame(frames_host[k], flow_host if k > 0 else None)
+                k += 1
+                if n_:
+                    if t_start is not None:
+                        got += n_
+                        steps_done += 1
+                    torch.cuda.synchronize()
+                    if t_start is None:
+                        t_start = time.perf_counter()     # after the first (unconstrained) chunk
+            if t_start is not None and steps_done > 0:
+                dt_h = time.perf_counter() - t_start
+                result["pcie"] = {"value": got / dt_h, "unit": "frames/s", "steps": steps_done,
+                                  "note": "frames (6.2 MB) and flow (16.6 MB) per frame copied from "
+                                          "pageable host memory inside the timed region"}
+            st_.close()
 
     if rank == 0:
         dt, frames_total, acc = result["dt"], result["frames"], result["acc"]
@@ -240,7 +290,7 @@ def main():
         # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes cannot run inside the
         # timed process, so the committed summary of the same workload is quoted (null if absent).
         traffic, traffic_note = None, "no PMC summary under profiles/"
-        pmc_path = os.path.join(ROOT, "profiles", "r1_e_pmc_wave.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_wave.json")
         if os.path.exists(pmc_path) and (W, H, chunk) == (1920, 1080, 20):
             pmc = json.load(open(pmc_path))
             traffic = pmc["fetch_bytes_per_launch_raw"] + pmc["write_bytes_per_launch_raw"]
@@ -266,6 +316,8 @@ def main():
                 "frames_per_step": chunk - 1,
                 "parallelism": result["parallelism"],
                 "mode": args.mode,
+                "inputs": "host buffers (H2D inside the timed region)" if args.host_inputs
+                          else "resident in HBM",
             },
             "roofline": {
                 "bound": "hbm",
@@ -294,9 +346,13 @@ def main():
             "edges_per_step": acc["edges_total"] / K,
             "merges_per_step": acc["merges"] / K,
         }
+        if result.get("pcie"):
+            out["pcie_inclusive"] = result["pcie"]
         if not args.no_cpu_baseline:
-            out["cpu_baseline"], out["parity_checked"] = cpu_baseline(W, H, chunk, args.cpu_frames,
-                                                                     local_rank)
+            out["cpu_baseline"], threaded, out["parity_checked"] = cpu_baseline(
+                W, H, chunk, args.cpu_frames, local_rank)
+            if threaded is not None:
+                out["cpu_baseline_threaded"] = threaded
             assert out["parity_checked"], "HIP output differs from the oracle on the bench workload"
         print(json.dumps(out), flush=True)
     if world > 1:

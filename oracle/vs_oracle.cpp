@@ -24,6 +24,7 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -464,6 +465,27 @@ static float BilateralTables(double min_val, double max_val, float sigma_space, 
 }
 
 // image: H*W*3 f32 interleaved.  output likewise.
+// Threading of the reference's defaults (timing baseline only; results are identical):
+// parallel_graph_construction (dense_segmentation_graph.cpp:31: one std::thread per Add*Edges
+// call, joined in FinishBuildingGraph) and the row-parallel bilateral filter (ParallelFor over
+// rows, base/base.h:155-158).  g_threads <= 1: everything on the calling thread.
+static int g_threads = 1;
+
+template <class F>
+static void ParallelRows(int rows, const F& fn) {
+  const int nt = std::max(1, std::min(g_threads, rows));
+  if (nt == 1) {
+    fn(0, rows);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; ++t) {
+    const int r0 = (int)((int64_t)rows * t / nt), r1 = (int)((int64_t)rows * (t + 1) / nt);
+    pool.emplace_back([=, &fn] { fn(r0, r1); });
+  }
+  for (std::thread& th : pool) th.join();
+}
+
 static void BilateralFilter3(const float* image, int W, int H, float sigma_space,
                              float sigma_color, float* output) {
   const int radius = (int)(sigma_space * 1.5f);
@@ -496,7 +518,8 @@ static void BilateralFilter3(const float* image, int W, int H, float sigma_space
   for (int k = 0; k < space_sz; ++k) space_ofs[k] = ((ptrdiff_t)sdy[k] * BW + sdx[k]) * 3;
 
   // ParallelBilateralColor::operator(), image_filter.cpp:130-167.
-  for (int i = 0; i < H; ++i) {
+  ParallelRows(H, [&](int row_begin, int row_end) {
+  for (int i = row_begin; i < row_end; ++i) {
     const float* src_ptr = border.data() + ((size_t)(i + radius) * BW + radius) * 3;
     float* dst_ptr = output + (size_t)i * W * 3;
     for (int j = 0; j < W; ++j, src_ptr += 3, dst_ptr += 3) {
@@ -524,6 +547,7 @@ static void BilateralFilter3(const float* image, int W, int H, float sigma_space
       }
     }
   }
+  });
 }
 
 // dense_segmentation.cpp:164-198.  convertTo(CV_32FC3, 1.0/255.0) is OpenCV (un-vendored);
@@ -746,6 +770,11 @@ struct BucketCensus {
 
 class DenseGraph {
  public:
+  ~DenseGraph() {
+    for (std::thread& t : add_edges_tasks_) {
+      if (t.joinable()) t.join();
+    }
+  }
   // dense_segmentation_graph.h:290-312; segmentation_graph.h:322-337.
   DenseGraph(int W, int H, int max_frames, bool l1)
       : W_(W), H_(H), max_frames_(max_frames), l1_(l1) {
@@ -766,7 +795,12 @@ class DenseGraph {
   // AddNodesAndSpatialEdges[Constrained] (dense_segmentation_graph.h:83-105, 906-930).
   void AddFrame(const float* feat, const int32_t* constraint_ids) {
     AddNodesWithDescriptors(feat, constraint_ids);
-    AddSpatialEdgesImpl(feat, num_frames_);
+    const int frame_idx = num_frames_;
+    if (g_threads > 1) {   // every task fills its own bucket list
+      add_edges_tasks_.emplace_back([this, feat, frame_idx] { AddSpatialEdgesImpl(feat, frame_idx); });
+    } else {
+      AddSpatialEdgesImpl(feat, frame_idx);
+    }
     ++num_frames_;
     VSO_CHECK(num_frames_ <= max_frames_);
   }
@@ -805,6 +839,22 @@ class DenseGraph {
   // incremented for the current slice).
   void AddTemporal(const float* cur, const float* prev, const float* flow, bool is_virtual) {
     const int frame_idx = num_frames_;
+    if (g_threads > 1) {
+      add_edges_tasks_.emplace_back(
+          [=] { AddTemporalImpl(cur, prev, flow, is_virtual, frame_idx); });
+    } else {
+      AddTemporalImpl(cur, prev, flow, is_virtual, frame_idx);
+    }
+  }
+
+  // FinishBuildingGraph, dense_segmentation_graph.h:396-403.
+  void FinishBuildingGraph() {
+    for (std::thread& t : add_edges_tasks_) t.join();
+    add_edges_tasks_.clear();
+  }
+
+  void AddTemporalImpl(const float* cur, const float* prev, const float* flow, bool is_virtual,
+                       int frame_idx) {
     const int base_diff = W_ * H_;
     const int base_idx = (frame_idx - 1) * W_ * H_;
     const int bucket_list_idx = 2 * (frame_idx - 1) - 1;
@@ -858,6 +908,7 @@ class DenseGraph {
   // unless reset_stats is set.
   void SegmentGraph(int min_region_size, bool force_constraints,
                     const std::vector<int>* bucket_list_ids = nullptr, bool reset_stats = false) {
+    FinishBuildingGraph();
     const float inv_scale = (float)(1.0 / (double)scale_);
     if (reset_stats || !segmented_once_) {
       num_forced_merges_ = num_regular_merges_ = num_small_region_merges_ = 0;
@@ -1448,6 +1499,7 @@ class DenseGraph {
   int max_region_id_ = 0;
   int64_t num_forced_merges_ = 0, num_regular_merges_ = 0, num_small_region_merges_ = 0;
   bool segmented_once_ = false;
+  std::vector<std::thread> add_edges_tasks_;
   std::vector<BucketCensus> census_;
 };
 
@@ -1831,6 +1883,8 @@ struct vso_graph {
 };
 
 extern "C" {
+
+void vso_set_threads(int n) { vso::g_threads = n < 1 ? 1 : n; }
 
 void vso_default_options(vso_options* o) {
   o->presmoothing = 2;

@@ -43,6 +43,10 @@ typedef struct vso_options {
 } vso_options;
 
 void vso_default_options(vso_options* o);
+/* Threads of the CPU baseline (results do not depend on it): 1 = everything on the calling thread;
+ * n > 1 = the reference's defaults, i.e. one thread per Add*Edges call of the graph construction
+ * (dense_segmentation_graph.cpp:31) and an n-way row-parallel bilateral filter. */
+void vso_set_threads(int n);
 
 /* ---- streaming level: DenseSegmentation::ProcessFrame ------------------------------- */
 vso_stream* vso_stream_create(const vso_options* o, int width, int height);

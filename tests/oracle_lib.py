@@ -81,6 +81,7 @@ def lib():
     L.vso_graph_add_frame.argtypes = [vp, vp, vp]
     L.vso_graph_add_virtual_frame.argtypes = [vp, vp]
     L.vso_graph_add_temporal.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.vso_set_threads.argtypes = [C.c_int]
     L.vso_graph_segment_spatially.argtypes = [vp]
     L.vso_graph_segment.argtypes = [vp, C.c_int, C.c_int]
     L.vso_graph_obtain_results.argtypes = [vp, vp, C.c_int, C.c_int]
@@ -99,6 +100,11 @@ def lib():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def set_threads(n):
+    """1: single threaded; n > 1: the reference's default threading (see vs_oracle.h)."""
+    lib().vso_set_threads(int(n))
 
 
 def default_options(**kw):

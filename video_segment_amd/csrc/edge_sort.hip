@@ -56,9 +56,15 @@ __device__ __forceinline__ int TruncToIntX86(float v) {
   return (int)v;
 }
 
+// The matrix is zeroed before the kernel (one coalesced memset); a tile only touches the few bins
+// it has edges in -- 2050 scattered 4-byte stores per tile would cost more HBM write traffic than
+// the keys themselves.
 __device__ __forceinline__ void StoreTileHist(const int32_t* __restrict__ lds_hist, int tile,
                                               int num_tiles, int32_t* __restrict__ hist) {
-  for (int b = threadIdx.x; b < kBucketSlots; b += 256) hist[(size_t)b * num_tiles + tile] = lds_hist[b];
+  for (int b = threadIdx.x; b < kBucketSlots; b += 256) {
+    const int c = lds_hist[b];
+    if (c) hist[(size_t)b * num_tiles + tile] = c;
+  }
 }
 
 // K3: slot = pix * 4 + k, k = 0 right, 1 bottom, 2 bottom-left, 3 bottom-right
@@ -331,6 +337,7 @@ size_t EdgeSortSumInts(size_t n_px) {
 void LaunchSpatialKeys(const float* feat, int W, int H, int l1, uint16_t* keys, int32_t* hist,
                        hipStream_t s) {
   const int T = NumTiles((size_t)W * H, 4);
+  VSG_HIP(hipMemsetAsync(hist, 0, (size_t)kBucketSlots * T * sizeof(int32_t), s));
   hipLaunchKernelGGL(k_spatial_keys, dim3(T), dim3(256), 0, s, feat, W, H, l1,
                      reinterpret_cast<ushort4*>(keys), hist, T);
   VSG_HIP(hipGetLastError());
@@ -340,6 +347,7 @@ void LaunchTemporalKeys(const float* cur, const float* prev, const float* flow, 
                         int l1, int is_virtual, uint16_t* keys, int32_t* prev_idx, int32_t* hist,
                         hipStream_t s) {
   const int T = NumTiles((size_t)W * H, 9);
+  VSG_HIP(hipMemsetAsync(hist, 0, (size_t)kBucketSlots * T * sizeof(int32_t), s));
   hipLaunchKernelGGL(k_temporal_keys, dim3(T), dim3(256), 0, s, cur, prev, flow, W, H, l1,
                      is_virtual, keys, prev_idx, hist, T);
   VSG_HIP(hipGetLastError());
