@@ -61,6 +61,7 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   hist_sums_.alloc(EdgeSortSumInts(wh_) + 1);
   scalars_.alloc(16);
   stats_.alloc(64);
+
   size_t temp = ScanTempBytes((int)N);
   cub_temp_.alloc(temp);
   Reset(max_frames);
@@ -203,6 +204,49 @@ void DenseGraphHip::EnsureScratch(size_t n) {
 // ---------------------------------------------------------------------------------------------
 // SegmentFullGraph
 // ---------------------------------------------------------------------------------------------
+// One stage, with the per-stage counters of VSG_DEBUG_STAGES printed around it.
+void DenseGraphHip::RunStageDebug(int b, int w, int windows, int j0, int n, const MergeParams& P,
+                                  int inert_mode, MergeScratch& S, bool debug_stages, StageInfo* info) {
+  unsigned long long s0[64] = {0}, s1[64] = {0};
+  double ts = 0;
+  size_t ev0 = 0;
+  if (debug_stages) {
+    VSG_HIP(hipMemsetAsync(stats_.get() + 16, 0, 2 * sizeof(unsigned long long), stream_));
+    VSG_HIP(hipMemsetAsync(stats_.get() + 48, 0, 16 * sizeof(unsigned long long), stream_));
+    D2H(s0, stats_.get(), 64, stream_);
+    VSG_HIP(hipStreamSynchronize(stream_));
+    ts = NowMs();
+    ev0 = ev_wave_.size();
+  }
+  RunBucketStage(b, j0, n, list_desc_dev_.get(), bucket_base_dev_.get(), list_slot_base_dev_.get(),
+                 kept_all_.get(), nodes(), P, inert_mode, S, stream_, info);
+  if (!debug_stages) return;
+  D2H(s1, stats_.get(), 64, stream_);
+  VSG_HIP(hipStreamSynchronize(stream_));
+  const double te = NowMs();
+  float wave_ms = 0;
+  for (size_t k = ev0; k < ev_wave_.size(); ++k) {
+    float ms = 0;
+    VSG_HIP(hipEventElapsedTime(&ms, ev_pool_[ev_wave_[k].first], ev_pool_[ev_wave_[k].second]));
+    wave_ms += ms;
+  }
+  if (te - ts <= 1.0) return;
+  std::fprintf(stderr, "[vsg] stage b=%d w=%d/%d n=%d wall %.2f ms workers %.2f ms | replayed %d components %d | "
+               "wave edges %llu batches %llu rounds %llu nwin %llu chain %llu | max_seg %llu slowest %.2f Mcyc | "
+               "cyc load %.0f M loop %.0f M wait %.0f M\n",
+               b, w, windows, n, te - ts, wave_ms, info ? info->replayed : -1, info ? info->components : -1,
+               s1[3] - s0[3], s1[7] - s0[7], s1[5] - s0[5], s1[4] - s0[4], s1[20] - s0[20],
+               s1[17], s1[16] / 1e6, (s1[18] - s0[18]) / 1e6, (s1[19] - s0[19]) / 1e6,
+               (s1[26] - s0[26]) / 1e6);
+  std::fprintf(stderr, "[vsg]   largest: %.2f Mcyc batches %llu rounds %llu live %llu chain %llu nwin %llu | kcyc/batch: "
+               "wait %.1f stage+table %.1f loop %.1f (reserve %.1f closure %.1f masks+generic %.1f chain %.1f) | cuts %llu kept %llu\n",
+               s1[48] / 1e6, s1[49], s1[50], s1[51], s1[55], s1[56],
+               s1[52] / 1e3 / std::max(1.0, (double)s1[49]), s1[53] / 1e3 / std::max(1.0, (double)s1[49]),
+               s1[54] / 1e3 / std::max(1.0, (double)s1[49]), s1[57] / 1e3 / std::max(1.0, (double)s1[49]),
+               s1[58] / 1e3 / std::max(1.0, (double)s1[49]), s1[59] / 1e3 / std::max(1.0, (double)s1[49]),
+               s1[60] / 1e3 / std::max(1.0, (double)s1[49]), s1[61], s1[62]);
+}
+
 void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, int pass) {
   VSG_REQUIRE(num_frames_ >= 1, -3, "no frames");
   VSG_REQUIRE(!halo_pending_, -3, "the labels of the previous chunk have not been imported");
@@ -352,45 +396,14 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
       const int j0 = (int)((int64_t)n_b * w / windows);
       int j1 = (int)((int64_t)n_b * (w + 1) / windows);
       const bool probe = windows > 1 && w == 0 && window_bushy > 0;
-      unsigned long long s0[64] = {0}, s1[64] = {0};
-      double ts = 0;
-      size_t ev0 = 0;
-      if (debug_stages) {
-        VSG_HIP(hipMemsetAsync(stats_.get() + 16, 0, 2 * sizeof(unsigned long long), stream_));
-        D2H(s0, stats_.get(), 64, stream_);
-        VSG_HIP(hipStreamSynchronize(stream_));
-        ts = NowMs();
-        ev0 = ev_wave_.size();
-      }
       StageInfo info;
-      RunBucketStage(b, j0, j1 - j0, list_desc_dev_.get(), bucket_base_dev_.get(),
-                     list_slot_base_dev_.get(), kept_all_.get(), nodes(), P, inert_mode, S, stream_,
-                     (probe || debug_stages) ? &info : nullptr);
-      if (debug_stages) {
-        D2H(s1, stats_.get(), 64, stream_);
-        VSG_HIP(hipStreamSynchronize(stream_));
-        const double te = NowMs();
-        float wave_ms = 0;
-        for (size_t k = ev0; k < ev_wave_.size(); ++k) {
-          float ms = 0;
-          VSG_HIP(hipEventElapsedTime(&ms, ev_pool_[ev_wave_[k].first], ev_pool_[ev_wave_[k].second]));
-          wave_ms += ms;
-        }
-        if (te - ts > 1.0) {
-          std::fprintf(stderr, "[vsg] stage b=%d w=%d/%d n=%d wall %.2f ms workers %.2f ms | replayed %d components %d | "
-                       "wave edges %llu batches %llu rounds %llu nwin %llu chain %llu | max_seg %llu slowest %.2f Mcyc | "
-                       "cyc load %.0f M loop %.0f M wait %.0f M\n",
-                       b, w, windows, j1 - j0, te - ts, wave_ms, info.replayed, info.components,
-                       s1[3] - s0[3], s1[7] - s0[7], s1[5] - s0[5], s1[4] - s0[4], s1[20] - s0[20],
-                       s1[17], s1[16] / 1e6, (s1[18] - s0[18]) / 1e6, (s1[19] - s0[19]) / 1e6,
-                       (s1[26] - s0[26]) / 1e6);
-        }
-      }
+      RunStageDebug(b, w, windows, j0, j1 - j0, P, inert_mode, S, debug_stages,
+                    (probe || debug_stages) ? &info : nullptr);
       if (probe && (int64_t)info.replayed >= (int64_t)window_bushy * std::max(info.components, 1)) {
         // few, large components already: the rest of the bucket in one stage
-        RunBucketStage(b, j1, n_b - j1, list_desc_dev_.get(), bucket_base_dev_.get(),
-                       list_slot_base_dev_.get(), kept_all_.get(), nodes(), P, inert_mode, S,
-                       stream_);
+        StageInfo rest;
+        RunStageDebug(b, -1, windows, j1, n_b - j1, P, inert_mode, S, debug_stages,
+                      debug_stages ? &rest : nullptr);
         break;
       }
     }

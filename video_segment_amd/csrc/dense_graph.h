@@ -129,6 +129,8 @@ class DenseGraphHip {
   int deferred_virtual_slice_ = -1, deferred_constrained_slice_ = -1;
   // pass: 0 all lists, 1 spatial lists only, 2 all lists after a spatial pass
   void SegmentLists(int min_region_size, bool force_constraints, int pass);
+  void RunStageDebug(int b, int w, int windows, int j0, int n, const MergeParams& P, int inert_mode,
+                     MergeScratch& S, bool debug_stages, StageInfo* info);
   DevBuf<int32_t> bucket_base_dev_;
   std::vector<int32_t> bucket_base_host_;
   // temporaries for edge generation / sorting

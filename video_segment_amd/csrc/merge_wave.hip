@@ -116,6 +116,403 @@ __device__ __forceinline__ void CommitLoser(WaveTable& t, const NodeArrays& node
   if (t.flags[ls] & kTabDirty) nodes.cons[lid] = t.cons[ls];
 }
 
+// Counters of one worker wavefront (per lane where noted; reduced at the end of the kernel).
+struct WaveCounters {
+  unsigned n_forced = 0, n_regular = 0, n_small = 0;   // per lane
+  unsigned dbg_rounds = 0, dbg_nwin = 0, dbg_chain = 0, dbg_solo = 0, dbg_cut = 0, dbg_kept = 0;
+  unsigned long long cyc_ph[5] = {0, 0, 0, 0, 0};   // reserve+load, closure, masks, generic, chain
+  unsigned long long dbg_x[6] = {0, 0, 0, 0, 0, 0};
+};
+
+// Replays one batch: lane `lane` holds the edge whose end regions sit in the table slots sa / sb
+// (`valid`: the lane has an edge).  Returns whether this lane's edge is kept.
+template <bool kDbg>
+__device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, const NodeArrays& nodes,
+                                             const StageThr& T, int optimistic, int32_t* violation,
+                                             unsigned long long* stats, int dbg_flags, int lane,
+                                             bool valid, int sa, int sb, WaveCounters& C) {
+  auto Clock = []() -> unsigned long long { return kDbg ? __builtin_readcyclecounter() : 0ull; };
+  bool pending = valid;
+  int hot = -1;   // wave-uniform slot of the round's hot region
+  bool my_kept = false;
+  bool failed = false;    // this lane's chain test failed: replay it with the generic code
+  for (unsigned round = 0;; ++round) {
+    {   // current root slots of both ends
+      for (bool more = pending; more;) {
+        const int pa = tab.link[sa], pb = tab.link[sb];
+        more = (pa != sa) || (pb != sb);
+        sa = pa;
+        sb = pb;
+      }
+      if (pending && sa == sb) pending = false;   // became internal
+    }
+    const unsigned long long pend_mask = __ballot(pending);
+    if (!pend_mask) break;
+    // The round's hot region: the larger end of the earliest pending edge.  That edge owns
+    // its other end by construction, so the chain can always start, and the run of edges that
+    // depends on it (the growth front of its cluster) joins the chain in this round.  On the
+    // scheduler model (tools/sched_sim.cpp) this needs 2.6 M instead of 5.5 M rounds for the
+    // cluster bucket of the 1080p input, compared with one hot region per batch.
+    {
+      const int first = (int)__builtin_ctzll(pend_mask);
+      const int fa = ReadLaneI(sa, first), fb = ReadLaneI(sb, first);
+      const int sza = __float_as_int(tab.ds[fa].w), szb = __float_as_int(tab.ds[fb].w);
+      hot = (sza >= szb) ? fa : fb;
+      if (kDbg && (dbg_flags & 4)) hot = -1;
+    }
+    if (round > 140u) {   // cannot happen (the earliest pending lane commits, after at most one failed chain test): report
+      if (lane == 0) atomicAdd(&stats[22], 1ull);
+      break;
+    }
+    const unsigned long long ph0 = Clock();
+    const bool a_hot = (sa == hot), b_hot = (sb == hot);
+    const uint32_t key = ((0xfffffu - round) << 6) | (uint32_t)lane;
+    if (pending) {
+      if (!a_hot) atomicMin(&tab.res[sa], key);
+      if (!b_hot) atomicMin(&tab.res[sb], key);
+    }
+    WaveSync();
+    uint32_t res_a = 0, res_b = 0;
+    RState A = {}, B = {};
+    if (pending) {
+      res_a = tab.res[sa];
+      res_b = tab.res[sb];
+      A = TabLoad(tab, sa);
+      B = TabLoad(tab, sb);
+    }
+    // own_x: this lane is the earliest pending edge on region x (the hot region is not reserved)
+    const unsigned long long ph1 = Clock();
+    const bool own_a = pending && !a_hot && res_a == key;
+    const bool own_b = pending && !b_hot && res_b == key;
+    const int oa = (int)(res_a & 63u), ob = (int)(res_b & 63u);   // owners (earlier lanes)
+    RState Hs = {}, P = {};
+    int ps = 0;            // partner slot of a chain lane
+    bool hot_lane = pending && (a_hot || b_hot);
+    bool elig = false;     // chain lane
+    bool both = false;     // both ends (will) belong to the hot region: internal once committed
+    bool merging = false;
+    bool case_s = false;
+    bool fin = false;
+    // A chain starts at the first edge that touches the hot region and only if that lane is the
+    // earliest pending edge on its other end; otherwise nothing can be absorbed in this round
+    // and the classification below is skipped (the other hot edges just wait).
+    const unsigned long long lit_mask = __ballot(hot_lane);
+    const bool chain_possible =
+        lit_mask != 0 && ((__ballot(hot_lane && (own_a || own_b)) >> __builtin_ctzll(lit_mask)) & 1ull);
+    if (chain_possible) {
+      Hs = TabLoad(tab, hot);   // uniform
+      fin = (Hs.flags & kFlagFinalized) != 0;
+      const bool mode_ok = !(Hs.flags & kFlagNoDesc) && (!fin || Hs.sz >= T.min_size) &&
+                           !(kDbg && (dbg_flags & 1));
+      // A region is *effectively hot* for a lane when it is the hot region or when its owner
+      // (an earlier lane) is a chain lane that absorbs it into the hot region: by the time this
+      // lane is replayed the region is part of the hot one.  So a run of edges p1-p2, p2-p3, ...
+      // hanging off the hot region joins the chain in one round.  The set of absorbing lanes
+      // only grows, so the loop ends (no memory access inside).
+      // Per end, evaluated once: would this end qualify as the partner of a chain edge
+      // (plain, smaller, owned by this lane) and would the edge merge?
+      // Case S (partner with the hot region's constraint) merges unless the descriptors are
+      // further apart than the split threshold, whatever the sizes and flags; Case U
+      // (unconstrained partner): regular test while the hot region is not finalized, a finalized
+      // hot region (>= min size) absorbs small partners only.
+      const bool base = pending && mode_ok && !failed;
+      const bool part_a = base && own_a && A.flags == 0 && (A.cons < 0 || A.cons == Hs.cons) &&
+                          A.sz < Hs.sz;
+      const bool part_b = base && own_b && B.flags == 0 && (B.cons < 0 || B.cons == Hs.cons) &&
+                          B.sz < Hs.sz;
+      const bool merge_a = part_a && (A.cons >= 0 || !fin || A.sz < T.min_size);
+      const bool merge_b = part_b && (B.cons >= 0 || !fin || B.sz < T.min_size);
+      const bool abs_a = pending && !own_a, abs_b = pending && !own_b;   // may be absorbed
+      // A lane merges into the chain when one end is effectively hot and the other end is a
+      // partner it owns (merge_x implies own_x, so that end can only be hot literally).  Hence a
+      // lane depends on at most ONE earlier lane -- the owner of its not-owned end -- and the
+      // closure is an OR propagation along those single links:
+      //   em = stat | { j : dyn_j in em }.
+      const bool cand1 = merge_b && !b_hot;   // partner b, hot side a
+      const bool cand2 = merge_a && !a_hot;   // partner a, hot side b
+      const unsigned long long stat = __ballot((cand1 && a_hot) || (cand2 && b_hot));
+      const int dyn = (cand1 && abs_a && !a_hot) ? oa : ((cand2 && abs_b && !b_hot) ? ob : -1);
+      unsigned long long em = stat;   // chain lanes that merge
+      for (;;) {
+        const unsigned long long em2 = stat | __ballot(dyn >= 0 && ((em >> (dyn & 63)) & 1ull));
+        if (em2 == em) break;
+        em = em2;
+      }
+      const bool ea = a_hot || (abs_a && ((em >> oa) & 1ull));
+      const bool eb = b_hot || (abs_b && ((em >> ob) & 1ull));
+      hot_lane = pending && (ea || eb);
+      both = hot_lane && ea && eb;
+      const bool pb_side = ea;   // the partner is the end that is not effectively hot
+      P.d0 = pb_side ? B.d0 : A.d0;
+      P.d1 = pb_side ? B.d1 : A.d1;
+      P.d2 = pb_side ? B.d2 : A.d2;
+      P.sz = pb_side ? B.sz : A.sz;
+      P.cons = pb_side ? B.cons : A.cons;
+      P.flags = 0;
+      ps = pb_side ? sb : sa;
+      elig = hot_lane && !both && (pb_side ? part_b : part_a);
+      merging = hot_lane && !both && (pb_side ? merge_b : merge_a);
+      case_s = P.cons >= 0;
+    }
+    const unsigned long long ph2 = Clock();
+    const unsigned long long hot_mask = __ballot(hot_lane);
+    const unsigned long long elig_mask = __ballot(elig);
+    // hot lanes that are neither chain lanes nor internal end the chain
+    const unsigned long long blocked = hot_mask & ~(elig_mask | __ballot(both));
+    const unsigned long long prefix =
+        blocked ? ((1ull << __builtin_ctzll(blocked)) - 1ull) : ~0ull;
+    unsigned long long chain_mask = elig_mask & prefix;
+    if (kDbg && (dbg_flags & 32)) {   // no jumping over earlier pending lanes
+      const unsigned long long others = __ballot(pending) & ~chain_mask;
+      if (others) chain_mask &= (1ull << __builtin_ctzll(others)) - 1ull;
+    }
+    if ((kDbg && (dbg_flags & 64)) && chain_mask) chain_mask = 1ull << __builtin_ctzll(chain_mask);
+    // The first hot lane, when it is no chain lane, is replayed alone by the generic code (it
+    // touches the hot region itself: nothing earlier can have absorbed one of its ends).
+    const bool own = pending && (a_hot || own_a) && (b_hot || own_b);
+    const bool solo = hot_lane && own && !elig && !both &&
+                      lane == (int)__builtin_ctzll(hot_mask | (1ull << 63));
+    bool n_win = pending && own && (!hot_lane || solo);
+    if (kDbg && (dbg_flags & 8)) n_win = n_win && lane == (int)__builtin_ctzll(__ballot(pending));
+    if constexpr (kDbg) {
+      const unsigned long long nwin_mask = __ballot(n_win), solo_mask = __ballot(solo);
+      const unsigned long long pend_mask = __ballot(pending);
+      if (lane == 0) {
+        ++C.dbg_rounds;
+        C.dbg_nwin += (unsigned)__popcll(nwin_mask);
+        C.dbg_solo += (unsigned)__popcll(solo_mask);
+        C.dbg_x[0] += (unsigned)__popcll(pend_mask);                 // pending lanes per round
+        C.dbg_x[1] += (unsigned)__popcll(hot_mask);                  // (effectively) hot lanes
+        C.dbg_x[2] += (unsigned)__popcll(blocked);                   // hot lanes that end the chain
+        C.dbg_x[3] += (chain_mask != 0);                             // rounds with a chain
+        C.dbg_x[4] += (nwin_mask != 0);                              // rounds with generic commits
+        C.dbg_x[5] += (unsigned)__popcll(pend_mask & ~hot_mask & ~nwin_mask);   // waiting non-hot lanes
+      }
+    }
+
+    const unsigned long long ph3 = Clock();
+    // ---- lanes that own both regions: generic edge ------------------------------------------
+    if (n_win) {
+      const RState& s1 = A;
+      const RState& s2 = B;
+      // Fast path, by far the most common generic edge: two plain regions (unconstrained,
+      // not finalized, unmarked) that pass the regular test.  Same arithmetic as
+      // DecideEdge / MergeStates for this case.
+      if (s1.cons < 0 && s2.cons < 0 && (s1.flags | s2.flags) == 0 &&
+          SquaredDistance(s1, s2) <= T.pass_s && !(kDbg && (dbg_flags & 256))) {
+        const bool first = s1.sz > s2.sz;   // ties keep region 2
+        const int ws = first ? sa : sb, ls = first ? sb : sa;
+        RState m, o;
+        m.d0 = first ? s1.d0 : s2.d0;
+        m.d1 = first ? s1.d1 : s2.d1;
+        m.d2 = first ? s1.d2 : s2.d2;
+        m.sz = first ? s1.sz : s2.sz;
+        o.d0 = first ? s2.d0 : s1.d0;
+        o.d1 = first ? s2.d1 : s1.d1;
+        o.d2 = first ? s2.d2 : s1.d2;
+        o.sz = first ? s2.sz : s1.sz;
+        const float denom = 1.0f / (float)(o.sz + m.sz);
+        const float ca = (float)o.sz * denom;
+        const float cb = (float)m.sz * denom;
+        m.d0 = ca * o.d0 + cb * m.d0;
+        m.d1 = ca * o.d1 + cb * m.d1;
+        m.d2 = ca * o.d2 + cb * m.d2;
+        m.sz += o.sz;
+        m.cons = max(s1.cons, s2.cons);
+        m.flags = 0;
+        TabStore(tab, ws, m, kTabDirty);
+        CommitLoser(tab, nodes, ls, ws);
+        ++C.n_regular;
+        pending = false;
+        n_win = false;
+      }
+    }
+    if (n_win) {
+      RState s1 = A, s2 = B;
+      const RState o1 = s1, o2 = s2;
+      int stat;
+      const int out = DecideEdge(s1, s2, T, stat);
+      if (optimistic) {
+        const bool v = (out == kOutKeep)     ? TentativeViolated(o1, o2, s1, s2)
+                       : (out == kOutMerge1) ? TentativeViolated(o1, o2, s1, s1)
+                                             : TentativeViolated(o1, o2, s2, s2);
+        if (v) *violation = 1;
+      }
+      if (stat == 4 && T.rle) *violation = 1;
+      C.n_forced += (stat == 1);
+      C.n_regular += (stat == 2);
+      C.n_small += (stat == 3);
+      if (out == kOutKeep) {
+        my_kept = true;
+        if (!SameState(o1, s1)) TabStore(tab, sa, s1, kTabDirty);
+        if (!SameState(o2, s2)) TabStore(tab, sb, s2, kTabDirty);
+      } else if (out == kOutMerge1) {
+        TabStore(tab, sa, s1, kTabDirty);
+        CommitLoser(tab, nodes, sb, sa);
+      } else {
+        TabStore(tab, sb, s2, kTabDirty);
+        CommitLoser(tab, nodes, sa, sb);
+      }
+      pending = false;
+    }
+
+    const unsigned long long ph4 = Clock();
+    // ---- the chain on the hot region -----------------------------------------------------
+    if (chain_mask) {
+      const bool in_chain = (chain_mask >> lane) & 1ull;
+      merging = in_chain && merging;
+      case_s = in_chain && case_s;
+      const bool tested = case_s || (in_chain && !fin);
+      const int v = merging ? P.sz : 0;
+      const int incl = WaveInclusiveSum(v);
+      const int S = Hs.sz + incl - v;     // size of the hot region before this lane's merge
+      // MergeStates with o = partner, m = hot region
+      const float denom = 1.0f / (float)(P.sz + S);
+      const float ca = (float)P.sz * denom;
+      const float cb = (float)S * denom;
+      const float t0 = ca * P.d0, t1 = ca * P.d1, t2 = ca * P.d2;
+      // The recurrence  h <- t + cb * h  is replayed on the merging lanes only: they are packed
+      // into the lanes 0..m-1 (through LDS, position = rank among the merging lanes) and run as
+      // a systolic chain: every step each lane takes the mean its left neighbour holds
+      // (v_mul_f32_dpp wave_shr:1) and applies its own merge.  After step k the lanes 0..k hold
+      // the mean after their merge, so m steps finish the chain (further steps change nothing).
+      // Same two roundings per channel and merge as MergeStates, in the same order.
+      const unsigned long long merging_mask = __ballot(merging);
+      float r0 = Hs.d0, r1 = Hs.d1, r2 = Hs.d2;   // hot mean before this lane's merge
+      float h0 = Hs.d0, h1 = Hs.d1, h2 = Hs.d2;   // hot mean after the whole chain (uniform)
+      if (merging_mask) {
+        const int m = (int)__popcll(merging_mask);
+        const int idx = (int)__popcll(merging_mask & ((1ull << lane) - 1ull));
+        if (merging) chain_buf[idx] = make_float4(t0, t1, t2, cb);
+        WaveSync();
+        float c = 1.0f, u0 = 0.0f, u1 = 0.0f, u2 = 0.0f;   // identity for the lanes >= m
+        if (lane < m) {
+          const float4 q = chain_buf[lane];
+          u0 = q.x;
+          u1 = q.y;
+          u2 = q.z;
+          c = q.w;
+        }
+        if (lane == 0) {   // lane 0 starts from the hot region's mean and ignores what is shifted in
+          u0 = u0 + c * Hs.d0;
+          u1 = u1 + c * Hs.d1;
+          u2 = u2 + c * Hs.d2;
+          c = 0.0f;
+        }
+        float g0 = u0, g1 = u1, g2 = u2;
+        for (int s4 = 1; s4 < m; s4 += 4) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            g0 = u0 + c * DppWaveShr1Zero(g0);
+            g1 = u1 + c * DppWaveShr1Zero(g1);
+            g2 = u2 + c * DppWaveShr1Zero(g2);
+          }
+        }
+        // packed lane j: mean before its merge = what lane j-1 ends with
+        const float b0 = DppWaveShr1Old(g0, Hs.d0);
+        const float b1 = DppWaveShr1Old(g1, Hs.d1);
+        const float b2 = DppWaveShr1Old(g2, Hs.d2);
+        h0 = ReadLaneF(g0, m - 1);
+        h1 = ReadLaneF(g1, m - 1);
+        h2 = ReadLaneF(g2, m - 1);
+        WaveSync();
+        if (lane < m) chain_buf[lane] = make_float4(b0, b1, b2, 0.0f);
+        WaveSync();
+        if (merging) {
+          const float4 q = chain_buf[idx];
+          r0 = q.x;
+          r1 = q.y;
+          r2 = q.z;
+        }
+      }
+      unsigned long long fail = 0;
+      {
+        const float x = r0 - P.d0, y = r1 - P.d1, z = r2 - P.d2;
+        const float sd = (x * x + y * y + z * z) * (1.0f / 3.0f);
+        const bool pass = case_s ? !(sd > T.split_s) : (sd <= T.pass_s);
+        fail = __ballot(tested && !pass);
+      }
+      int fcut = 64;
+      RState Hn = Hs;
+      if (fail) {
+        fcut = (int)__builtin_ctzll(fail);
+        if (lane == fcut) failed = true;
+        Hn.d0 = ReadLaneF(r0, fcut);
+        Hn.d1 = ReadLaneF(r1, fcut);
+        Hn.d2 = ReadLaneF(r2, fcut);
+        Hn.sz = ReadLaneI(S, fcut);
+        if (kDbg && lane == 0) ++C.dbg_cut;
+      } else {
+        Hn.d0 = h0;
+        Hn.d1 = h1;
+        Hn.d2 = h2;
+        Hn.sz = Hs.sz + ReadLaneI(incl, 63);
+      }
+      const unsigned long long below = (fcut < 64) ? ((1ull << fcut) - 1ull) : ~0ull;
+      const bool do_commit = in_chain && lane < fcut;
+      if constexpr (kDbg) if (dbg_flags & 16) {   // self check: replay the committed chain with DecideEdge
+        RState Hc = Hs;
+        unsigned bad = 0;
+        for (unsigned long long mm = chain_mask & below; mm; mm &= mm - 1) {
+          const int k = (int)__builtin_ctzll(mm);
+          RState a = Hc, b = ReadLaneState(P, k);
+          const RState b0 = b;
+          int st;
+          const int out = DecideEdge(a, b, T, st);
+          const bool km = (merging_mask >> k) & 1ull;
+          if (km) {
+            if (out != kOutMerge1 || st != (b0.cons >= 0 ? 1 : (fin ? 3 : 2))) ++bad;
+            Hc = a;
+          } else {
+            if (out != kOutKeep || !SameState(a, Hc) || !SameState(b, b0)) ++bad;
+          }
+        }
+        if (__float_as_int(Hc.d0) != __float_as_int(Hn.d0) || __float_as_int(Hc.d1) != __float_as_int(Hn.d1) ||
+            __float_as_int(Hc.d2) != __float_as_int(Hn.d2) || !SameState(Hc, Hn)) ++bad;
+        if (fail) {
+          RState a = Hc, b = ReadLaneState(P, fcut);
+          int st;
+          DecideEdge(a, b, T, st);
+          if (st == 2 || st == 1) ++bad;
+        }
+        if (lane == 0 && bad) atomicAdd(&stats[23], (unsigned long long)bad);
+      }
+      if (do_commit) {
+        if (merging) {
+          CommitLoser(tab, nodes, ps, hot);
+          if (case_s) ++C.n_forced; else if (fin) ++C.n_small; else ++C.n_regular;
+        } else {
+          my_kept = true;   // both regions large, the hot one finalized: nothing changes
+        }
+        pending = false;
+      }
+      // An edge with both ends (by then) inside the hot region is internal: every lane that
+      // absorbs one of its ends is an earlier chain lane, committed if this lane is below the
+      // cut.
+      // (the debug modes that shorten the chain leave these lanes to the next round's internal test)
+      if (both && lane < fcut && ((prefix >> lane) & 1ull) && !(kDbg && (dbg_flags & (32 | 64)))) {
+        pending = false;
+      }
+      if (lane == 0) {
+        if (kDbg) C.dbg_chain += (unsigned)__popcll(merging_mask & below);
+        if (merging_mask & below) TabStore(tab, hot, Hn, kTabDirty);
+      }
+    }
+    if constexpr (kDbg) {
+      const unsigned long long ph5 = Clock();
+      C.cyc_ph[0] += ph1 - ph0;
+      C.cyc_ph[1] += ph2 - ph1;
+      C.cyc_ph[2] += ph3 - ph2;
+      C.cyc_ph[3] += ph4 - ph3;
+      C.cyc_ph[4] += ph5 - ph4;
+    }
+    if (!__ballot(pending)) break;   // nothing left: skip the next round's root resolution
+    WaveSync();
+  }
+  if (kDbg) C.dbg_kept += (unsigned)__popcll(__ballot(my_kept));
+  return my_kept;
+}
+
 template <bool kDbg>
 __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ num_segs,
                                                     const int32_t* __restrict__ seg_off,
@@ -132,6 +529,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
   auto Clock = []() -> unsigned long long { return kDbg ? __builtin_readcyclecounter() : 0ull; };
   __shared__ WaveQueue queue;
   __shared__ WaveStage stage;
+  __shared__ float4 chain_buf[64];   // the merging lanes of a chain, packed
   const int lane = threadIdx.x & 63;
   const bool producer = threadIdx.x >= 64;   // wave 1 reads ahead, wave 0 replays
   for (int s = threadIdx.x; s < kTabSize; s += 128) {
@@ -140,11 +538,9 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
   }
   __syncthreads();
   const int nseg = *num_segs;
-  unsigned n_forced = 0, n_regular = 0, n_small = 0;   // per lane, reduced at the end
-  unsigned dbg_rounds = 0, dbg_nwin = 0, dbg_chain = 0, dbg_solo = 0, dbg_batches = 0, dbg_cut = 0;
+  WaveCounters C;
+  unsigned dbg_batches = 0;
   unsigned long long dbg_taken = 0, dbg_live = 0;
-  unsigned long long cyc_ph[5] = {0, 0, 0, 0, 0};
-  unsigned long long dbg_x[6] = {0, 0, 0, 0, 0, 0};   // reserve+load, closure, masks, generic, chain
   unsigned long long cyc_load = 0, cyc_loop = 0, cyc_wait = 0;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int cnt = seg_cnt[seg];
@@ -234,6 +630,10 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
     // ---- consumer --------------------------------------------------------------------------------
     if (lane == 0) atomicAdd(&stats[3], (unsigned long long)cnt);
     const unsigned long long seg_t0 = Clock();
+    const unsigned seg_cut0 = C.dbg_cut, seg_kept0 = C.dbg_kept;
+    const unsigned long long seg_c0[12] = {dbg_batches, C.dbg_rounds, dbg_live, cyc_wait, cyc_load, cyc_loop,
+                                           C.dbg_chain, C.dbg_nwin, C.cyc_ph[0], C.cyc_ph[1], C.cyc_ph[2] + C.cyc_ph[3],
+                                           C.cyc_ph[4]};
     int consumed = 0;   // wave-uniform
     int n_raw = 0;      // staged edges left over from the previous batch: roots to be re-validated
     for (;;) {
@@ -334,7 +734,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
         }
       }
       WaveSync();
-      bool pending = valid;
+      const bool pending = valid;
       int sa = 0, sb = 0;     // table slots of the current roots of the two end regions
       int mine_a = -1, mine_b = -1;   // slots this lane inserted (it writes them back and frees them)
       if (pending) {
@@ -354,372 +754,12 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
         if (ins_b) mine_b = sb;
       }
       WaveSync();
-      int hot = -1;   // wave-uniform slot of the round's hot region
       if (kDbg && lane == 0) ++dbg_batches;
       const unsigned long long bt1 = Clock();
       cyc_load += bt1 - bt0b;
 
-      bool my_kept = false;
-      bool failed = false;    // this lane's chain test failed: replay it with the generic code
-      for (unsigned round = 0;; ++round) {
-        {   // current root slots of both ends
-          for (bool more = pending; more;) {
-            const int pa = tab.link[sa], pb = tab.link[sb];
-            more = (pa != sa) || (pb != sb);
-            sa = pa;
-            sb = pb;
-          }
-          if (pending && sa == sb) pending = false;   // became internal
-        }
-        const unsigned long long pend_mask = __ballot(pending);
-        if (!pend_mask) break;
-        // The round's hot region: the larger end of the earliest pending edge.  That edge owns
-        // its other end by construction, so the chain can always start, and the run of edges that
-        // depends on it (the growth front of its cluster) joins the chain in this round.  On the
-        // scheduler model (tools/sched_sim.cpp) this needs 2.6 M instead of 5.5 M rounds for the
-        // cluster bucket of the 1080p input, compared with one hot region per batch.
-        {
-          const int first = (int)__builtin_ctzll(pend_mask);
-          const int fa = ReadLaneI(sa, first), fb = ReadLaneI(sb, first);
-          const int sza = __float_as_int(tab.ds[fa].w), szb = __float_as_int(tab.ds[fb].w);
-          hot = (sza >= szb) ? fa : fb;
-          if (kDbg && (dbg_flags & 4)) hot = -1;
-        }
-        if (round > 140u) {   // cannot happen (the earliest pending lane commits, after at most one failed chain test): report
-          if (lane == 0) atomicAdd(&stats[22], 1ull);
-          break;
-        }
-        const unsigned long long ph0 = Clock();
-        const bool a_hot = (sa == hot), b_hot = (sb == hot);
-        const uint32_t key = ((0xfffffu - round) << 6) | (uint32_t)lane;
-        if (pending) {
-          if (!a_hot) atomicMin(&tab.res[sa], key);
-          if (!b_hot) atomicMin(&tab.res[sb], key);
-        }
-        WaveSync();
-        uint32_t res_a = 0, res_b = 0;
-        RState A = {}, B = {};
-        if (pending) {
-          res_a = tab.res[sa];
-          res_b = tab.res[sb];
-          A = TabLoad(tab, sa);
-          B = TabLoad(tab, sb);
-        }
-        // own_x: this lane is the earliest pending edge on region x (the hot region is not reserved)
-        const unsigned long long ph1 = Clock();
-        const bool own_a = pending && !a_hot && res_a == key;
-        const bool own_b = pending && !b_hot && res_b == key;
-        const int oa = (int)(res_a & 63u), ob = (int)(res_b & 63u);   // owners (earlier lanes)
-        RState Hs = {}, P = {};
-        int ps = 0;            // partner slot of a chain lane
-        bool hot_lane = pending && (a_hot || b_hot);
-        bool elig = false;     // chain lane
-        bool both = false;     // both ends (will) belong to the hot region: internal once committed
-        bool merging = false;
-        bool case_s = false;
-        bool fin = false;
-        // A chain starts at the first edge that touches the hot region and only if that lane is the
-        // earliest pending edge on its other end; otherwise nothing can be absorbed in this round
-        // and the classification below is skipped (the other hot edges just wait).
-        const unsigned long long lit_mask = __ballot(hot_lane);
-        const bool chain_possible =
-            lit_mask != 0 && ((__ballot(hot_lane && (own_a || own_b)) >> __builtin_ctzll(lit_mask)) & 1ull);
-        if (chain_possible) {
-          Hs = TabLoad(tab, hot);   // uniform
-          fin = (Hs.flags & kFlagFinalized) != 0;
-          const bool mode_ok = !(Hs.flags & kFlagNoDesc) && (!fin || Hs.sz >= T.min_size) &&
-                               !(kDbg && (dbg_flags & 1));
-          // A region is *effectively hot* for a lane when it is the hot region or when its owner
-          // (an earlier lane) is a chain lane that absorbs it into the hot region: by the time this
-          // lane is replayed the region is part of the hot one.  So a run of edges p1-p2, p2-p3, ...
-          // hanging off the hot region joins the chain in one round.  The set of absorbing lanes
-          // only grows, so the loop ends (no memory access inside).
-          // Per end, evaluated once: would this end qualify as the partner of a chain edge
-          // (plain, smaller, owned by this lane) and would the edge merge?
-          // Case S (partner with the hot region's constraint) merges unless the descriptors are
-          // further apart than the split threshold, whatever the sizes and flags; Case U
-          // (unconstrained partner): regular test while the hot region is not finalized, a finalized
-          // hot region (>= min size) absorbs small partners only.
-          const bool base = pending && mode_ok && !failed;
-          const bool part_a = base && own_a && A.flags == 0 && (A.cons < 0 || A.cons == Hs.cons) &&
-                              A.sz < Hs.sz;
-          const bool part_b = base && own_b && B.flags == 0 && (B.cons < 0 || B.cons == Hs.cons) &&
-                              B.sz < Hs.sz;
-          const bool merge_a = part_a && (A.cons >= 0 || !fin || A.sz < T.min_size);
-          const bool merge_b = part_b && (B.cons >= 0 || !fin || B.sz < T.min_size);
-          const bool abs_a = pending && !own_a, abs_b = pending && !own_b;   // may be absorbed
-          // A lane merges into the chain when one end is effectively hot and the other end is a
-          // partner it owns (merge_x implies own_x, so that end can only be hot literally).  Hence a
-          // lane depends on at most ONE earlier lane -- the owner of its not-owned end -- and the
-          // closure is an OR propagation along those single links:
-          //   em = stat | { j : dyn_j in em }.
-          const bool cand1 = merge_b && !b_hot;   // partner b, hot side a
-          const bool cand2 = merge_a && !a_hot;   // partner a, hot side b
-          const unsigned long long stat = __ballot((cand1 && a_hot) || (cand2 && b_hot));
-          const int dyn = (cand1 && abs_a && !a_hot) ? oa : ((cand2 && abs_b && !b_hot) ? ob : -1);
-          unsigned long long em = stat;   // chain lanes that merge
-          for (;;) {
-            const unsigned long long em2 = stat | __ballot(dyn >= 0 && ((em >> (dyn & 63)) & 1ull));
-            if (em2 == em) break;
-            em = em2;
-          }
-          const bool ea = a_hot || (abs_a && ((em >> oa) & 1ull));
-          const bool eb = b_hot || (abs_b && ((em >> ob) & 1ull));
-          hot_lane = pending && (ea || eb);
-          both = hot_lane && ea && eb;
-          const bool pb_side = ea;   // the partner is the end that is not effectively hot
-          P.d0 = pb_side ? B.d0 : A.d0;
-          P.d1 = pb_side ? B.d1 : A.d1;
-          P.d2 = pb_side ? B.d2 : A.d2;
-          P.sz = pb_side ? B.sz : A.sz;
-          P.cons = pb_side ? B.cons : A.cons;
-          P.flags = 0;
-          ps = pb_side ? sb : sa;
-          elig = hot_lane && !both && (pb_side ? part_b : part_a);
-          merging = hot_lane && !both && (pb_side ? merge_b : merge_a);
-          case_s = P.cons >= 0;
-        }
-        const unsigned long long ph2 = Clock();
-        const unsigned long long hot_mask = __ballot(hot_lane);
-        const unsigned long long elig_mask = __ballot(elig);
-        // hot lanes that are neither chain lanes nor internal end the chain
-        const unsigned long long blocked = hot_mask & ~(elig_mask | __ballot(both));
-        const unsigned long long prefix =
-            blocked ? ((1ull << __builtin_ctzll(blocked)) - 1ull) : ~0ull;
-        unsigned long long chain_mask = elig_mask & prefix;
-        if (kDbg && (dbg_flags & 32)) {   // no jumping over earlier pending lanes
-          const unsigned long long others = __ballot(pending) & ~chain_mask;
-          if (others) chain_mask &= (1ull << __builtin_ctzll(others)) - 1ull;
-        }
-        if ((kDbg && (dbg_flags & 64)) && chain_mask) chain_mask = 1ull << __builtin_ctzll(chain_mask);
-        // The first hot lane, when it is no chain lane, is replayed alone by the generic code (it
-        // touches the hot region itself: nothing earlier can have absorbed one of its ends).
-        const bool own = pending && (a_hot || own_a) && (b_hot || own_b);
-        const bool solo = hot_lane && own && !elig && !both &&
-                          lane == (int)__builtin_ctzll(hot_mask | (1ull << 63));
-        bool n_win = pending && own && (!hot_lane || solo);
-        if (kDbg && (dbg_flags & 8)) n_win = n_win && lane == (int)__builtin_ctzll(__ballot(pending));
-        if constexpr (kDbg) {
-          const unsigned long long nwin_mask = __ballot(n_win), solo_mask = __ballot(solo);
-          const unsigned long long pend_mask = __ballot(pending);
-          if (lane == 0) {
-            ++dbg_rounds;
-            dbg_nwin += (unsigned)__popcll(nwin_mask);
-            dbg_solo += (unsigned)__popcll(solo_mask);
-            dbg_x[0] += (unsigned)__popcll(pend_mask);                 // pending lanes per round
-            dbg_x[1] += (unsigned)__popcll(hot_mask);                  // (effectively) hot lanes
-            dbg_x[2] += (unsigned)__popcll(blocked);                   // hot lanes that end the chain
-            dbg_x[3] += (chain_mask != 0);                             // rounds with a chain
-            dbg_x[4] += (nwin_mask != 0);                              // rounds with generic commits
-            dbg_x[5] += (unsigned)__popcll(pend_mask & ~hot_mask & ~nwin_mask);   // waiting non-hot lanes
-          }
-        }
-
-        const unsigned long long ph3 = Clock();
-        // ---- lanes that own both regions: generic edge ------------------------------------------
-        if (n_win) {
-          const RState& s1 = A;
-          const RState& s2 = B;
-          // Fast path, by far the most common generic edge: two plain regions (unconstrained,
-          // not finalized, unmarked) that pass the regular test.  Same arithmetic as
-          // DecideEdge / MergeStates for this case.
-          if (s1.cons < 0 && s2.cons < 0 && (s1.flags | s2.flags) == 0 &&
-              SquaredDistance(s1, s2) <= T.pass_s && !(kDbg && (dbg_flags & 256))) {
-            const bool first = s1.sz > s2.sz;   // ties keep region 2
-            const int ws = first ? sa : sb, ls = first ? sb : sa;
-            RState m, o;
-            m.d0 = first ? s1.d0 : s2.d0;
-            m.d1 = first ? s1.d1 : s2.d1;
-            m.d2 = first ? s1.d2 : s2.d2;
-            m.sz = first ? s1.sz : s2.sz;
-            o.d0 = first ? s2.d0 : s1.d0;
-            o.d1 = first ? s2.d1 : s1.d1;
-            o.d2 = first ? s2.d2 : s1.d2;
-            o.sz = first ? s2.sz : s1.sz;
-            const float denom = 1.0f / (float)(o.sz + m.sz);
-            const float ca = (float)o.sz * denom;
-            const float cb = (float)m.sz * denom;
-            m.d0 = ca * o.d0 + cb * m.d0;
-            m.d1 = ca * o.d1 + cb * m.d1;
-            m.d2 = ca * o.d2 + cb * m.d2;
-            m.sz += o.sz;
-            m.cons = max(s1.cons, s2.cons);
-            m.flags = 0;
-            TabStore(tab, ws, m, kTabDirty);
-            CommitLoser(tab, nodes, ls, ws);
-            ++n_regular;
-            pending = false;
-            n_win = false;
-          }
-        }
-        if (n_win) {
-          RState s1 = A, s2 = B;
-          const RState o1 = s1, o2 = s2;
-          int stat;
-          const int out = DecideEdge(s1, s2, T, stat);
-          if (optimistic) {
-            const bool v = (out == kOutKeep)     ? TentativeViolated(o1, o2, s1, s2)
-                           : (out == kOutMerge1) ? TentativeViolated(o1, o2, s1, s1)
-                                                 : TentativeViolated(o1, o2, s2, s2);
-            if (v) *violation = 1;
-          }
-          if (stat == 4 && T.rle) *violation = 1;
-          n_forced += (stat == 1);
-          n_regular += (stat == 2);
-          n_small += (stat == 3);
-          if (out == kOutKeep) {
-            my_kept = true;
-            if (!SameState(o1, s1)) TabStore(tab, sa, s1, kTabDirty);
-            if (!SameState(o2, s2)) TabStore(tab, sb, s2, kTabDirty);
-          } else if (out == kOutMerge1) {
-            TabStore(tab, sa, s1, kTabDirty);
-            CommitLoser(tab, nodes, sb, sa);
-          } else {
-            TabStore(tab, sb, s2, kTabDirty);
-            CommitLoser(tab, nodes, sa, sb);
-          }
-          pending = false;
-        }
-
-        const unsigned long long ph4 = Clock();
-        // ---- the chain on the hot region -----------------------------------------------------
-        if (chain_mask) {
-          const bool in_chain = (chain_mask >> lane) & 1ull;
-          merging = in_chain && merging;
-          case_s = in_chain && case_s;
-          const bool tested = case_s || (in_chain && !fin);
-          const int v = merging ? P.sz : 0;
-          const int incl = WaveInclusiveSum(v);
-          const int S = Hs.sz + incl - v;     // size of the hot region before this lane's merge
-          // MergeStates with o = partner, m = hot region
-          const float denom = 1.0f / (float)(P.sz + S);
-          const float ca = (float)P.sz * denom;
-          const float cb = (float)S * denom;
-          const float t0 = ca * P.d0, t1 = ca * P.d1, t2 = ca * P.d2;
-          // The recurrence  h <- t + cb * h  as a systolic chain over the lanes: every step each
-          // lane takes the mean its left neighbour holds (v_mul_f32_dpp wave_shr:1) and applies its
-          // own merge; lanes that do not merge pass the value on (0 + 1 * h is exact).  After step
-          // k the lanes 0..k hold the mean after their edge, so the chain is done after as many
-          // steps as its last merging lane; further steps change nothing.  Same two roundings per
-          // channel and merge as MergeStates, in the same order.
-          const unsigned long long merging_mask = __ballot(merging);
-          float r0 = Hs.d0, r1 = Hs.d1, r2 = Hs.d2;   // hot mean before this lane's merge
-          float h0 = Hs.d0, h1 = Hs.d1, h2 = Hs.d2;
-          if (merging_mask) {
-            float c = merging ? cb : 1.0f;
-            float u0 = merging ? t0 : 0.0f, u1 = merging ? t1 : 0.0f, u2 = merging ? t2 : 0.0f;
-            if (lane == 0) {   // lane 0 starts from the hot region's mean and ignores what is shifted in
-              u0 = u0 + c * Hs.d0;
-              u1 = u1 + c * Hs.d1;
-              u2 = u2 + c * Hs.d2;
-              c = 0.0f;
-            }
-            h0 = u0;
-            h1 = u1;
-            h2 = u2;
-            const int steps = 64 - (int)__builtin_clzll(merging_mask);   // index of the last merging lane + 1
-            for (int s8 = 0; s8 < steps; s8 += 8) {
-#pragma unroll
-              for (int q = 0; q < 8; ++q) {
-                h0 = u0 + c * DppWaveShr1Zero(h0);
-                h1 = u1 + c * DppWaveShr1Zero(h1);
-                h2 = u2 + c * DppWaveShr1Zero(h2);
-              }
-            }
-            r0 = DppWaveShr1Old(h0, Hs.d0);
-            r1 = DppWaveShr1Old(h1, Hs.d1);
-            r2 = DppWaveShr1Old(h2, Hs.d2);
-            // every lane behind the last merging one would need more steps: take the final mean
-            // from that lane
-            const int last = steps - 1;
-            h0 = ReadLaneF(h0, last);
-            h1 = ReadLaneF(h1, last);
-            h2 = ReadLaneF(h2, last);
-          }
-          unsigned long long fail = 0;
-          {
-            const float x = r0 - P.d0, y = r1 - P.d1, z = r2 - P.d2;
-            const float sd = (x * x + y * y + z * z) * (1.0f / 3.0f);
-            const bool pass = case_s ? !(sd > T.split_s) : (sd <= T.pass_s);
-            fail = __ballot(tested && !pass);
-          }
-          int fcut = 64;
-          RState Hn = Hs;
-          if (fail) {
-            fcut = (int)__builtin_ctzll(fail);
-            if (lane == fcut) failed = true;
-            Hn.d0 = ReadLaneF(r0, fcut);
-            Hn.d1 = ReadLaneF(r1, fcut);
-            Hn.d2 = ReadLaneF(r2, fcut);
-            Hn.sz = ReadLaneI(S, fcut);
-            if (kDbg && lane == 0) ++dbg_cut;
-          } else {
-            Hn.d0 = h0;
-            Hn.d1 = h1;
-            Hn.d2 = h2;
-            Hn.sz = Hs.sz + ReadLaneI(incl, 63);
-          }
-          const unsigned long long below = (fcut < 64) ? ((1ull << fcut) - 1ull) : ~0ull;
-          const bool do_commit = in_chain && lane < fcut;
-          if constexpr (kDbg) if (dbg_flags & 16) {   // self check: replay the committed chain with DecideEdge
-            RState Hc = Hs;
-            unsigned bad = 0;
-            for (unsigned long long mm = chain_mask & below; mm; mm &= mm - 1) {
-              const int k = (int)__builtin_ctzll(mm);
-              RState a = Hc, b = ReadLaneState(P, k);
-              const RState b0 = b;
-              int st;
-              const int out = DecideEdge(a, b, T, st);
-              const bool km = (merging_mask >> k) & 1ull;
-              if (km) {
-                if (out != kOutMerge1 || st != (b0.cons >= 0 ? 1 : (fin ? 3 : 2))) ++bad;
-                Hc = a;
-              } else {
-                if (out != kOutKeep || !SameState(a, Hc) || !SameState(b, b0)) ++bad;
-              }
-            }
-            if (__float_as_int(Hc.d0) != __float_as_int(Hn.d0) || __float_as_int(Hc.d1) != __float_as_int(Hn.d1) ||
-                __float_as_int(Hc.d2) != __float_as_int(Hn.d2) || !SameState(Hc, Hn)) ++bad;
-            if (fail) {
-              RState a = Hc, b = ReadLaneState(P, fcut);
-              int st;
-              DecideEdge(a, b, T, st);
-              if (st == 2 || st == 1) ++bad;
-            }
-            if (lane == 0 && bad) atomicAdd(&stats[23], (unsigned long long)bad);
-          }
-          if (do_commit) {
-            if (merging) {
-              CommitLoser(tab, nodes, ps, hot);
-              if (case_s) ++n_forced; else if (fin) ++n_small; else ++n_regular;
-            } else {
-              my_kept = true;   // both regions large, the hot one finalized: nothing changes
-            }
-            pending = false;
-          }
-          // An edge with both ends (by then) inside the hot region is internal: every lane that
-          // absorbs one of its ends is an earlier chain lane, committed if this lane is below the
-          // cut.
-          // (the debug modes that shorten the chain leave these lanes to the next round's internal test)
-          if (both && lane < fcut && ((prefix >> lane) & 1ull) && !(kDbg && (dbg_flags & (32 | 64)))) {
-            pending = false;
-          }
-          if (lane == 0) {
-            if (kDbg) dbg_chain += (unsigned)__popcll(merging_mask & below);
-            if (merging_mask & below) TabStore(tab, hot, Hn, kTabDirty);
-          }
-        }
-        if constexpr (kDbg) {
-          const unsigned long long ph5 = Clock();
-          cyc_ph[0] += ph1 - ph0;
-          cyc_ph[1] += ph2 - ph1;
-          cyc_ph[2] += ph3 - ph2;
-          cyc_ph[3] += ph4 - ph3;
-          cyc_ph[4] += ph5 - ph4;
-        }
-        if (!__ballot(pending)) break;   // nothing left: skip the next round's root resolution
-        WaveSync();
-      }
+      const bool my_kept = ReplayRounds<kDbg>(tab, chain_buf, nodes, T, optimistic, violation, stats,
+                                              dbg_flags, lane, valid, sa, sb, C);
       WaveSync();
 
       if (valid && my_kept) kept_all[gpos] = 1;
@@ -742,7 +782,16 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
     }
     if (kDbg && lane == 0) {
       atomicMax(&stats[16], Clock() - seg_t0);            // slowest component
-      atomicMax(&stats[17], (unsigned long long)cnt);     // largest component
+      if (atomicMax(&stats[17], (unsigned long long)cnt) < (unsigned long long)cnt) {
+        // counters of the largest component alone (the stage's critical path)
+        const unsigned long long seg_c1[12] = {dbg_batches, C.dbg_rounds, dbg_live, cyc_wait, cyc_load,
+                                               cyc_loop, C.dbg_chain, C.dbg_nwin, C.cyc_ph[0], C.cyc_ph[1],
+                                               C.cyc_ph[2] + C.cyc_ph[3], C.cyc_ph[4]};
+        stats[48] = Clock() - seg_t0;
+        for (int k = 0; k < 12; ++k) stats[49 + k] = seg_c1[k] - seg_c0[k];
+        stats[61] = C.dbg_cut - seg_cut0;
+        stats[62] = C.dbg_kept - seg_kept0;
+      }
     }
     __syncthreads();   // end of the segment (matches the producer's)
   }
@@ -754,28 +803,28 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
     return;
   }
   for (int off = 32; off > 0; off >>= 1) {
-    n_forced += __shfl_down(n_forced, off);
-    n_regular += __shfl_down(n_regular, off);
-    n_small += __shfl_down(n_small, off);
+    C.n_forced += __shfl_down(C.n_forced, off);
+    C.n_regular += __shfl_down(C.n_regular, off);
+    C.n_small += __shfl_down(C.n_small, off);
   }
   if (lane == 0) {
-    if (n_forced) atomicAdd(&stats[0], (unsigned long long)n_forced);
-    if (n_regular) atomicAdd(&stats[1], (unsigned long long)n_regular);
-    if (n_small) atomicAdd(&stats[2], (unsigned long long)n_small);
+    if (C.n_forced) atomicAdd(&stats[0], (unsigned long long)C.n_forced);
+    if (C.n_regular) atomicAdd(&stats[1], (unsigned long long)C.n_regular);
+    if (C.n_small) atomicAdd(&stats[2], (unsigned long long)C.n_small);
   }
   if (kDbg && lane == 0) {
-    atomicAdd(&stats[4], (unsigned long long)dbg_nwin);
-    atomicAdd(&stats[5], (unsigned long long)dbg_rounds);
-    atomicAdd(&stats[6], (unsigned long long)dbg_solo);
+    atomicAdd(&stats[4], (unsigned long long)C.dbg_nwin);
+    atomicAdd(&stats[5], (unsigned long long)C.dbg_rounds);
+    atomicAdd(&stats[6], (unsigned long long)C.dbg_solo);
     atomicAdd(&stats[7], (unsigned long long)dbg_batches);
     atomicAdd(&stats[18], cyc_load);
     atomicAdd(&stats[26], cyc_wait);   // consumer: ring empty
     atomicAdd(&stats[19], cyc_loop);
-    atomicAdd(&stats[20], (unsigned long long)dbg_chain);
-    atomicAdd(&stats[21], (unsigned long long)dbg_cut);
+    atomicAdd(&stats[20], (unsigned long long)C.dbg_chain);
+    atomicAdd(&stats[21], (unsigned long long)C.dbg_cut);
     atomicAdd(&stats[29], dbg_taken);
-    for (int k = 0; k < 5; ++k) atomicAdd(&stats[32 + k], cyc_ph[k]);
-    for (int k = 0; k < 6; ++k) atomicAdd(&stats[38 + k], dbg_x[k]);
+    for (int k = 0; k < 5; ++k) atomicAdd(&stats[32 + k], C.cyc_ph[k]);
+    for (int k = 0; k < 6; ++k) atomicAdd(&stats[38 + k], C.dbg_x[k]);
     atomicAdd(&stats[30], dbg_live);
   }
 }
