@@ -327,6 +327,19 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.bk_flags = bk_flags_.get();
   S.force_rollback = getenv("VSG_FORCE_ROLLBACK") ? 1 : 0;
   S.wave_v1 = getenv("VSG_WAVE_V1") ? 1 : 0;
+  S.spine_min = getenv("VSG_SPINE_MIN") ? atoi(getenv("VSG_SPINE_MIN")) : 4096;
+  S.spine_max_edges = getenv("VSG_SPINE_MAX_EDGES") ? atoi(getenv("VSG_SPINE_MAX_EDGES")) : (48 << 20);
+  S.spine_debug = getenv("VSG_SPINE_DEBUG") ? 1 : 0;
+  S.spine_check = getenv("VSG_SPINE_CHECK") ? 1 : 0;
+  if (S.spine_min > 0) {
+    const size_t ints = SpinePoolInts((size_t)S.spine_max_edges);
+    if (spine_pool_.size() < ints) spine_pool_.alloc(ints);
+  }
+  S.spine_pool = spine_pool_.get();
+  S.spine_pool_ints = spine_pool_.size();
+  S.nmap[0] = label_uf_.get();
+  S.nmap[1] = label_img_.get();
+  S.nmap[2] = adjust_.get();
   S.lead_pos = lead_pos_.get();
   S.l_ra = l_ra_.get();
   S.l_rb = l_rb_.get();
@@ -378,7 +391,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   int inert_mode = has_constraints_ ? 2 : 1;
   if (const char* e = getenv("VSG_INERT_MODE")) inert_mode = std::min(inert_mode, atoi(e));
   const bool debug_stages = getenv("VSG_DEBUG_STAGES") != nullptr;
-  const int num_windows = getenv("VSG_WINDOWS") ? std::max(1, atoi(getenv("VSG_WINDOWS"))) : 12;
+  const int num_windows = getenv("VSG_WINDOWS") ? std::max(1, atoi(getenv("VSG_WINDOWS"))) : 6;
   const int window_bushy = getenv("VSG_WINDOW_BUSHY") ? atoi(getenv("VSG_WINDOW_BUSHY")) : 64;
   const int window_min_edges = getenv("VSG_WINDOW_MIN") ? atoi(getenv("VSG_WINDOW_MIN")) : (4 << 20);
   // A bucket is replayed as consecutive *rank windows* (each a full stage: filter -> components ->

@@ -135,6 +135,13 @@ struct MergeScratch {
   int32_t* l_rb;
   uint32_t* l_gpos;
   int use_rle;           // replay one edge per run of equal root pairs (default on)
+  // Kruskal-tree replay of the large components (merge_spine.hip)
+  int spine_min;         // components of at least this many replayed edges; 0: never
+  int spine_max_edges;   // at most this many edges per stage (scratch pool)
+  int spine_debug, spine_check;
+  int32_t* spine_pool;   // scratch, SpinePoolInts(spine_max_edges) ints
+  size_t spine_pool_ints;
+  int32_t* nmap[3];      // three more [N] scratch maps (free during the bucket stages)
   int wave_v1;           // debug hook: use the sequential wave worker (k_merge_wave_v1)
   int wave_debug;        // use the instrumented build of the wave worker (counters, self checks)
   int wave_dbg;          // debug hook (bit mask): 1 no chain, 4 no hot region, 8 one generic lane per round,
@@ -168,6 +175,8 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
                     const uint32_t* list_slot_base, uint8_t* kept_all, NodeArrays nodes,
                     const MergeParams& P, int inert_mode, MergeScratch& S, hipStream_t s,
                     StageInfo* info = nullptr);
+// Scratch ints the Kruskal-tree replay (merge_spine.hip) needs for max_edges edges per stage.
+size_t SpinePoolInts(size_t max_edges);
 // Marks every edge of bucket 2048 (virtual edges) as kept.
 void LaunchKeepVirtualBucket(const ListDesc* lists, int num_lists, hipStream_t s);
 

@@ -4,6 +4,9 @@
 #ifndef VSG_MERGE_COMMON_H_
 #define VSG_MERGE_COMMON_H_
 
+#include <functional>
+#include <vector>
+
 #include "device_graph.h"
 
 namespace vsg {
@@ -155,6 +158,8 @@ struct StageThr {
   int min_size;
   int rle;         // the stage replays run leaders only (see k_mark_leaders): a constrained split
                    // invalidates the run's followers and has to be reported as a violation
+  int side;        // the segments are side clusters of a spine (merge_spine.hip): a kept edge means
+                   // the cluster does not end up as one region and is reported as a violation
 };
 
 __device__ __forceinline__ int DecideEdge(RState& s1, RState& s2, const StageThr& T, int& stat) {
@@ -298,11 +303,35 @@ struct WorkerArgs {
   int optimistic;
   int32_t* violation;
   unsigned long long* stats;
+  int wave_min;             // the wave worker takes components of more than wave_min and less than
+  int wave_max;             // wave_max edges (k_merge_small: up to kSmallSegment, when wave_min is that)
 };
 // Edge-by-edge replay by one wavefront (round 1a; debug reference, VSG_WAVE_V1).
 void LaunchMergeWaveV1(int grid, const WorkerArgs& a, hipStream_t s);
 // Round-based replay by one consumer wavefront + one reader wavefront (the default).
 void LaunchMergeWave(int grid, const WorkerArgs& a, bool instrumented, int dbg_flags, hipStream_t s);
+
+// Kruskal-tree replay of the large components (merge_spine.hip).
+struct SpineSeg {
+  int off;   // first edge in the component-sorted arrays
+  int cnt;
+};
+struct SpineInput {
+  std::vector<SpineSeg> segs;
+};
+// Launches the ordinary workers (k_merge_small + wave worker) on the given segments.
+using SpineWorkers = std::function<void(const WorkerArgs&, int n_edges)>;
+// The head of the spine scratch pool holds the list SelectLargeSegments reads back.
+constexpr int kSpineListCap = 4095;
+constexpr size_t kSpineListInts = 8192;
+// Chooses the components (segments) of at least min_cnt edges for the Kruskal-tree replay, raising
+// the threshold until all of them fit max_edges; returns the threshold (the ordinary workers leave
+// segments of at least that many edges alone), 0x7fffffff when there is none.  Synchronises.
+int SelectLargeSegments(int max_segs, const int32_t* num_segs, const int32_t* seg_off, const int32_t* seg_cnt,
+                        int min_cnt, long long max_edges, int32_t* d_list, hipStream_t s, SpineInput* out);
+// pool_used: ints of S.spine_pool already taken (by the caller's lists and outer levels).
+bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch& S, hipStream_t s,
+                        const SpineWorkers& run_workers, size_t pool_used, int depth);
 
 }  // namespace vsg
 

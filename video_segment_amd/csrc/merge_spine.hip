@@ -1,0 +1,1034 @@
+// merge_spine.hip -- the large components of a stage, replayed along their Kruskal tree.
+//
+// The ordered replay of one component is Kruskal's algorithm with a merge test: as long as every
+// live edge merges (what the force-merge buckets do, and what the giant components of the bench
+// input do without exception), the merges are the edges of the component's minimum spanning tree
+// by rank (rank = position in the component's edge sequence), and *which* edges merge does not
+// depend on any float.  Only the region means do, through the order of the merges.  Seen from one
+// vertex R (the largest region of the component), the replay is:
+//
+//   t(x)  = rank at which vertex x joins R's cluster = largest rank on the tree path R..x;
+//   spine = the tree edges that attach something to R's cluster: rank(e) == t(child end of e);
+//   side cluster of a spine edge e = the vertices x with t(x) == rank(e): they are connected among
+//           themselves by edges of smaller rank, every other edge that leaves them has a larger
+//           rank (minimax property), so before rank(e) they only ever interact with each other --
+//           a side cluster is an independent sequential sub-problem, exact whatever its outcomes;
+//   every other edge has both ends in R's cluster by the time it is visited: internal.
+//
+// So: the side clusters are replayed by the ordinary workers (all of them at once, they are
+// usually a pixel or two), then one wavefront per component walks the spine in rank order and
+// absorbs the finished side clusters into R's cluster, 64 at a time, with the same chain
+// arithmetic as k_merge_wave (sizes by prefix sum, weights and divisions lane parallel, the mean
+// as a systolic recurrence, all merge tests verified afterwards; anything that is not a plain
+// chain step runs through the exact DecideEdge).  The region states of the partners are final
+// when the spine starts, so a reader wavefront can fetch them arbitrarily far ahead.
+//
+// The structure is only valid while every live edge merges.  A side cluster that keeps an edge
+// or a spine edge that is kept raises the stage's violation flag: the stage is undone from its
+// backup and replayed by the ordinary workers (RunBucketStage), so the result is always the
+// sequential one.
+//
+// Tree machinery (all data parallel): Boruvka for the tree edges, Euler tour + list ranking to
+// root the tree at R, pointer jumping for the path maxima and for the side cluster of every vertex.
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstdio>
+#include <unordered_map>
+#include <vector>
+
+#include "merge_common.h"
+
+namespace vsg {
+
+namespace {
+
+constexpr int kNone = -1;
+
+static inline unsigned Blocks(size_t n) { return (unsigned)((n + 255) / 256); }
+
+// Component of edge e of the concatenated list: the largest k with comp_base[k] <= e.
+__device__ __forceinline__ int CompOf(const int32_t* __restrict__ comp_base, int K, int e) {
+  int lo = 0, hi = K;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (comp_base[mid] <= e) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// ---- edges of the large components, concatenated --------------------------------------------------
+__global__ __launch_bounds__(256) void k_spine_gather(int mE, int K, const int32_t* __restrict__ comp_base,
+                                                       const int32_t* __restrict__ comp_off,
+                                                       const int32_t* __restrict__ s_ra,
+                                                       const int32_t* __restrict__ s_rb,
+                                                       int32_t* __restrict__ eu, int32_t* __restrict__ ev,
+                                                       int32_t* __restrict__ estate, int32_t* __restrict__ cc,
+                                                       uint32_t* __restrict__ best) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= mE) return;
+  const int lo = CompOf(comp_base, K, e);
+  const int pos = comp_off[lo] + (e - comp_base[lo]);
+  const int u = s_ra[pos], v = s_rb[pos];
+  eu[e] = u;
+  ev[e] = v;
+  estate[e] = 0;
+  cc[u] = u;
+  cc[v] = v;
+  best[u] = 0xffffffffu;
+  best[v] = 0xffffffffu;
+}
+
+// ---- Boruvka ----------------------------------------------------------------------------------------
+// estate: 0 alive, 1 tree edge, 2 internal, 3 tree edge chosen in this round.
+// best[c] holds the smallest rank among the edges that leave component c, stamped with the round
+// ((31 - round) << 27 | rank, unsigned): a later round's entry is smaller than anything an
+// earlier round left behind, so the table never has to be cleared.
+__device__ __forceinline__ uint32_t BorKey(int round, int e) { return ((uint32_t)(31 - round) << 27) | (uint32_t)e; }
+
+__global__ __launch_bounds__(256) void k_bor_min(int mE, int round, const int32_t* __restrict__ eu,
+                                                  const int32_t* __restrict__ ev, int32_t* __restrict__ estate,
+                                                  int32_t* __restrict__ cc, uint32_t* __restrict__ best,
+                                                  int32_t* __restrict__ ecu, int32_t* __restrict__ ecv,
+                                                  int32_t* __restrict__ alive) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  bool live = false;
+  if (e < mE && estate[e] == 0) {
+    const int cu = CcFind(cc, eu[e]), cv = CcFind(cc, ev[e]);
+    if (cu == cv) {
+      estate[e] = 2;
+    } else {
+      live = true;
+      ecu[e] = cu;
+      ecv[e] = cv;
+      const uint32_t key = BorKey(round, e);
+      // ranks only ever decrease: the read keeps all but the first few edges of a huge component
+      // away from the atomic
+      if (key < __hip_atomic_load(&best[cu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&best[cu], key);
+      if (key < __hip_atomic_load(&best[cv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&best[cv], key);
+    }
+  }
+  const unsigned long long m = __ballot(live);
+  if (m && (threadIdx.x & 63) == 0) atomicAdd(alive, (int)__popcll(m));
+}
+
+__global__ __launch_bounds__(256) void k_bor_mark(int mE, int round, int32_t* __restrict__ estate,
+                                                   const uint32_t* __restrict__ best,
+                                                   const int32_t* __restrict__ ecu, const int32_t* __restrict__ ecv) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= mE || estate[e] != 0) return;
+  const uint32_t key = BorKey(round, e);
+  if (best[ecu[e]] == key || best[ecv[e]] == key) estate[e] = 3;
+}
+
+__global__ __launch_bounds__(256) void k_bor_union(int mE, const int32_t* __restrict__ eu,
+                                                    const int32_t* __restrict__ ev, int32_t* __restrict__ estate,
+                                                    int32_t* __restrict__ cc) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= mE || estate[e] != 3) return;
+  CcUnion(cc, eu[e], ev[e]);
+  estate[e] = 1;
+}
+
+// ---- R: the largest region of every component --------------------------------------------------------
+__global__ __launch_bounds__(256) void k_spine_pick_root(int mE, int K, const int32_t* __restrict__ eu,
+                                                          const int32_t* __restrict__ ev,
+                                                          const int32_t* __restrict__ comp_base, NodeArrays nodes,
+                                                          unsigned long long* __restrict__ root_key) {
+  __shared__ unsigned long long red[256];
+  __shared__ int comp0;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long key = 0;
+  int k = -1;
+  if (e < mE) {
+    k = CompOf(comp_base, K, e);
+    const int u = eu[e], v = ev[e];
+    const unsigned su = (unsigned)__float_as_int(nodes.desc_sz[u].w);
+    const unsigned sv = (unsigned)__float_as_int(nodes.desc_sz[v].w);
+    const unsigned long long ku = ((unsigned long long)su << 32) | (unsigned)(~u);
+    const unsigned long long kv = ((unsigned long long)sv << 32) | (unsigned)(~v);
+    key = ku > kv ? ku : kv;
+  }
+  if (threadIdx.x == 0) comp0 = k;
+  __syncthreads();
+  const bool same = (k == comp0);
+  red[threadIdx.x] = same ? key : 0ull;
+  if (!same && k >= 0) atomicMax(&root_key[k], key);   // a block that straddles two components
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && comp0 >= 0) atomicMax(&root_key[comp0], red[0]);
+}
+
+__global__ void k_spine_roots(int K, const unsigned long long* __restrict__ root_key,
+                              int32_t* __restrict__ root_vertex, int32_t* __restrict__ childidx) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= K) return;
+  const int r = (int)(~(unsigned)(root_key[k] & 0xffffffffull));
+  root_vertex[k] = r;
+  childidx[r] = kNone;
+}
+
+// ---- tree edges -> arcs ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flag_state(int mE, const int32_t* __restrict__ estate, int want,
+                                                     int32_t* __restrict__ flag) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < mE) flag[e] = (estate[e] == want) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_compact_tree(int mE, const int32_t* __restrict__ flag,
+                                                       const int32_t* __restrict__ scan,
+                                                       int32_t* __restrict__ te_e) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < mE && flag[e]) te_e[scan[e]] = e;
+}
+
+__global__ void k_scan_total(int n, const int32_t* __restrict__ flag, const int32_t* __restrict__ scan,
+                             int32_t* __restrict__ count) {
+  *count = scan[n - 1] + flag[n - 1];
+}
+
+__global__ __launch_bounds__(256) void k_arc_keys(int mt, const int32_t* __restrict__ te_e,
+                                                   const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= 2 * mt) return;
+  const int e = te_e[a >> 1];
+  keys[a] = (uint32_t)((a & 1) ? ev[e] : eu[e]);   // source vertex of the arc
+  vals[a] = (uint32_t)a;
+}
+
+__global__ __launch_bounds__(256) void k_arc_first(int na, const uint32_t* __restrict__ ks,
+                                                    const uint32_t* __restrict__ as, int32_t* __restrict__ firstq,
+                                                    int32_t* __restrict__ pos_arc) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= na) return;
+  if (q == 0 || ks[q] != ks[q - 1]) firstq[ks[q]] = q;
+  pos_arc[as[q]] = q;
+}
+
+// Euler tour successor: after arc u->v comes the arc that follows v->u in v's list (cyclically).
+// The tour of a tree is cut in front of the first arc of its root.
+__global__ __launch_bounds__(256) void k_arc_succ(int na, const uint32_t* __restrict__ ks,
+                                                   const uint32_t* __restrict__ as,
+                                                   const int32_t* __restrict__ firstq,
+                                                   const int32_t* __restrict__ pos_arc,
+                                                   const int32_t* __restrict__ te_e,
+                                                   const int32_t* __restrict__ comp_base, int K,
+                                                   const int32_t* __restrict__ root_vertex,
+                                                   int32_t* __restrict__ succ, int32_t* __restrict__ dist) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= na) return;
+  const int qb = pos_arc[a ^ 1];
+  const uint32_t w = ks[qb];   // source of the twin = destination of a
+  int q = qb + 1;
+  if (q == na || ks[q] != w) q = firstq[w];
+  int nx = (int)as[q];
+  const int root = root_vertex[CompOf(comp_base, K, te_e[a >> 1])];
+  if ((int)w == root && q == firstq[root]) nx = kNone;   // back at the start of the tour
+  succ[a] = nx;
+  dist[a] = nx == kNone ? 0 : 1;
+}
+
+// List ranking by pointer jumping (distance to the end of the tour), double buffered.
+__global__ __launch_bounds__(256) void k_rank_step(int na, const int32_t* __restrict__ s_in,
+                                                    const int32_t* __restrict__ d_in, int32_t* __restrict__ s_out,
+                                                    int32_t* __restrict__ d_out) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= na) return;
+  const int s = s_in[a];
+  if (s == kNone) {
+    s_out[a] = kNone;
+    d_out[a] = d_in[a];
+  } else {
+    s_out[a] = s_in[s];
+    d_out[a] = d_in[a] + d_in[s];
+  }
+}
+
+// The arc walked first goes down: its destination is the child.
+__global__ __launch_bounds__(256) void k_tree_parent(int mt, const int32_t* __restrict__ te_e,
+                                                      const int32_t* __restrict__ eu,
+                                                      const int32_t* __restrict__ ev,
+                                                      const int32_t* __restrict__ dist, int32_t* __restrict__ child,
+                                                      int32_t* __restrict__ par, int32_t* __restrict__ childidx) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= mt) return;
+  const int e = te_e[j];
+  const bool down = dist[2 * j] > dist[2 * j + 1];   // u->v comes first
+  const int c = down ? ev[e] : eu[e];
+  child[j] = c;
+  par[j] = down ? eu[e] : ev[e];
+  childidx[c] = j;
+}
+
+// jump: tree edge of the parent (kNone: the parent is the root); val: largest rank on the path so far.
+__global__ __launch_bounds__(256) void k_jump_init(int mt, const int32_t* __restrict__ te_e,
+                                                    const int32_t* __restrict__ par,
+                                                    const int32_t* __restrict__ childidx, int32_t* __restrict__ jump,
+                                                    int32_t* __restrict__ val) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= mt) return;
+  jump[j] = childidx[par[j]];
+  val[j] = te_e[j];
+}
+
+__global__ __launch_bounds__(256) void k_jump_max(int mt, const int32_t* __restrict__ j_in,
+                                                   const int32_t* __restrict__ v_in, int32_t* __restrict__ j_out,
+                                                   int32_t* __restrict__ v_out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= mt) return;
+  const int p = j_in[j];
+  if (p == kNone) {
+    j_out[j] = kNone;
+    v_out[j] = v_in[j];
+  } else {
+    j_out[j] = j_in[p];
+    v_out[j] = max(v_in[j], v_in[p]);
+  }
+}
+
+// head: the spine edge through which the vertex joins R's cluster (itself for the child of a spine
+// edge, otherwise the head of the parent: a non-spine edge has a smaller rank than t(parent)).
+__global__ __launch_bounds__(256) void k_head_init(int mt, const int32_t* __restrict__ te_e,
+                                                    const int32_t* __restrict__ tval,
+                                                    const int32_t* __restrict__ par,
+                                                    const int32_t* __restrict__ childidx, int32_t* __restrict__ head) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= mt) return;
+  head[j] = (tval[j] == te_e[j]) ? j : childidx[par[j]];
+}
+
+__global__ __launch_bounds__(256) void k_head_step(int mt, const int32_t* __restrict__ h_in,
+                                                    int32_t* __restrict__ h_out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < mt) h_out[j] = h_in[h_in[j]];
+}
+
+// ---- classification of every edge ----------------------------------------------------------------------
+// side_key[e]: head (tree edge index) of the side cluster the edge is replayed in, or kNone;
+// spine_flag[e]: the edge attaches its side cluster to R's cluster.
+__global__ __launch_bounds__(256) void k_classify(int mE, const int32_t* __restrict__ eu,
+                                                   const int32_t* __restrict__ ev,
+                                                   const int32_t* __restrict__ estate,
+                                                   const int32_t* __restrict__ childidx,
+                                                   const int32_t* __restrict__ head,
+                                                   const int32_t* __restrict__ te_e,
+                                                   int32_t* __restrict__ side_flag, int32_t* __restrict__ side_key,
+                                                   int32_t* __restrict__ spine_flag) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= mE) return;
+  const int ju = childidx[eu[e]], jv = childidx[ev[e]];   // kNone: the root
+  const int hu = ju == kNone ? kNone : head[ju];
+  const int hv = jv == kNone ? kNone : head[jv];
+  const bool side = hu != kNone && hu == hv && e < te_e[hu];
+  side_flag[e] = side ? 1 : 0;
+  side_key[e] = side ? hu : kNone;
+  // a tree edge is a spine edge when it is the head of its own child
+  bool spine = false;
+  if (estate[e] == 1) {
+    const int jc = (ju != kNone && te_e[ju] == e) ? ju : jv;   // the tree edge e itself (child end)
+    spine = head[jc] == jc;
+  }
+  spine_flag[e] = spine ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_compact_side(int mE, const int32_t* __restrict__ flag,
+                                                       const int32_t* __restrict__ scan,
+                                                       const int32_t* __restrict__ side_key,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= mE) return;
+  if (flag[e]) {
+    keys[scan[e]] = (uint32_t)side_key[e];
+    idx[scan[e]] = (uint32_t)e;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gather_side(int n, const uint32_t* __restrict__ sorted_e,
+                                                      const int32_t* __restrict__ comp_base,
+                                                      const int32_t* __restrict__ comp_off, int K,
+                                                      const int32_t* __restrict__ s_ra,
+                                                      const int32_t* __restrict__ s_rb,
+                                                      const uint32_t* __restrict__ s_gpos,
+                                                      int32_t* __restrict__ o_ra, int32_t* __restrict__ o_rb,
+                                                      uint32_t* __restrict__ o_gpos) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int e = (int)sorted_e[i];
+  const int k = CompOf(comp_base, K, e);
+  const int pos = comp_off[k] + (e - comp_base[k]);
+  o_ra[i] = s_ra[pos];
+  o_rb[i] = s_rb[pos];
+  o_gpos[i] = s_gpos[pos];
+}
+
+// Spine edges in rank order: the child end (whose side cluster is absorbed) and whether it is the
+// edge's first region.  comp_spine[k]: start of component k's spine (from the scan).
+__global__ __launch_bounds__(256) void k_compact_spine(int mE, int K, const int32_t* __restrict__ flag,
+                                                        const int32_t* __restrict__ scan,
+                                                        const int32_t* __restrict__ eu,
+                                                        const int32_t* __restrict__ ev,
+                                                        const int32_t* __restrict__ childidx,
+                                                        const int32_t* __restrict__ te_e,
+                                                        const int32_t* __restrict__ comp_base,
+                                                        int32_t* __restrict__ sp_child, int32_t* __restrict__ sp_is_a,
+                                                        int32_t* __restrict__ comp_spine) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= mE) return;
+  if (flag[e]) {
+    const int ju = childidx[eu[e]];
+    const bool child_is_u = ju != kNone && te_e[ju] == e;
+    sp_child[scan[e]] = child_is_u ? eu[e] : ev[e];
+    sp_is_a[scan[e]] = child_is_u ? 1 : 0;
+  }
+  if (e == mE - 1) comp_spine[K] = scan[e] + flag[e];
+  if (e < K) comp_spine[e] = scan[comp_base[e]];
+}
+
+// ---- the spine ---------------------------------------------------------------------------------------------
+constexpr int kSpineFill = 4;        // 64-edge groups per fill
+constexpr int kSpineFills = 8;       // fills the ring holds
+constexpr int kSpineRing = kSpineFills * kSpineFill * 64;
+constexpr int kSpineReaders = 3;     // reader wavefronts: one consumer cannot hide the latency of a
+                                     // dependent chain of loads per fill behind one reader
+
+struct SpineRing {
+  int32_t p[kSpineRing];       // representative of the side cluster
+  float4 ds[kSpineRing];
+  int32_t cons[kSpineRing];
+  int32_t flags[kSpineRing];
+  int32_t is_a[kSpineRing];
+  int ready[kSpineFills];   // fill f is complete when ready[f % kSpineFills] == f + 1
+  int consumed;
+  int abort;   // the consumer gave up (violation): the readers stop
+};
+
+__device__ __forceinline__ void WaveSyncS() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
+__global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const int32_t* __restrict__ comp_spine,
+                                               const int32_t* __restrict__ root_vertex,
+                                               const int32_t* __restrict__ sp_child,
+                                               const int32_t* __restrict__ sp_is_a, NodeArrays nodes, StageThr T,
+                                               int optimistic, int32_t* __restrict__ violation,
+                                               unsigned long long* __restrict__ stats) {
+  __shared__ SpineRing ring;
+  const int k = blockIdx.x;
+  if (k >= K) return;
+  const int lane = threadIdx.x & 63;
+  const int beg = comp_spine[k], n = comp_spine[k + 1] - beg;
+  if (threadIdx.x < kSpineFills) ring.ready[threadIdx.x] = 0;
+  if (threadIdx.x == 0) {
+    ring.consumed = 0;
+    ring.abort = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) {
+    // ---- readers: representative and state of every side cluster, in spine order ------------------------
+    const int reader = (threadIdx.x >> 6) - 1;
+    for (int f = reader; f * (kSpineFill * 64) < n; f += kSpineReaders) {
+      const int next = f * (kSpineFill * 64);
+      bool stop = false;
+      while (next + kSpineFill * 64 - __hip_atomic_load(&ring.consumed, __ATOMIC_ACQUIRE,
+                                                          __HIP_MEMORY_SCOPE_WORKGROUP) > kSpineRing) {
+        if (__hip_atomic_load(&ring.abort, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          stop = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (stop) break;
+      int c[kSpineFill], isa[kSpineFill];
+      bool vd[kSpineFill];
+#pragma unroll
+      for (int q = 0; q < kSpineFill; ++q) {
+        const int i = next + q * 64 + lane;
+        vd[q] = i < n;
+        c[q] = vd[q] ? sp_child[beg + i] : root_vertex[k];
+        isa[q] = vd[q] ? sp_is_a[beg + i] : 0;
+      }
+      for (bool any = true; any;) {   // all root searches of the fill advance together
+        int pa[kSpineFill];
+#pragma unroll
+        for (int q = 0; q < kSpineFill; ++q) pa[q] = nodes.parent[c[q]];
+        any = false;
+#pragma unroll
+        for (int q = 0; q < kSpineFill; ++q) {
+          if (pa[q] != c[q]) {
+            c[q] = pa[q];
+            any = true;
+          }
+        }
+      }
+      RState st[kSpineFill];
+#pragma unroll
+      for (int q = 0; q < kSpineFill; ++q) st[q] = LoadState(nodes, c[q]);
+#pragma unroll
+      for (int q = 0; q < kSpineFill; ++q) {
+        if (vd[q]) {
+          const int slot = (next + q * 64 + lane) & (kSpineRing - 1);
+          ring.p[slot] = c[q];
+          ring.ds[slot] = make_float4(st[q].d0, st[q].d1, st[q].d2, __int_as_float(st[q].sz));
+          ring.cons[slot] = st[q].cons;
+          ring.flags[slot] = st[q].flags;
+          ring.is_a[slot] = isa[q];
+        }
+      }
+      WaveSyncS();
+      if (lane == 0) {
+        __hip_atomic_store(&ring.ready[f % kSpineFills], f + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    return;
+  }
+
+  // ---- consumer: R's cluster absorbs the side clusters in rank order --------------------------------------
+  int rep = root_vertex[k];
+  RState H = LoadState(nodes, rep);
+  unsigned n_forced = 0, n_regular = 0, n_small = 0;   // per lane
+  bool violated = false;
+  for (int base = 0; base < n && !violated; base += 64) {
+    const int cnt = n - base < 64 ? n - base : 64;
+    const int fill = base / (kSpineFill * 64);
+    while (__hip_atomic_load(&ring.ready[fill % kSpineFills], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) !=
+           fill + 1) {
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const bool valid = lane < cnt;
+    int p = 0, is_a = 0;
+    RState P = {};
+    if (valid) {
+      const int slot = (base + lane) & (kSpineRing - 1);
+      p = ring.p[slot];
+      const float4 ds = ring.ds[slot];
+      P.d0 = ds.x;
+      P.d1 = ds.y;
+      P.d2 = ds.z;
+      P.sz = __float_as_int(ds.w);
+      P.cons = ring.cons[slot];
+      P.flags = ring.flags[slot];
+      is_a = ring.is_a[slot];
+    }
+    WaveSyncS();   // the entries are in registers: their slots may be reused
+    if (lane == 0) {
+      __hip_atomic_store(&ring.consumed, base + cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    int start = 0;       // first lane not replayed yet (wave uniform)
+    bool generic_next = false;   // lane `start` failed its chain test: exact replay
+    while (start < cnt) {
+      // ---- chain: the leading run of plain, smaller partners that merge ---------------------------------------
+      const bool fin = (H.flags & kFlagFinalized) != 0;
+      const bool mode_ok = !(H.flags & kFlagNoDesc) && (!fin || H.sz >= T.min_size);
+      const bool part = valid && lane >= start && mode_ok && P.flags == 0 &&
+                        (P.cons < 0 || P.cons == H.cons) && P.sz < H.sz;
+      const bool merging = part && (P.cons >= 0 || !fin || P.sz < T.min_size);
+      const unsigned long long pend = __ballot(valid && lane >= start);
+      const unsigned long long elig = __ballot(merging);
+      const unsigned long long stop = pend & ~elig;
+      int end = stop ? (int)__builtin_ctzll(stop) : cnt;   // chain = [start, end)
+      if (generic_next) end = start;
+      if (end > start) {
+        const bool in_chain = lane >= start && lane < end;
+        const bool case_s = in_chain && P.cons >= 0;
+        const int v = in_chain ? P.sz : 0;
+        const int incl = WaveInclusiveSum(v);
+        const int S = H.sz + incl - v;     // size of R's cluster before this lane's merge
+        // MergeStates with o = partner, m = R's cluster (symmetric in the two)
+        const float denom = 1.0f / (float)(P.sz + S);
+        const float ca = (float)P.sz * denom;
+        const float cb = (float)S * denom;
+        float c = in_chain ? cb : 1.0f;
+        float u0 = in_chain ? ca * P.d0 : 0.0f;
+        float u1 = in_chain ? ca * P.d1 : 0.0f;
+        float u2 = in_chain ? ca * P.d2 : 0.0f;
+        if (lane == start) {   // starts from the cluster's mean and ignores what is shifted in
+          u0 = u0 + c * H.d0;
+          u1 = u1 + c * H.d1;
+          u2 = u2 + c * H.d2;
+          c = 0.0f;
+        }
+        float g0 = u0, g1 = u1, g2 = u2;
+        for (int s4 = 1; s4 < end - start; s4 += 4) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            g0 = u0 + c * DppWaveShr1Zero(g0);
+            g1 = u1 + c * DppWaveShr1Zero(g1);
+            g2 = u2 + c * DppWaveShr1Zero(g2);
+          }
+        }
+        float r0 = DppWaveShr1Old(g0, H.d0);   // mean before this lane's merge
+        float r1 = DppWaveShr1Old(g1, H.d1);
+        float r2 = DppWaveShr1Old(g2, H.d2);
+        if (lane == start) {
+          r0 = H.d0;
+          r1 = H.d1;
+          r2 = H.d2;
+        }
+        const float x = r0 - P.d0, y = r1 - P.d1, z = r2 - P.d2;
+        const float sd = (x * x + y * y + z * z) * (1.0f / 3.0f);
+        const bool pass = case_s ? !(sd > T.split_s) : (sd <= T.pass_s);
+        const bool tested = case_s || (in_chain && !fin);
+        const unsigned long long fail = __ballot(in_chain && tested && !pass);
+        const int fcut = fail ? (int)__builtin_ctzll(fail) : end;
+        if (fcut > start) {
+          if (fail) {
+            H.d0 = ReadLaneF(r0, fcut);
+            H.d1 = ReadLaneF(r1, fcut);
+            H.d2 = ReadLaneF(r2, fcut);
+            H.sz = ReadLaneI(S, fcut);
+          } else {
+            H.d0 = ReadLaneF(g0, end - 1);
+            H.d1 = ReadLaneF(g1, end - 1);
+            H.d2 = ReadLaneF(g2, end - 1);
+            H.sz = H.sz + ReadLaneI(incl, end - 1);
+          }
+          if (in_chain && lane < fcut) {
+            nodes.parent[p] = rep;
+            if (case_s) ++n_forced; else if (fin) ++n_small; else ++n_regular;
+          }
+        }
+        start = fcut;
+        generic_next = fail != 0;
+        if (!generic_next) continue;
+      }
+      if (start >= cnt) break;
+      // ---- lane `start` through the exact edge semantics (uniform) -------------------------------------------
+      generic_next = false;
+      const RState Ps = ReadLaneState(P, start);
+      const int pid = ReadLaneI(p, start);
+      const bool child_first = ReadLaneI(is_a, start) != 0;
+      RState s1 = child_first ? Ps : H;
+      RState s2 = child_first ? H : Ps;
+      const RState o1 = s1, o2 = s2;
+      int stat;
+      const int out = DecideEdge(s1, s2, T, stat);
+      if (out == kOutKeep) {   // the structure assumed a merge
+        violated = true;
+        break;
+      }
+      if (optimistic) {
+        const bool vio = (out == kOutMerge1) ? TentativeViolated(o1, o2, s1, s1)
+                                             : TentativeViolated(o1, o2, s2, s2);
+        if (vio) {
+          violated = true;
+          break;
+        }
+      }
+      const bool partner_wins = (out == kOutMerge1) == child_first;
+      if (lane == 0) {
+        n_forced += (stat == 1);
+        n_regular += (stat == 2);
+        n_small += (stat == 3);
+        if (partner_wins) {
+          // R's representative is merged away: it keeps its own constraint field (MergeRegions
+          // only updates the survivor), which may have changed since it was loaded
+          nodes.cons[rep] = H.cons;
+          nodes.parent[rep] = pid;
+        } else {
+          nodes.parent[pid] = rep;
+        }
+      }
+      if (partner_wins) rep = pid;
+      H = (out == kOutMerge1) ? s1 : s2;
+      ++start;
+    }
+  }
+  if (violated) {
+    if (lane == 0) {
+      *violation = 1;
+      __hip_atomic_store(&ring.abort, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return;   // the stage is undone
+  }
+  if (lane == 0) StoreState(nodes, rep, H);
+  for (int off = 32; off > 0; off >>= 1) {
+    n_forced += __shfl_down(n_forced, off);
+    n_regular += __shfl_down(n_regular, off);
+    n_small += __shfl_down(n_small, off);
+  }
+  if (lane == 0) {
+    if (n_forced) atomicAdd(&stats[0], (unsigned long long)n_forced);
+    if (n_regular) atomicAdd(&stats[1], (unsigned long long)n_regular);
+    if (n_small) atomicAdd(&stats[2], (unsigned long long)n_small);
+  }
+}
+
+// Debug self check (VSG_SPINE_CHECK): the classification against a sequential replay of the
+// structure on the host -- Kruskal with "is in R's cluster" per cluster.
+void SpineSelfCheck(const std::vector<int32_t>& base, int mE, const int32_t* d_eu, const int32_t* d_ev,
+                    const int32_t* d_root, const int32_t* d_side_key, const int32_t* d_spine_flag,
+                    const int32_t* d_te_e, int mt) {
+  const int K = (int)base.size() - 1;
+  std::vector<int32_t> eu(mE), ev(mE), side_key(mE), spine_flag(mE), te_e(mt), root(K);
+  VSG_HIP(hipMemcpy(eu.data(), d_eu, mE * sizeof(int32_t), hipMemcpyDeviceToHost));
+  VSG_HIP(hipMemcpy(ev.data(), d_ev, mE * sizeof(int32_t), hipMemcpyDeviceToHost));
+  VSG_HIP(hipMemcpy(side_key.data(), d_side_key, mE * sizeof(int32_t), hipMemcpyDeviceToHost));
+  VSG_HIP(hipMemcpy(spine_flag.data(), d_spine_flag, mE * sizeof(int32_t), hipMemcpyDeviceToHost));
+  VSG_HIP(hipMemcpy(te_e.data(), d_te_e, mt * sizeof(int32_t), hipMemcpyDeviceToHost));
+  VSG_HIP(hipMemcpy(root.data(), d_root, K * sizeof(int32_t), hipMemcpyDeviceToHost));
+  long long bad = 0;
+  for (int k = 0; k < K; ++k) {
+    std::unordered_map<int, int> id;   // vertex -> dense index
+    std::vector<int> uf, t;
+    std::vector<char> in_r;
+    std::vector<std::vector<int>> members;
+    auto vid = [&](int x) {
+      auto it = id.find(x);
+      if (it != id.end()) return it->second;
+      const int i = (int)uf.size();
+      id.emplace(x, i);
+      uf.push_back(i);
+      t.push_back(-1);
+      in_r.push_back(0);
+      members.push_back({i});
+      return i;
+    };
+    auto find = [&](int x) {
+      while (uf[x] != x) x = uf[x] = uf[uf[x]];
+      return x;
+    };
+    in_r[vid(root[k])] = 1;
+    std::vector<int> cls(base[k + 1] - base[k]);   // 0 dropped, 1 side, 2 spine
+    for (int e = base[k]; e < base[k + 1]; ++e) {
+      int a = find(vid(eu[e])), b = find(vid(ev[e]));
+      int c;
+      if (a == b) {
+        c = in_r[a] ? 0 : 1;
+      } else {
+        if (in_r[a] != in_r[b]) {
+          c = 2;
+          for (int x : members[in_r[a] ? b : a]) t[x] = e;
+        } else {
+          c = 1;
+        }
+        if (members[a].size() < members[b].size()) std::swap(a, b);
+        uf[b] = a;
+        in_r[a] = in_r[a] | in_r[b];
+        members[a].insert(members[a].end(), members[b].begin(), members[b].end());
+        std::vector<int>().swap(members[b]);
+      }
+      cls[e - base[k]] = c;
+    }
+    for (int e = base[k]; e < base[k + 1]; ++e) {
+      const int c = cls[e - base[k]];
+      const bool side = side_key[e] != kNone;
+      if (side != (c == 1)) ++bad;
+      else if (side && te_e[side_key[e]] != t[id[eu[e]]]) ++bad;
+      if ((spine_flag[e] != 0) != (c == 2)) ++bad;
+      if (bad && bad < 8) {
+        std::fprintf(stderr, "[vsg] spine check: comp %d edge %d expected class %d t %d, device side_key %d (rank %d) spine %d\n",
+                     k, e, c, t[id[eu[e]]], side_key[e], side_key[e] != kNone ? te_e[side_key[e]] : -1,
+                     spine_flag[e]);
+      }
+    }
+  }
+  if (bad) throw Error(-4 /* VSG_ERR_INTERNAL */, "spine: the structure differs from the sequential replay");
+}
+
+// Components of at least min_cnt replayed edges: (offset, count) pairs.  out[0] = number found
+// (may exceed the capacity).
+__global__ __launch_bounds__(256) void k_list_large_segments(int max_segs, const int32_t* __restrict__ num_segs,
+                                                              const int32_t* __restrict__ seg_off,
+                                                              const int32_t* __restrict__ seg_cnt, int min_cnt,
+                                                              int32_t* __restrict__ out) {
+  const int seg = blockIdx.x * 256 + threadIdx.x;
+  if (seg >= max_segs || seg >= *num_segs) return;
+  const int cnt = seg_cnt[seg];
+  if (cnt < min_cnt) return;
+  const int i = atomicAdd(&out[0], 1);
+  if (i < kSpineListCap) {
+    out[1 + 2 * i] = seg_off[seg];
+    out[2 + 2 * i] = cnt;
+  }
+}
+
+struct Pool {   // stack allocator over the spine scratch
+  int32_t* base;
+  size_t cap, used = 0;
+  bool ok = true;
+  size_t mark() const { return used; }
+  void release(size_t m) { used = m; }
+  int32_t* take(size_t n) {
+    n = (n + 63) & ~(size_t)63;
+    if (used + n > cap) {
+      ok = false;
+      return base;
+    }
+    int32_t* p = base + used;
+    used += n;
+    return p;
+  }
+};
+
+}  // namespace
+
+// 7 ints per edge, 29 per tree edge while the trees are rooted (a fifth to two thirds of the edges
+// are tree edges), nested levels on top: a level that does not fit is left to the ordinary workers.
+size_t SpinePoolInts(size_t max_edges) { return 16 * max_edges + 64 * 1024; }
+
+int SelectLargeSegments(int max_segs, const int32_t* num_segs, const int32_t* seg_off, const int32_t* seg_cnt,
+                        int min_cnt, long long max_edges, int32_t* d_list, hipStream_t s, SpineInput* out) {
+  out->segs.clear();
+  std::vector<int32_t> large(1 + 2 * kSpineListCap);
+  int found = 0;
+  for (;; min_cnt *= 4) {   // too many for the list: only the larger ones
+    VSG_HIP(hipMemsetAsync(d_list, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_list_large_segments, dim3(Blocks(max_segs)), dim3(256), 0, s, max_segs, num_segs, seg_off,
+                       seg_cnt, min_cnt, d_list);
+    VSG_HIP(hipMemcpyAsync(large.data(), d_list, large.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    VSG_HIP(hipStreamSynchronize(s));
+    found = large[0];
+    if (found <= kSpineListCap) break;
+  }
+  if (getenv("VSG_SPINE_DEBUG") && max_segs > 1000000) {
+    long long sum = 0;
+    int mx = 0;
+    for (int i = 0; i < found; ++i) {
+      sum += large[2 + 2 * i];
+      mx = std::max(mx, large[2 + 2 * i]);
+    }
+    std::fprintf(stderr, "[vsg] spine select: max_segs %d min_cnt %d found %d sum %lld max %d (max_edges %lld)\n",
+                 max_segs, min_cnt, found, sum, mx, max_edges);
+  }
+  if (found == 0) return 0x7fffffff;
+  int thr = min_cnt;
+  for (;;) {   // every component above the threshold has to fit
+    long long sum = 0;
+    int cnt = 0;
+    for (int i = 0; i < found; ++i) {
+      if (large[2 + 2 * i] >= thr) {
+        sum += large[2 + 2 * i];
+        ++cnt;
+      }
+    }
+    if (cnt == 0) return 0x7fffffff;
+    if (sum <= max_edges && cnt <= 256) break;
+    thr *= 2;
+  }
+  for (int i = 0; i < found; ++i) {
+    if (large[2 + 2 * i] >= thr) out->segs.push_back(SpineSeg{large[1 + 2 * i], large[2 + 2 * i]});
+  }
+  return thr;
+}
+
+// Replays the listed large components (segments of the stage's component-sorted edge arrays).
+// Returns false when the scratch pool cannot hold them (the caller hands them to the ordinary
+// workers instead).  On return the side clusters and the spines are queued on the stream; a
+// failed speculation raises *wa.violation.
+bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch& S, hipStream_t s,
+                        const SpineWorkers& run_workers, size_t pool_used, int depth) {
+  const int K = (int)in.segs.size();
+  if (K == 0) return false;
+  std::vector<int32_t> base(K + 1, 0), off(K);
+  for (int k = 0; k < K; ++k) {
+    base[k + 1] = base[k] + in.segs[k].cnt;
+    off[k] = in.segs[k].off;
+  }
+  const int mE = base[K];
+  VSG_REQUIRE(mE < (1 << 27), -4, "spine: too many edges for the stamped ranks");
+  double tph[8] = {0};
+  auto Mark = [&](int i) {   // debug: phase boundaries (synchronises)
+    if (!S.spine_debug) return;
+    VSG_HIP(hipStreamSynchronize(s));
+    tph[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  };
+  Mark(0);
+  if (pool_used >= S.spine_pool_ints) return false;
+  Pool pool{S.spine_pool + pool_used, S.spine_pool_ints - pool_used};
+  int32_t* d_base = pool.take(K + 1);
+  int32_t* d_off = pool.take(K);
+  int32_t* root_vertex = pool.take(K);
+  int32_t* comp_spine = pool.take(K + 1);
+  unsigned long long* root_key = reinterpret_cast<unsigned long long*>(pool.take(2 * (size_t)K));
+  int32_t* scalars = pool.take(64);
+  int32_t* eu = pool.take(mE);
+  int32_t* ev = pool.take(mE);
+  int32_t* estate = pool.take(mE);
+  int32_t* flag = pool.take(mE);
+  int32_t* scan = pool.take(mE);
+  int32_t* side_key = pool.take(mE);
+  int32_t* spine_flag = pool.take(mE);
+  if (!pool.ok) return false;
+  int32_t* cc = S.cc;
+  uint32_t* best = reinterpret_cast<uint32_t*>(S.nmap[0]);
+  int32_t* firstq = S.nmap[1];
+  int32_t* childidx = S.nmap[2];
+
+  VSG_HIP(hipMemcpyAsync(d_base, base.data(), (K + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  VSG_HIP(hipMemcpyAsync(d_off, off.data(), K * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  VSG_HIP(hipMemsetAsync(root_key, 0, K * sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(k_spine_gather, dim3(Blocks(mE)), dim3(256), 0, s, mE, K, d_base, d_off, wa.s_ra,
+                     wa.s_rb, eu, ev, estate, cc, best);
+  hipLaunchKernelGGL(k_spine_pick_root, dim3(Blocks(mE)), dim3(256), 0, s, mE, K, eu, ev, d_base, wa.nodes,
+                     root_key);
+  hipLaunchKernelGGL(k_spine_roots, dim3((K + 63) / 64), dim3(64), 0, s, K, root_key, root_vertex, childidx);
+
+  // ---- tree edges ----------------------------------------------------------------------------------------
+  int32_t* d_alive = scalars;
+  int dbg_rounds = 0;
+  for (int round = 0;; ++round) {
+    dbg_rounds = round;
+    VSG_REQUIRE(round < 32, -4, "spine: the spanning forest did not converge");
+    VSG_HIP(hipMemsetAsync(d_alive, 0, sizeof(int32_t), s));
+    // ecu / ecv (the components of the round) live in the side_key / spine_flag arrays, which are
+    // only written once the forest is done
+    hipLaunchKernelGGL(k_bor_min, dim3(Blocks(mE)), dim3(256), 0, s, mE, round, eu, ev, estate, cc, best,
+                       side_key, spine_flag, d_alive);
+    int alive = 0;
+    VSG_HIP(hipMemcpyAsync(&alive, d_alive, sizeof(int), hipMemcpyDeviceToHost, s));
+    VSG_HIP(hipStreamSynchronize(s));
+    if (alive == 0) break;
+    hipLaunchKernelGGL(k_bor_mark, dim3(Blocks(mE)), dim3(256), 0, s, mE, round, estate, best, side_key,
+                       spine_flag);
+    hipLaunchKernelGGL(k_bor_union, dim3(Blocks(mE)), dim3(256), 0, s, mE, eu, ev, estate, cc);
+  }
+  Mark(1);
+  hipLaunchKernelGGL(k_flag_state, dim3(Blocks(mE)), dim3(256), 0, s, mE, estate, 1, flag);
+  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, flag, scan, mE, s);
+  hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, s, mE, flag, scan, scalars + 1);
+  int mt = 0;
+  VSG_HIP(hipMemcpyAsync(&mt, scalars + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+  VSG_HIP(hipStreamSynchronize(s));
+  VSG_REQUIRE(mt > 0, -4, "spine: a component without tree edges");
+  const int na = 2 * mt;
+  int32_t* te_e = pool.take(mt);
+  int32_t* child = pool.take(mt);
+  int32_t* par = pool.take(mt);
+  int32_t* jump[2] = {pool.take(mt), pool.take(mt)};
+  int32_t* val[2] = {pool.take(mt), pool.take(mt)};
+  int32_t* head[2] = {pool.take(mt), pool.take(mt)};
+  int32_t* sp_child = pool.take(mt);
+  int32_t* sp_is_a = pool.take(mt);
+  const size_t arcs_mark = pool.mark();
+
+  // ---- root the trees: Euler tour, list ranking -----------------------------------------------------------------
+  uint32_t* ak_in = reinterpret_cast<uint32_t*>(pool.take(na));
+  uint32_t* av_in = reinterpret_cast<uint32_t*>(pool.take(na));
+  uint32_t* ak = reinterpret_cast<uint32_t*>(pool.take(na));
+  uint32_t* av = reinterpret_cast<uint32_t*>(pool.take(na));
+  int32_t* pos_arc = pool.take(na);
+  int32_t* succ[2] = {pool.take(na), pool.take(na)};
+  int32_t* dist[2] = {pool.take(na), pool.take(na)};
+  if (!pool.ok) return false;
+  hipLaunchKernelGGL(k_compact_tree, dim3(Blocks(mE)), dim3(256), 0, s, mE, flag, scan, te_e);
+  hipLaunchKernelGGL(k_arc_keys, dim3(Blocks(na)), dim3(256), 0, s, mt, te_e, eu, ev, ak_in, av_in);
+  SortPairsU32(S.cub_temp, S.cub_temp_bytes, ak_in, ak, av_in, av, na, 32, s);
+  hipLaunchKernelGGL(k_arc_first, dim3(Blocks(na)), dim3(256), 0, s, na, ak, av, firstq, pos_arc);
+  hipLaunchKernelGGL(k_arc_succ, dim3(Blocks(na)), dim3(256), 0, s, na, ak, av, firstq, pos_arc, te_e, d_base, K,
+                     root_vertex, succ[0], dist[0]);
+  int cur = 0;
+  for (int span = 1; span < na; span *= 2) {
+    hipLaunchKernelGGL(k_rank_step, dim3(Blocks(na)), dim3(256), 0, s, na, succ[cur], dist[cur], succ[cur ^ 1],
+                       dist[cur ^ 1]);
+    cur ^= 1;
+  }
+  hipLaunchKernelGGL(k_tree_parent, dim3(Blocks(mt)), dim3(256), 0, s, mt, te_e, eu, ev, dist[cur], child, par,
+                     childidx);
+
+  Mark(2);
+  // ---- t(x), side clusters -------------------------------------------------------------------------------------
+  hipLaunchKernelGGL(k_jump_init, dim3(Blocks(mt)), dim3(256), 0, s, mt, te_e, par, childidx, jump[0], val[0]);
+  int cj = 0;
+  for (int span = 1; span < mt; span *= 2) {
+    hipLaunchKernelGGL(k_jump_max, dim3(Blocks(mt)), dim3(256), 0, s, mt, jump[cj], val[cj], jump[cj ^ 1],
+                       val[cj ^ 1]);
+    cj ^= 1;
+  }
+  hipLaunchKernelGGL(k_head_init, dim3(Blocks(mt)), dim3(256), 0, s, mt, te_e, val[cj], par, childidx, head[0]);
+  int ch = 0;
+  for (int span = 1; span < mt; span *= 2) {
+    hipLaunchKernelGGL(k_head_step, dim3(Blocks(mt)), dim3(256), 0, s, mt, head[ch], head[ch ^ 1]);
+    ch ^= 1;
+  }
+  hipLaunchKernelGGL(k_classify, dim3(Blocks(mE)), dim3(256), 0, s, mE, eu, ev, estate, childidx, head[ch],
+                     te_e, flag, side_key, spine_flag);
+
+  Mark(3);
+  // ---- side clusters: segments for the ordinary workers ------------------------------------------------------
+  pool.release(arcs_mark);   // the tour is done with
+  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, flag, scan, mE, s);
+  hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, s, mE, flag, scan, scalars + 2);
+  int n_side = 0;
+  VSG_HIP(hipMemcpyAsync(&n_side, scalars + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+  VSG_HIP(hipStreamSynchronize(s));
+  const size_t ns = (size_t)(n_side > 0 ? n_side : 1);
+  uint32_t* sk_in = reinterpret_cast<uint32_t*>(pool.take(ns));
+  uint32_t* si_in = reinterpret_cast<uint32_t*>(pool.take(ns));
+  uint32_t* sk = reinterpret_cast<uint32_t*>(pool.take(ns));
+  uint32_t* si = reinterpret_cast<uint32_t*>(pool.take(ns));
+  uint32_t* seg_key = reinterpret_cast<uint32_t*>(pool.take(ns));
+  int32_t* seg_cnt = pool.take(ns);
+  int32_t* seg_off = pool.take(ns);
+  int32_t* o_ra = pool.take(ns);
+  int32_t* o_rb = pool.take(ns);
+  uint32_t* o_gpos = reinterpret_cast<uint32_t*>(pool.take(ns));
+  if (!pool.ok) return false;
+  hipLaunchKernelGGL(k_compact_side, dim3(Blocks(mE)), dim3(256), 0, s, mE, flag, scan, side_key, sk_in, si_in);
+  // spine edges (the scan buffer is reused once the side positions are consumed)
+  hipLaunchKernelGGL(k_flag_state, dim3(Blocks(mE)), dim3(256), 0, s, mE, spine_flag, 1, flag);
+  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, flag, scan, mE, s);
+  hipLaunchKernelGGL(k_compact_spine, dim3(Blocks(mE)), dim3(256), 0, s, mE, K, flag, scan, eu, ev, childidx,
+                     te_e, d_base, sp_child, sp_is_a, comp_spine);
+  int dbg_spine_edges = 0;
+  if (S.spine_debug) {
+    std::vector<int32_t> cs(K + 1);
+    VSG_HIP(hipMemcpy(cs.data(), comp_spine, (K + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    dbg_spine_edges = cs[K];
+  }
+  Mark(4);
+  if (S.spine_check) SpineSelfCheck(base, mE, eu, ev, root_vertex, side_key, spine_flag, te_e, mt);
+  if (n_side > 0) {
+    SortPairsU32(S.cub_temp, S.cub_temp_bytes, sk_in, sk, si_in, si, n_side, 32, s);
+    int32_t* d_nseg = scalars + 3;
+    RunLengthEncodeU32(S.cub_temp, S.cub_temp_bytes, sk, seg_key, seg_cnt, d_nseg, n_side, s);
+    ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, seg_cnt, seg_off, n_side, s);
+    hipLaunchKernelGGL(k_gather_side, dim3(Blocks(n_side)), dim3(256), 0, s, n_side, si, d_base, d_off, K, wa.s_ra,
+                       wa.s_rb, wa.s_gpos, o_ra, o_rb, o_gpos);
+    WorkerArgs w2 = wa;
+    w2.num_segs = d_nseg;
+    w2.seg_off = seg_off;
+    w2.seg_cnt = seg_cnt;
+    w2.s_ra = o_ra;
+    w2.s_rb = o_rb;
+    w2.s_gpos = o_gpos;
+    w2.T.side = 1;
+    // A large side cluster is a component like any other: one level down.
+    SpineInput nested;
+    int32_t* d_list = pool.take(kSpineListInts);
+    w2.wave_max = 0x7fffffff;
+    if (pool.ok && depth < 8 && n_side >= S.spine_min) {
+      const long long room = (long long)((S.spine_pool_ints - pool_used - pool.used) / 16);
+      w2.wave_max = SelectLargeSegments(n_side, d_nseg, seg_off, seg_cnt, S.spine_min,
+                                        room < S.spine_max_edges ? room : S.spine_max_edges, d_list, s, &nested);
+    }
+    run_workers(w2, n_side);
+    if (!nested.segs.empty()) {
+      if (!RunSpineComponents(nested, w2, S, s, run_workers, pool_used + pool.used, depth + 1)) {
+        WorkerArgs w3 = w2;   // no room: the wave worker replays them
+        w3.wave_min = w2.wave_max - 1;
+        w3.wave_max = 0x7fffffff;
+        run_workers(w3, n_side);
+      }
+    }
+  }
+  Mark(5);
+  hipLaunchKernelGGL(k_spine, dim3(K), dim3(64 * (1 + kSpineReaders)), 0, s, K, comp_spine, root_vertex, sp_child, sp_is_a, wa.nodes,
+                     wa.T, wa.optimistic, wa.violation, wa.stats);
+  VSG_HIP(hipGetLastError());
+  Mark(6);
+  if (S.spine_debug) {
+    std::fprintf(stderr, "[vsg] spine[%d]: %d components, %d edges (largest %d), %d tree edges, %d side edges, %d spine edges, "
+                 "%d boruvka rounds | ms: forest %.2f rooting %.2f paths %.2f classify %.2f side %.2f spine %.2f\n",
+                 depth, K, mE, in.segs[0].cnt, mt, n_side, dbg_spine_edges, dbg_rounds, tph[1] - tph[0], tph[2] - tph[1],
+                 tph[3] - tph[2], tph[4] - tph[3], tph[5] - tph[4], tph[6] - tph[5]);
+  }
+  return true;
+}
+
+}  // namespace vsg

@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
         n_regular += (stat == 2);
         n_small += (stat == 3);
         if (out == kOutKeep) {
+          if (T.side) *violation = 1;
           kept_all[s_gpos[p]] = 1;
           StoreState(nodes, r1, s1);
           StoreState(nodes, r2, s2);
@@ -477,7 +478,18 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   // the prefix of an exclusive scan never depends on later elements).
   ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, S.seg_cnt, S.seg_off, n_work, s);
 
-  const bool optimistic = (inert_mode == 2) && (n_ti > 0 || rle);
+  // The large components are replayed along their Kruskal tree (merge_spine.hip): the choice is
+  // made on the host from the list of components above the threshold.
+  SpineInput spine_in;
+  int spine_thr = 0x7fffffff;
+  if (S.spine_min > 0 && inert_mode != 0 && !S.wave_v1 && n_work >= S.spine_min) {
+    spine_thr = SelectLargeSegments(n_work, S.num_segs, S.seg_off, S.seg_cnt, S.spine_min,
+                                    S.spine_max_edges, S.spine_pool, s, &spine_in);
+  }
+  const bool spine = !spine_in.segs.empty();
+  // A stage that settles edges tentatively, replays run leaders only or relies on the spine
+  // structure has to stay undoable.
+  const bool optimistic = ((inert_mode == 2) && (n_ti > 0 || rle)) || spine;
   if (optimistic) {
     hipLaunchKernelGGL(k_backup_roots, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, w_rb,
                        nodes, S.bk_ds, S.bk_cons, S.bk_flags);
@@ -492,6 +504,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   T.split_s = force ? P.s_lt_02 : P.s_le_015;
   T.min_size = P.min_region_size;
   T.rle = rle ? 1 : 0;
+  T.side = 0;
   // Replayed edges in component order; the scratch arrays of the earlier steps are free by now.
   int32_t* s_ra = reinterpret_cast<int32_t*>(S.a_comp);
   int32_t* s_rb = reinterpret_cast<int32_t*>(S.a_idx);
@@ -516,7 +529,10 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   wa.optimistic = optimistic ? 1 : 0;
   wa.violation = d_violation;
   wa.stats = S.stats;
+  wa.wave_min = kSmallSegment;
+  wa.wave_max = spine_thr;
   auto general_workers = [&](const WorkerArgs& w, int small_threads, int grid) {
+    if (w.wave_min == kSmallSegment)
     hipLaunchKernelGGL(k_merge_small, dim3(Blocks(small_threads)), dim3(256), 0, s, w.num_segs,
                        w.seg_off, w.seg_cnt, w.s_ra, w.s_rb, w.s_gpos, w.nodes, w.kept_all, w.T,
                        w.optimistic, w.violation, w.stats);
@@ -527,6 +543,18 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     }
   };
   general_workers(wa, n_work, wave_grid);
+  if (spine) {
+    const bool done = RunSpineComponents(spine_in, wa, S, s, [&](const WorkerArgs& w, int n) {
+      const int g = n / (kSmallSegment + 1) < 1 ? 1 : (n / (kSmallSegment + 1) > 8192 ? 8192 : n / (kSmallSegment + 1));
+      general_workers(w, n, g);
+    }, kSpineListInts, 0);
+    if (!done) {   // no room in the scratch pool: the wave worker replays them
+      WorkerArgs w3 = wa;
+      w3.wave_min = spine_thr - 1;
+      w3.wave_max = 0x7fffffff;
+      general_workers(w3, n_work, wave_grid);
+    }
+  }
   const int ew1 = NextEvent(S);
   if (ew1 >= 0) {
     VSG_HIP(hipEventRecord((*S.ev_pool)[ew1], s));

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
                                                     StageThr T, int optimistic,
                                                     int32_t* __restrict__ violation,
                                                     unsigned long long* __restrict__ stats,
-                                                    int dbg_flags) {
+                                                    int dbg_flags, int wave_min, int wave_max) {
   __shared__ WaveTable tab;
   auto Clock = []() -> unsigned long long { return kDbg ? __builtin_readcyclecounter() : 0ull; };
   __shared__ WaveQueue queue;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
   unsigned long long cyc_load = 0, cyc_loop = 0, cyc_wait = 0;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int cnt = seg_cnt[seg];
-    if (cnt <= kSmallSegment) continue;
+    if (cnt <= wave_min || cnt >= wave_max) continue;
     const int beg = seg_off[seg];
     const int end = beg + cnt;
     // Edges whose two ends already share a region are dropped when they are read (a large share
@@ -763,6 +763,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
       WaveSync();
 
       if (valid && my_kept) kept_all[gpos] = 1;
+      if (T.side && __ballot(my_kept) && lane == 0) *violation = 1;
       // ---- write the changed regions back, reset the table ---------------------------------------
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -833,11 +834,11 @@ void LaunchMergeWave(int grid, const WorkerArgs& a, bool instrumented, int dbg_f
   if (instrumented) {
     hipLaunchKernelGGL(k_merge_wave<true>, dim3(grid), dim3(128), 0, s, a.num_segs, a.seg_off,
                        a.seg_cnt, a.s_ra, a.s_rb, a.s_gpos, a.nodes, a.kept_all, a.T, a.optimistic,
-                       a.violation, a.stats, dbg_flags);
+                       a.violation, a.stats, dbg_flags, a.wave_min, a.wave_max);
   } else {
     hipLaunchKernelGGL(k_merge_wave<false>, dim3(grid), dim3(128), 0, s, a.num_segs, a.seg_off,
                        a.seg_cnt, a.s_ra, a.s_rb, a.s_gpos, a.nodes, a.kept_all, a.T, a.optimistic,
-                       a.violation, a.stats, 0);
+                       a.violation, a.stats, 0, a.wave_min, a.wave_max);
   }
   VSG_HIP(hipGetLastError());
 }
