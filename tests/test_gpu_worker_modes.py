@@ -38,11 +38,21 @@ def test_chain_self_check_is_silent(vsg, monkeypatch, capfd):
 @pytest.mark.parametrize("env", [{"VSG_RLE": "0"}, {"VSG_WINDOWS": "1"},
                                  {"VSG_WINDOWS": "5", "VSG_WINDOW_MIN": "1"},
                                  {"VSG_WINDOWS": "3", "VSG_WINDOW_MIN": "1", "VSG_RLE": "0"},
-                                 {"VSG_WINDOWS": "4", "VSG_WINDOW_MIN": "1", "VSG_FORCE_ROLLBACK": "1"}])
+                                 {"VSG_WINDOWS": "4", "VSG_WINDOW_MIN": "1", "VSG_FORCE_ROLLBACK": "1"},
+                                 {"VSG_GROUP_BUCKETS": "0"},
+                                 {"VSG_SPINE_MIN": "0"},
+                                 {"VSG_SPINE_MIN": "32", "VSG_SPINE_CHECK": "1"},
+                                 {"VSG_SPINE_MIN": "32", "VSG_SPINE_CHECK": "1", "VSG_WINDOWS": "1",
+                                  "VSG_GROUP_BUCKETS": "0"},
+                                 {"VSG_SPINE_MIN": "48", "VSG_FORCE_ROLLBACK": "1"},
+                                 {"VSG_SPINE_MIN": "32", "VSG_SPINE_MAX_EDGES": "4096"}])
 def test_stage_decomposition_variants(vsg, monkeypatch, env):
     """The stage driver's two decompositions are exact whatever their parameters: a bucket split
-    into consecutive rank windows (each its own filter -> components -> replay), and runs of equal
-    root pairs replayed through their leader only (with the rollback of a constrained split)."""
+    into consecutive rank windows (each its own filter -> components -> replay), runs of equal
+    root pairs replayed through their leader only (with the rollback of a constrained split), the
+    buckets above the force-merge weight replayed as one edge sequence, and the large components
+    replayed along their Kruskal tree (from which size, with its structure checked against a
+    sequential replay on the host, with a scratch pool that is too small, with forced rollbacks)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for (W, H, N, kind, chunk) in CASES + [(256, 144, 44, "bench", 20)]:

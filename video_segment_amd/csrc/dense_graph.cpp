@@ -295,13 +295,38 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   LaunchInitIdentity(cc_.get(), N, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
 
-  int n_max = 0;
+  // Consecutive buckets above the force-merge weight share their thresholds, and a stage is exact
+  // for any consecutive range of the edge sequence (RunBucketStage): the long tail of nearly empty
+  // buckets is replayed in groups, hundreds of stages of a few edges each would cost more in
+  // launches than in work.  A group must stay small, though: its filter sees the regions as they
+  // are when the group starts, so what the group's own earlier buckets settle (regions finalized
+  // by a failed test make their later edges inert) is only known to the workers.  The width
+  // follows the number of edges the last group had to replay.
+  const bool group_buckets = !getenv("VSG_GROUP_BUCKETS") || atoi(getenv("VSG_GROUP_BUCKETS")) != 0;
+  std::vector<int32_t> bucket_prefix(kNumBuckets + 2, 0);
+  int first_plain = kNumBuckets;
+  {
+    const float scale = 2048.0f / (1.0f + 1e-6f);
+    const float inv_scale = (float)(1.0 / (double)scale);
+    const float force_w = l1_ ? 0.002f : 0.001f;
+    for (int b = 0; b < kNumBuckets; ++b) {
+      if (!((float)b * inv_scale < force_w)) {
+        first_plain = b;
+        break;
+      }
+    }
+  }
+  int64_t n_max = 0;
   for (int b = 0; b <= kNumBuckets; ++b) {
     const int tot = bucket_base_host_[(size_t)b * (L + 1) + L];
     edges_total += tot;
-    if (b < kNumBuckets) n_max = std::max(n_max, tot);
+    bucket_prefix[b + 1] = bucket_prefix[b] + tot;
   }
-  EnsureScratch((size_t)std::max(n_max, 1));
+  for (int b = 0; b < kNumBuckets; ++b) n_max = std::max<int64_t>(n_max, bucket_prefix[b + 1] - bucket_prefix[b]);
+  VSG_REQUIRE(bucket_prefix[kNumBuckets] >= 0, -1, "too many edges");
+  EnsureScratch((size_t)std::max<int64_t>(n_max, 1));
+  bucket_prefix_dev_.ensure(bucket_prefix.size());
+  H2D(bucket_prefix_dev_.get(), bucket_prefix.data(), bucket_prefix.size(), stream_);
 
   MergeScratch S = {};
   S.e_ra = e_ra_.get();
@@ -394,6 +419,8 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   const int num_windows = getenv("VSG_WINDOWS") ? std::max(1, atoi(getenv("VSG_WINDOWS"))) : 6;
   const int window_bushy = getenv("VSG_WINDOW_BUSHY") ? atoi(getenv("VSG_WINDOW_BUSHY")) : 64;
   const int window_min_edges = getenv("VSG_WINDOW_MIN") ? atoi(getenv("VSG_WINDOW_MIN")) : (4 << 20);
+  const int window_min_replayed =
+      getenv("VSG_WINDOW_MIN_REPLAYED") ? atoi(getenv("VSG_WINDOW_MIN_REPLAYED")) : (getenv("VSG_WINDOW_MIN") ? 0 : (1 << 20));
   // A bucket is replayed as consecutive *rank windows* (each a full stage: filter -> components ->
   // workers; exact for any split, see RunBucketStage).  While the regions of a bucket are still
   // many small clusters growing side by side, the edges of one window fall into many small
@@ -401,23 +428,46 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   // chain them into a few huge components replayed by one wavefront each.  Once one region
   // dominates (its component is a chain whatever the split) windows only add overhead.  The first
   // window tells which case it is: average component size below `bushy` -> keep splitting.
-  for (int b = 0; b < kNumBuckets; ++b) {
-    const int n_b = bucket_base_host_[(size_t)b * (L + 1) + L];
+  S.bucket_prefix = bucket_prefix_dev_.get();
+  S.bucket_prefix_host = bucket_prefix.data();
+  int group_width = 1;
+  for (int b = 0, hi = 0; b < kNumBuckets; b = hi) {
+    hi = b + 1;
+    if (group_buckets && b >= first_plain) {   // as many buckets as fit the scratch arrays
+      while (hi < kNumBuckets && hi - b < group_width &&
+             (int64_t)bucket_prefix[hi + 1] - bucket_prefix[b] <= n_max) {
+        ++hi;
+      }
+    }
+    S.group_hi = hi;
+    const int n_b = bucket_prefix[hi] - bucket_prefix[b];
     if (n_b == 0) continue;
+    int64_t group_active = 0;
     int windows = n_b >= window_min_edges ? num_windows : 1;
     for (int w = 0; w < windows; ++w) {
       const int j0 = (int)((int64_t)n_b * w / windows);
       int j1 = (int)((int64_t)n_b * (w + 1) / windows);
       const bool probe = windows > 1 && w == 0 && window_bushy > 0;
       StageInfo info;
-      RunStageDebug(b, w, windows, j0, j1 - j0, P, inert_mode, S, debug_stages,
-                    (probe || debug_stages) ? &info : nullptr);
-      if (probe && (int64_t)info.replayed >= (int64_t)window_bushy * std::max(info.components, 1)) {
+      info.want_components = probe || debug_stages;
+      RunStageDebug(b, w, windows, j0, j1 - j0, P, inert_mode, S, debug_stages, &info);
+      group_active += info.replayed;
+      // (and a window that replays few edges is all overhead)
+      if (probe && ((int64_t)info.replayed >= (int64_t)window_bushy * std::max(info.components, 1) ||
+                    info.replayed < window_min_replayed)) {
         // few, large components already: the rest of the bucket in one stage
         StageInfo rest;
-        RunStageDebug(b, -1, windows, j1, n_b - j1, P, inert_mode, S, debug_stages,
-                      debug_stages ? &rest : nullptr);
+        rest.want_components = debug_stages;
+        RunStageDebug(b, -1, windows, j1, n_b - j1, P, inert_mode, S, debug_stages, &rest);
+        group_active += rest.replayed;
         break;
+      }
+    }
+    if (b >= first_plain) {
+      if (group_active < 2048) {
+        group_width = std::min(group_width * 2, 256);
+      } else if (group_active > 16384) {
+        group_width = std::max(group_width / 4, 1);
       }
     }
   }

@@ -146,6 +146,7 @@ class DenseGraphHip {
   DevBuf<int32_t> bk_cons_;
   int64_t optimistic_stages_ = 0, rollbacks_ = 0;
   DevBuf<int32_t> scalars_;   // num_active, num_segs, misc
+  DevBuf<int32_t> bucket_prefix_dev_;   // edges in the buckets before b
   DevBuf<int32_t> spine_pool_;   // scratch of the Kruskal-tree replay (merge_spine.hip)
   DevBuf<unsigned long long> stats_;
   DevBuf<uint8_t> cub_temp_;

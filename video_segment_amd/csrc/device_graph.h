@@ -135,6 +135,11 @@ struct MergeScratch {
   int32_t* l_rb;
   uint32_t* l_gpos;
   int use_rle;           // replay one edge per run of equal root pairs (default on)
+  // A stage may cover several consecutive buckets with the same thresholds: [bucket, group_hi)
+  // (group_hi <= bucket: one bucket); bucket_prefix[b] = edges in the buckets before b (device).
+  int group_hi;
+  const int32_t* bucket_prefix;
+  const int32_t* bucket_prefix_host;   // the same table on the host
   // Kruskal-tree replay of the large components (merge_spine.hip)
   int spine_min;         // components of at least this many replayed edges; 0: never
   int spine_max_edges;   // at most this many edges per stage (scratch pool)
@@ -168,6 +173,7 @@ void LaunchInitIdentity(int32_t* a, size_t n, hipStream_t s);
 // bucket's edge sequence (list order, then position).  Any split of a bucket into consecutive
 // windows run one after the other is equivalent to one stage over the whole bucket.
 struct StageInfo {
+  bool want_components = false;   // in: also report `components` (one more synchronisation)
   int replayed = 0;     // edges handed to the workers (run leaders)
   int components = 0;   // independent components they fell into
 };

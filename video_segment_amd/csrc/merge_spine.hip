@@ -86,48 +86,81 @@ __global__ __launch_bounds__(256) void k_spine_gather(int mE, int K, const int32
 // earlier round left behind, so the table never has to be cleared.
 __device__ __forceinline__ uint32_t BorKey(int round, int e) { return ((uint32_t)(31 - round) << 27) | (uint32_t)e; }
 
-__global__ __launch_bounds__(256) void k_bor_min(int mE, int round, const int32_t* __restrict__ eu,
+// The kernels of a round run over all edges (list == null) or over the list of the edges that were
+// still alive a round or two ago.
+__global__ __launch_bounds__(256) void k_bor_min(int n, const int32_t* __restrict__ list, int round,
+                                                  const int32_t* __restrict__ eu,
                                                   const int32_t* __restrict__ ev, int32_t* __restrict__ estate,
                                                   int32_t* __restrict__ cc, uint32_t* __restrict__ best,
                                                   int32_t* __restrict__ ecu, int32_t* __restrict__ ecv,
                                                   int32_t* __restrict__ alive) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int e = i < n ? (list ? list[i] : i) : -1;
   bool live = false;
-  if (e < mE && estate[e] == 0) {
-    const int cu = CcFind(cc, eu[e]), cv = CcFind(cc, ev[e]);
+  int cu = -1, cv = -1;
+  if (e >= 0 && estate[e] == 0) {
+    cu = CcFind(cc, eu[e]);
+    cv = CcFind(cc, ev[e]);
     if (cu == cv) {
       estate[e] = 2;
+      cu = cv = -1;
     } else {
       live = true;
       ecu[e] = cu;
       ecv[e] = cv;
-      const uint32_t key = BorKey(round, e);
-      // ranks only ever decrease: the read keeps all but the first few edges of a huge component
-      // away from the atomic
-      if (key < __hip_atomic_load(&best[cu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&best[cu], key);
-      if (key < __hip_atomic_load(&best[cv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&best[cv], key);
     }
+  }
+  // The hub of a chain-like component is an end of most of its edges.  Ranks grow with the lane,
+  // so a lane whose component already appears in the lane before it has nothing to add; and a
+  // plain (cached, possibly stale: only ever too large) read keeps all but the first few of the
+  // others away from the atomic.
+  const int pu = __shfl_up(cu, 1), pv = __shfl_up(cv, 1);
+  if (live) {
+    const uint32_t key = BorKey(round, e);
+    const bool has_prev = (threadIdx.x & 63) != 0;
+    if (!(has_prev && (cu == pu || cu == pv)) && key < best[cu]) atomicMin(&best[cu], key);
+    if (!(has_prev && (cv == pu || cv == pv)) && key < best[cv]) atomicMin(&best[cv], key);
   }
   const unsigned long long m = __ballot(live);
   if (m && (threadIdx.x & 63) == 0) atomicAdd(alive, (int)__popcll(m));
 }
 
-__global__ __launch_bounds__(256) void k_bor_mark(int mE, int round, int32_t* __restrict__ estate,
+__global__ __launch_bounds__(256) void k_bor_mark(int n, const int32_t* __restrict__ list, int round,
+                                                   int32_t* __restrict__ estate,
                                                    const uint32_t* __restrict__ best,
                                                    const int32_t* __restrict__ ecu, const int32_t* __restrict__ ecv) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= mE || estate[e] != 0) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int e = list ? list[i] : i;
+  if (estate[e] != 0) return;
   const uint32_t key = BorKey(round, e);
   if (best[ecu[e]] == key || best[ecv[e]] == key) estate[e] = 3;
 }
 
-__global__ __launch_bounds__(256) void k_bor_union(int mE, const int32_t* __restrict__ eu,
+__global__ __launch_bounds__(256) void k_bor_union(int n, const int32_t* __restrict__ list,
+                                                    const int32_t* __restrict__ eu,
                                                     const int32_t* __restrict__ ev, int32_t* __restrict__ estate,
                                                     int32_t* __restrict__ cc) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= mE || estate[e] != 3) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int e = list ? list[i] : i;
+  if (estate[e] != 3) return;
   CcUnion(cc, eu[e], ev[e]);
   estate[e] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_bor_alive_flags(int n, const int32_t* __restrict__ list,
+                                                          const int32_t* __restrict__ estate,
+                                                          int32_t* __restrict__ flag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flag[i] = estate[list ? list[i] : i] == 0 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_bor_compact(int n, const int32_t* __restrict__ list,
+                                                      const int32_t* __restrict__ flag,
+                                                      const int32_t* __restrict__ scan, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n && flag[i]) out[scan[i]] = list ? list[i] : i;
 }
 
 // ---- R: the largest region of every component --------------------------------------------------------
@@ -872,21 +905,50 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   // ---- tree edges ----------------------------------------------------------------------------------------
   int32_t* d_alive = scalars;
   int dbg_rounds = 0;
-  for (int round = 0;; ++round) {
-    dbg_rounds = round;
-    VSG_REQUIRE(round < 32, -4, "spine: the spanning forest did not converge");
-    VSG_HIP(hipMemsetAsync(d_alive, 0, sizeof(int32_t), s));
-    // ecu / ecv (the components of the round) live in the side_key / spine_flag arrays, which are
-    // only written once the forest is done
-    hipLaunchKernelGGL(k_bor_min, dim3(Blocks(mE)), dim3(256), 0, s, mE, round, eu, ev, estate, cc, best,
-                       side_key, spine_flag, d_alive);
-    int alive = 0;
-    VSG_HIP(hipMemcpyAsync(&alive, d_alive, sizeof(int), hipMemcpyDeviceToHost, s));
-    VSG_HIP(hipStreamSynchronize(s));
-    if (alive == 0) break;
-    hipLaunchKernelGGL(k_bor_mark, dim3(Blocks(mE)), dim3(256), 0, s, mE, round, estate, best, side_key,
-                       spine_flag);
-    hipLaunchKernelGGL(k_bor_union, dim3(Blocks(mE)), dim3(256), 0, s, mE, eu, ev, estate, cc);
+  {
+    const size_t forest_mark = pool.mark();
+    const int32_t* list = nullptr;   // the edges the rounds still look at (null: all)
+    int n_list = mE;
+    int32_t* lists[2] = {nullptr, nullptr};
+    int which = 0;
+    for (int round = 0;; ++round) {
+      dbg_rounds = round;
+      VSG_REQUIRE(round < 32, -4, "spine: the spanning forest did not converge");
+      VSG_HIP(hipMemsetAsync(d_alive, 0, sizeof(int32_t), s));
+      // ecu / ecv (the components of the round) live in the side_key / spine_flag arrays, which are
+      // only written once the forest is done
+      hipLaunchKernelGGL(k_bor_min, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, round, eu, ev, estate, cc,
+                         best, side_key, spine_flag, d_alive);
+      int alive = 0;
+      VSG_HIP(hipMemcpyAsync(&alive, d_alive, sizeof(int), hipMemcpyDeviceToHost, s));
+      VSG_HIP(hipStreamSynchronize(s));
+      if (alive == 0) break;
+      if (alive < n_list / 2 && n_list > (1 << 16)) {   // drop the settled edges from the rounds to come
+        if (!lists[0]) {
+          const size_t m = pool.mark();
+          lists[0] = pool.take(alive);
+          lists[1] = pool.take(alive);
+          if (!pool.ok) {   // without room the rounds simply keep the longer list
+            pool.ok = true;
+            pool.release(m);
+            lists[0] = lists[1] = nullptr;
+          }
+        }
+        if (lists[0]) {
+          hipLaunchKernelGGL(k_bor_alive_flags, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, estate, flag);
+          ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, flag, scan, n_list, s);
+          hipLaunchKernelGGL(k_bor_compact, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, flag, scan,
+                             lists[which]);
+          list = lists[which];
+          which ^= 1;
+          n_list = alive;
+        }
+      }
+      hipLaunchKernelGGL(k_bor_mark, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, round, estate, best,
+                         side_key, spine_flag);
+      hipLaunchKernelGGL(k_bor_union, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, eu, ev, estate, cc);
+    }
+    pool.release(forest_mark);
   }
   Mark(1);
   hipLaunchKernelGGL(k_flag_state, dim3(Blocks(mE)), dim3(256), 0, s, mE, estate, 1, flag);
@@ -1002,9 +1064,10 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
     SpineInput nested;
     int32_t* d_list = pool.take(kSpineListInts);
     w2.wave_max = 0x7fffffff;
-    if (pool.ok && depth < 8 && n_side >= S.spine_min) {
+    if (pool.ok && depth < 8 && n_side >= S.spine_min * 4) {
       const long long room = (long long)((S.spine_pool_ints - pool_used - pool.used) / 16);
-      w2.wave_max = SelectLargeSegments(n_side, d_nseg, seg_off, seg_cnt, S.spine_min,
+      // (a level costs about a millisecond of launches: only for what the wave worker needs longer for)
+      w2.wave_max = SelectLargeSegments(n_side, d_nseg, seg_off, seg_cnt, S.spine_min * 4,
                                         room < S.spine_max_edges ? room : S.spine_max_edges, d_list, s, &nested);
     }
     run_workers(w2, n_side);

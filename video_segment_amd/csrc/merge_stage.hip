@@ -22,6 +22,8 @@
 // what matters is coalesced streaming in the filter and keeping the serial chains in registers.
 // The workers of the large components live in merge_wave.hip (default)
 // and merge_wave_v1.hip (edge-by-edge reference); shared device helpers in merge_common.h.
+#include <algorithm>
+
 #include "merge_common.h"
 
 namespace vsg {
@@ -71,9 +73,12 @@ void LaunchInitIdentity(int32_t* a, size_t n, hipStream_t s) {
 //   (kFlagTentative in the region flags, which travel with the state into the workers); a worker
 //   that changes the constraint of a marked region raises the stage's violation flag and the host
 //   rolls the stage back and replays it with inert_mode 0 (see RunBucketStage).
-__global__ __launch_bounds__(256) void k_filter(int bucket, int j0, int n_b,
+// The stage covers the edges [j0, j0 + n_b) of the buckets [bucket, bucket_hi) (one after the
+// other; bucket_prefix[b] = edges in the buckets before b).
+__global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j0, int n_b,
                                                  const ListDesc* __restrict__ lists,
-                                                 const int32_t* __restrict__ base_row,
+                                                 const int32_t* __restrict__ bucket_base,
+                                                 const int32_t* __restrict__ bucket_prefix,
                                                  const uint32_t* __restrict__ list_slot_base,
                                                  uint8_t* __restrict__ kept_all, NodeArrays nodes,
                                                  MergeParams P, int inert_mode,
@@ -87,10 +92,22 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int j0, int n_b,
   const int j = blockIdx.x * 256 + threadIdx.x;   // index inside the stage's window
   int ti = 0;
   if (j < n_b) {
-    const int jb = j0 + j;                         // index inside the bucket
+    int bk = bucket;
+    int jb = j0 + j;                               // index inside the bucket
+    if (bucket_hi > bucket + 1) {                  // several buckets: the last b with prefix[b] <= position
+      const int jg = bucket_prefix[bucket] + jb;
+      int lo = bucket, hi = bucket_hi;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bucket_prefix[mid] <= jg) lo = mid; else hi = mid;
+      }
+      bk = lo;
+      jb = jg - bucket_prefix[bk];
+    }
+    const int32_t* base_row = bucket_base + (size_t)bk * (P.num_lists + 1);
     const int l = LocateList(base_row, P.num_lists, jb);
     const ListDesc L = lists[l];
-    const int pos = L.offsets[bucket] + (jb - base_row[l]);
+    const int pos = L.offsets[bk] + (jb - base_row[l]);
     int a, b;
     DecodeEdge(L, L.slots[pos], P.W, a, b);
     const int ra = FindCompress(nodes.parent, a);
@@ -410,17 +427,20 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
                     const uint32_t* list_slot_base, uint8_t* kept_all, NodeArrays nodes,
                     const MergeParams& P, int inert_mode, MergeScratch& S, hipStream_t s,
                     StageInfo* info) {
-  if (info) *info = StageInfo();
+  if (info) {
+    info->replayed = 0;
+    info->components = 0;
+  }
   if (n_b <= 0) return;
-  const int32_t* base_row = bucket_base + (size_t)bucket * (P.num_lists + 1);
+  const int bucket_hi = S.group_hi > bucket ? S.group_hi : bucket + 1;
   int32_t* d_num_ti = S.num_active + 2;
   int32_t* d_violation = S.num_active + 3;
   int32_t* d_num_leaders = S.num_active + 5;
   VSG_HIP(hipMemsetAsync(d_num_ti, 0, 2 * sizeof(int32_t), s));
   const int ef0 = NextEvent(S);
   if (ef0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ef0], s));
-  hipLaunchKernelGGL(k_filter, dim3(Blocks(n_b)), dim3(256), 0, s, bucket, j0, n_b, lists, base_row,
-                     list_slot_base, kept_all, nodes, P, inert_mode, S.cc, S.e_ra, S.e_rb, S.e_gpos,
+  hipLaunchKernelGGL(k_filter, dim3(Blocks(n_b)), dim3(256), 0, s, bucket, bucket_hi, j0, n_b, lists,
+                     bucket_base, S.bucket_prefix, list_slot_base, kept_all, nodes, P, inert_mode, S.cc, S.e_ra, S.e_rb, S.e_gpos,
                      S.e_active, S.e_ti, d_num_ti);
   const int ef1 = NextEvent(S);
   if (ef1 >= 0) {
@@ -577,15 +597,37 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_gpos, kept_all);
       clear_marks();
       VSG_HIP(hipGetLastError());
+      if (bucket_hi > bucket + 1) {
+        // A group of buckets: bucket by bucket (each optimistic again) -- the conservative replay
+        // of everything the group holds would chain it into one huge component.
+        const int group_hi = S.group_hi;
+        const int64_t g0 = (int64_t)S.bucket_prefix_host[bucket] + j0, g1 = g0 + n_b;
+        int replayed = 0;
+        for (int bb = bucket; bb < bucket_hi; ++bb) {
+          const int64_t lo = std::max<int64_t>(g0, S.bucket_prefix_host[bb]);
+          const int64_t hi = std::min<int64_t>(g1, S.bucket_prefix_host[bb + 1]);
+          if (hi <= lo) continue;
+          S.group_hi = 0;
+          StageInfo sub;
+          RunBucketStage(bb, (int)(lo - S.bucket_prefix_host[bb]), (int)(hi - lo), lists, bucket_base,
+                         list_slot_base, kept_all, nodes, P, inert_mode, S, s, info ? &sub : nullptr);
+          replayed += sub.replayed;
+        }
+        S.group_hi = group_hi;
+        if (info) info->replayed = replayed;
+        return;
+      }
       RunBucketStage(bucket, j0, n_b, lists, bucket_base, list_slot_base, kept_all, nodes, P, 0, S,
                      s, info);
       return;
     }
   }
-  if (info) {   // how the stage decomposed (the caller sizes the next windows with it)
+  if (info) {   // how the stage decomposed (the caller sizes the next windows / groups with it)
     info->replayed = n_work;
-    VSG_HIP(hipMemcpyAsync(&info->components, S.num_segs, sizeof(int), hipMemcpyDeviceToHost, s));
-    VSG_HIP(hipStreamSynchronize(s));
+    if (info->want_components) {
+      VSG_HIP(hipMemcpyAsync(&info->components, S.num_segs, sizeof(int), hipMemcpyDeviceToHost, s));
+      VSG_HIP(hipStreamSynchronize(s));
+    }
   }
   if (rle && n_work < n_active) {
     hipLaunchKernelGGL(k_resolve_followers, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, lead,
