@@ -61,6 +61,9 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   hist_sums_.alloc(EdgeSortSumInts(wh_) + 1);
   scalars_.alloc(16);
   stats_.alloc(64);
+  VSG_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
+  VSG_HIP(hipEventCreateWithFlags(&aux_fork_, hipEventDisableTiming));
+  VSG_HIP(hipEventCreateWithFlags(&aux_join_, hipEventDisableTiming));
 
   size_t temp = ScanTempBytes((int)N);
   cub_temp_.alloc(temp);
@@ -69,6 +72,9 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
 
 DenseGraphHip::~DenseGraphHip() {
   for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
+  if (aux_fork_) (void)hipEventDestroy(aux_fork_);
+  if (aux_join_) (void)hipEventDestroy(aux_join_);
+  if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
 }
 
 void DenseGraphHip::Reset(int max_frames) {
@@ -365,6 +371,9 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.nmap[0] = label_uf_.get();
   S.nmap[1] = label_img_.get();
   S.nmap[2] = adjust_.get();
+  S.aux_stream = aux_stream_;
+  S.aux_fork = aux_fork_;
+  S.aux_join = aux_join_;
   S.lead_pos = lead_pos_.get();
   S.l_ra = l_ra_.get();
   S.l_rb = l_rb_.get();

@@ -103,6 +103,8 @@ class DenseGraphHip {
   int W_, H_, capacity_frames_, max_frames_;
   bool l1_;
   hipStream_t stream_;
+  hipStream_t aux_stream_ = nullptr;   // second stream of the merge stages (see RunBucketStage)
+  hipEvent_t aux_fork_ = nullptr, aux_join_ = nullptr;
   int num_frames_ = 0;
   size_t wh_;
   bool has_constraints_ = false;

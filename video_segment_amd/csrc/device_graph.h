@@ -147,6 +147,8 @@ struct MergeScratch {
   int32_t* spine_pool;   // scratch, SpinePoolInts(spine_max_edges) ints
   size_t spine_pool_ints;
   int32_t* nmap[3];      // three more [N] scratch maps (free during the bucket stages)
+  hipStream_t aux_stream;   // the ordinary workers run here while the trees are built on the main stream
+  hipEvent_t aux_fork, aux_join;
   int wave_v1;           // debug hook: use the sequential wave worker (k_merge_wave_v1)
   int wave_debug;        // use the instrumented build of the wave worker (counters, self checks)
   int wave_dbg;          // debug hook (bit mask): 1 no chain, 4 no hot region, 8 one generic lane per round,

@@ -905,6 +905,14 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   // ---- tree edges ----------------------------------------------------------------------------------------
   int32_t* d_alive = scalars;
   int dbg_rounds = 0;
+  auto NowMs = [] {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  };
+  const bool dbg_big = S.spine_debug && mE > (8 << 20);
+  if (dbg_big) {
+    VSG_HIP(hipStreamSynchronize(s));
+    std::fprintf(stderr, "[vsg]   forest: gather+root %.2f ms\n", NowMs() - tph[0]);
+  }
   {
     const size_t forest_mark = pool.mark();
     const int32_t* list = nullptr;   // the edges the rounds still look at (null: all)
@@ -919,9 +927,11 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
       // only written once the forest is done
       hipLaunchKernelGGL(k_bor_min, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, round, eu, ev, estate, cc,
                          best, side_key, spine_flag, d_alive);
+      const double tr0 = dbg_big ? NowMs() : 0;
       int alive = 0;
       VSG_HIP(hipMemcpyAsync(&alive, d_alive, sizeof(int), hipMemcpyDeviceToHost, s));
       VSG_HIP(hipStreamSynchronize(s));
+      if (dbg_big) std::fprintf(stderr, "[vsg]   forest round %d: %d in list, %d alive, min %.2f ms\n", round, n_list, alive, NowMs() - tr0);
       if (alive == 0) break;
       if (alive < n_list / 2 && n_list > (1 << 16)) {   // drop the settled edges from the rounds to come
         if (!lists[0]) {
@@ -947,6 +957,11 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
       hipLaunchKernelGGL(k_bor_mark, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, round, estate, best,
                          side_key, spine_flag);
       hipLaunchKernelGGL(k_bor_union, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, eu, ev, estate, cc);
+      if (dbg_big) {
+        const double tr1 = NowMs();
+        VSG_HIP(hipStreamSynchronize(s));
+        std::fprintf(stderr, "[vsg]   forest round %d: compaction+mark+union %.2f ms\n", round, NowMs() - tr1);
+      }
     }
     pool.release(forest_mark);
   }

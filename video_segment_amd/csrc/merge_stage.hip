@@ -551,7 +551,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   wa.stats = S.stats;
   wa.wave_min = kSmallSegment;
   wa.wave_max = spine_thr;
-  auto general_workers = [&](const WorkerArgs& w, int small_threads, int grid) {
+  auto general_workers = [&](const WorkerArgs& w, int small_threads, int grid, hipStream_t s) {
     if (w.wave_min == kSmallSegment)
     hipLaunchKernelGGL(k_merge_small, dim3(Blocks(small_threads)), dim3(256), 0, s, w.num_segs,
                        w.seg_off, w.seg_cnt, w.s_ra, w.s_rb, w.s_gpos, w.nodes, w.kept_all, w.T,
@@ -562,18 +562,26 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       LaunchMergeWave(grid, w, S.wave_debug != 0, S.wave_dbg, s);
     }
   };
-  general_workers(wa, n_work, wave_grid);
-  if (spine) {
+  if (!spine) {
+    general_workers(wa, n_work, wave_grid, s);
+  } else {
+    // The ordinary components on the second stream, beside the tree replay of the large ones
+    // (disjoint regions; the statistics and the violation flag are atomics / idempotent stores).
+    VSG_HIP(hipEventRecord(S.aux_fork, s));
+    VSG_HIP(hipStreamWaitEvent(S.aux_stream, S.aux_fork, 0));
+    general_workers(wa, n_work, wave_grid, S.aux_stream);
+    VSG_HIP(hipEventRecord(S.aux_join, S.aux_stream));
     const bool done = RunSpineComponents(spine_in, wa, S, s, [&](const WorkerArgs& w, int n) {
       const int g = n / (kSmallSegment + 1) < 1 ? 1 : (n / (kSmallSegment + 1) > 8192 ? 8192 : n / (kSmallSegment + 1));
-      general_workers(w, n, g);
+      general_workers(w, n, g, s);
     }, kSpineListInts, 0);
     if (!done) {   // no room in the scratch pool: the wave worker replays them
       WorkerArgs w3 = wa;
       w3.wave_min = spine_thr - 1;
       w3.wave_max = 0x7fffffff;
-      general_workers(w3, n_work, wave_grid);
+      general_workers(w3, n_work, wave_grid, s);
     }
+    VSG_HIP(hipStreamWaitEvent(s, S.aux_join, 0));
   }
   const int ew1 = NextEvent(S);
   if (ew1 >= 0) {
