@@ -37,10 +37,14 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_PX_FRAME = 111.0      # spatial + temporal + flow
-# Algorithmic bytes of the dominant kernel (k_merge_wave) per replayed edge, see DESIGN.md:
-# edge record (sorted index 4 + two root hints 8 + kept position 4) + two parent words 8
-# + two 21-byte region states (desc_sz 16, cons 4, flags 1).
+# Algorithmic bytes of the two candidates for the dominant kernel (the one with the larger
+# summed launch time in the timed region is reported):
+# k_merge_wave, per replayed edge: edge record (sorted index 4 + two root hints 8 + kept position
+#   4) + two parent words 8 + two 21-byte region states (desc_sz 16, cons 4, flags 1);
+# k_spine, per side cluster absorbed: child vertex 4 + orientation 4 + one parent word read 4 +
+#   one 21-byte region state + the parent word written 4.
 WAVE_BYTES_PER_EDGE = 4 + 8 + 4 + 8 + 2 * 21
+SPINE_BYTES_PER_EDGE = 4 + 4 + 4 + 21 + 4
 
 
 def parse():
@@ -180,7 +184,8 @@ def main():
             if world > 1:
                 dist.barrier()
 
-        keys = ["wave_ms", "wave_launches", "wave_edges", "merge_ms", "pre_ms", "edges_ms",
+        keys = ["wave_ms", "wave_launches", "wave_edges", "spine_ms", "spine_launches", "spine_edges",
+                "merge_ms", "pre_ms", "edges_ms",
                 "readout_ms", "host_ms", "filter_ms", "filter_launches", "edges_total", "merges"]
         accs = [dict((k_, 0) for k_ in keys) for _ in range(S)]
         outs = [0] * S
@@ -214,6 +219,9 @@ def main():
                         a["wave_ms"] += t.wave_kernel_ms
                         a["wave_launches"] += t.wave_kernel_launches
                         a["wave_edges"] += t.wave_kernel_edges
+                        a["spine_ms"] += t.spine_kernel_ms
+                        a["spine_launches"] += t.spine_kernel_launches
+                        a["spine_edges"] += t.spine_kernel_edges
                         a["filter_ms"] += t.filter_kernel_ms
                         a["filter_launches"] += t.filter_kernel_launches
                         a["merge_ms"] += t.merge_ms
@@ -283,14 +291,23 @@ def main():
         dt, frames_total, acc = result["dt"], result["frames"], result["acc"]
         fps = frames_total / dt
         px = W * H
-        wave_launches = max(acc["wave_launches"], 1)
-        wave_avg_s = acc["wave_ms"] / 1e3 / wave_launches
-        wave_bytes_per_launch = WAVE_BYTES_PER_EDGE * acc["wave_edges"] / wave_launches
+        # the dominant kernel of the timed region (HIP events around every launch, on the stream
+        # the kernel is launched on)
+        if acc["spine_ms"] >= acc["wave_ms"]:
+            dom = ("spine", "vsg::k_spine (large components replayed along their Kruskal tree: side "
+                   "clusters absorbed in rank order, 64 per step, f32 mean as a systolic recurrence)",
+                   SPINE_BYTES_PER_EDGE, "side cluster absorbed")
+        else:
+            dom = ("wave", "vsg::k_merge_wave (ordered per-component union-find replay, round based)",
+                   WAVE_BYTES_PER_EDGE, "replayed edge")
+        dom_launches = max(acc[dom[0] + "_launches"], 1)
+        wave_avg_s = acc[dom[0] + "_ms"] / 1e3 / dom_launches
+        wave_bytes_per_launch = dom[2] * acc[dom[0] + "_edges"] / dom_launches
         achieved = wave_bytes_per_launch / wave_avg_s / 1e9 if wave_avg_s > 0 else 0.0
         # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes cannot run inside the
         # timed process, so the committed summary of the same workload is quoted (null if absent).
         traffic, traffic_note = None, "no PMC summary under profiles/"
-        pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_wave.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_%s.json" % dom[0])
         if os.path.exists(pmc_path) and (W, H, chunk) == (1920, 1080, 20):
             pmc = json.load(open(pmc_path))
             traffic = pmc["fetch_bytes_per_launch_raw"] + pmc["write_bytes_per_launch_raw"]
@@ -321,7 +338,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "vsg::k_merge_wave (ordered per-component union-find replay, round based)",
+                "kernel": dom[1],
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -329,17 +346,18 @@ def main():
                 "traffic": traffic,
                 "traffic_unit": "B/launch",
                 "traffic_note": traffic_note,
-                "launches": acc["wave_launches"],
+                "launches": acc[dom[0] + "_launches"],
                 "avg_launch_ms": wave_avg_s * 1e3,
                 "bytes_per_launch": wave_bytes_per_launch,
-                "note": "dependency-bound serial replay: algorithmic bytes = %d B per replayed "
-                        "edge (DESIGN.md); whole path = %.1f B/px/frame -> %.2f GB/s end to end"
-                        % (WAVE_BYTES_PER_EDGE, BYTES_PER_PX_FRAME,
+                "note": "dependency-bound serial replay: algorithmic bytes = %d B per %s "
+                        "(DESIGN.md); whole path = %.1f B/px/frame -> %.2f GB/s end to end"
+                        % (dom[2], dom[3], BYTES_PER_PX_FRAME,
                            fps / world * px * BYTES_PER_PX_FRAME / 1e9),
             },
             "stage_ms_per_step": {
                 "preprocess": acc["pre_ms"] / K, "edges_sort": acc["edges_ms"] / K,
                 "merge": acc["merge_ms"] / K, "merge_wave_kernel": acc["wave_ms"] / K,
+                "merge_spine_kernel": acc["spine_ms"] / K,
                 "merge_filter_kernel": acc["filter_ms"] / K, "readout": acc["readout_ms"] / K,
                 "host_post": acc["host_ms"] / K,
             },

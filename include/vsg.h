@@ -83,6 +83,10 @@ typedef struct vsg_timings {
   int64_t wave_kernel_edges;   /* active edges replayed by wavefront workers                 */
   float filter_kernel_ms;      /* k_filter, summed                                           */
   int64_t filter_kernel_launches;
+  /* k_spine (large components replayed along their Kruskal tree), same measurement. */
+  float spine_kernel_ms;
+  int64_t spine_kernel_launches;
+  int64_t spine_kernel_edges;  /* side clusters absorbed along the spines                    */
 } vsg_timings;
 
 const char* vsg_last_error(void);

@@ -2,8 +2,8 @@
 
     python tools/pmc_summary.py <counter_collection.csv> [...] [--wave-json OUT]
 
---wave-json writes the dominant kernel's (vsg::k_merge_wave) per-launch bytes in the form bench.py
-reads from profiles/r2_pmc_wave.json.
+--wave-json OUT writes the per-launch bytes of vsg::k_merge_wave to OUT and those of k_spine to OUT
+with "wave" replaced by "spine", in the form bench.py reads from profiles/r2_pmc_{wave,spine}.json.
 
 Counter values of FETCH_SIZE / WRITE_SIZE are in KB (rocprofv3 derived metrics)."""
 import collections
@@ -43,7 +43,9 @@ def main():
     print(json.dumps(dict(rows[:25]), indent=1))
     if wave_json:
         for name, e in out.items():
-            if "k_merge_wave" in name:
+            for kern, tag in (("k_merge_wave", "wave"), ("k_spine", "spine")):
+                if kern not in name or "k_spine_" in name:
+                    continue
                 json.dump({
                     "kernel": name, "launches": e["launches"],
                     "fetch_bytes_per_launch_raw": e.get("FETCH_SIZE_KB_per_launch", 0.0) * 1e3,
@@ -51,7 +53,8 @@ def main():
                     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
                               "'bench.py --no-cpu-baseline --no-pcie-leg', tools/measure_round.sh; "
                               "raw counters (gfx950: FETCH_SIZE may under-count wide streaming "
-                              "reads by 2x, MI355X_MICROARCH.md)"}, open(wave_json, "w"), indent=1)
+                              "reads by 2x, MI355X_MICROARCH.md)"},
+                          open(wave_json.replace("wave", tag), "w"), indent=1)
 
 
 if __name__ == "__main__":

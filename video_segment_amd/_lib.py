@@ -51,6 +51,9 @@ class VsgTimings(C.Structure):
         ("wave_kernel_edges", C.c_int64),
         ("filter_kernel_ms", C.c_float),
         ("filter_kernel_launches", C.c_int64),
+        ("spine_kernel_ms", C.c_float),
+        ("spine_kernel_launches", C.c_int64),
+        ("spine_kernel_edges", C.c_int64),
     ]
 
 

@@ -680,6 +680,9 @@ int vsg_graph_timings(const vsg_graph* g, vsg_timings* t) {
     t->wave_kernel_edges = gt.wave_edges;
     t->filter_kernel_ms = gt.filter_ms;
     t->filter_kernel_launches = gt.filter_launches;
+    t->spine_kernel_ms = gt.spine_ms;
+    t->spine_kernel_launches = gt.spine_launches;
+    t->spine_kernel_edges = gt.spine_edges;
   });
 }
 

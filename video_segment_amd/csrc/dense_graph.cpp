@@ -392,9 +392,11 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   ev_used_ = 0;
   ev_wave_.clear();
   ev_filter_.clear();
+  ev_spine_.clear();
   S.ev_pool = &ev_pool_;
   S.ev_wave = &ev_wave_;
   S.ev_filter = &ev_filter_;
+  S.ev_spine = &ev_spine_;
   S.ev_used = &ev_used_;
 
   MergeParams P;
@@ -453,6 +455,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     if (n_b == 0) continue;
     int64_t group_active = 0;
     int windows = n_b >= window_min_edges ? num_windows : 1;
+
     for (int w = 0; w < windows; ++w) {
       const int j0 = (int)((int64_t)n_b * w / windows);
       int j1 = (int)((int64_t)n_b * (w + 1) / windows);
@@ -518,6 +521,13 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     VSG_HIP(hipEventElapsedTime(&ms, ev_pool_[pr.first], ev_pool_[pr.second]));
     timings_.filter_ms += ms;
   }
+  for (auto& pr : ev_spine_) {
+    float ms = 0;
+    VSG_HIP(hipEventElapsedTime(&ms, ev_pool_[pr.first], ev_pool_[pr.second]));
+    timings_.spine_ms += ms;
+  }
+  timings_.spine_launches += (int64_t)ev_spine_.size();
+  timings_.spine_edges += (int64_t)st[24];
   timings_.wave_launches += (int64_t)ev_wave_.size();
   timings_.filter_launches += (int64_t)ev_filter_.size();
   timings_.wave_edges += (int64_t)st[3];

@@ -17,8 +17,8 @@ struct GraphTimings {
   float edges_ms = 0, sort_ms = 0, merge_ms = 0, readout_ms = 0, host_post_ms = 0;
   int64_t edges_total = 0, edges_active = 0;
   int64_t merges[3] = {0, 0, 0};   // forced, regular, small
-  float wave_ms = 0, filter_ms = 0;
-  int64_t wave_launches = 0, filter_launches = 0, wave_edges = 0;
+  float wave_ms = 0, filter_ms = 0, spine_ms = 0;
+  int64_t wave_launches = 0, filter_launches = 0, wave_edges = 0, spine_launches = 0, spine_edges = 0;
   int64_t optimistic_stages = 0, rollbacks = 0;
 };
 
@@ -167,7 +167,7 @@ class DenseGraphHip {
   DevBuf<int32_t> small_i32_a_, small_i32_b_, small_i32_c_;
   DevBuf<float4> small_f4_;
   std::vector<hipEvent_t> ev_pool_;
-  std::vector<std::pair<int, int>> ev_wave_, ev_filter_;
+  std::vector<std::pair<int, int>> ev_wave_, ev_filter_, ev_spine_;
   int ev_used_ = 0;
 
   std::vector<RegionInfo> regions_;

@@ -164,6 +164,7 @@ struct MergeScratch {
   std::vector<hipEvent_t>* ev_pool;
   std::vector<std::pair<int, int>>* ev_wave;     // indices into ev_pool
   std::vector<std::pair<int, int>>* ev_filter;
+  std::vector<std::pair<int, int>>* ev_spine;    // k_spine launches
   int* ev_used;
 };
 

@@ -311,6 +311,18 @@ void LaunchMergeWaveV1(int grid, const WorkerArgs& a, hipStream_t s);
 // Round-based replay by one consumer wavefront + one reader wavefront (the default).
 void LaunchMergeWave(int grid, const WorkerArgs& a, bool instrumented, int dbg_flags, hipStream_t s);
 
+// Next event of the stage's pool (HIP events recorded around the dominant kernels; resolved by the
+// caller once the stream has been synchronised); -1 without a pool.
+inline int NextEvent(MergeScratch& S) {
+  if (!S.ev_pool) return -1;
+  if (*S.ev_used >= (int)S.ev_pool->size()) {
+    hipEvent_t e;
+    VSG_HIP(hipEventCreate(&e));
+    S.ev_pool->push_back(e);
+  }
+  return (*S.ev_used)++;
+}
+
 // Kruskal-tree replay of the large components (merge_spine.hip).
 struct SpineSeg {
   int off;   // first edge in the component-sorted arrays

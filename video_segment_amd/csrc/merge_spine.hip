@@ -679,7 +679,10 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
     }
     return;   // the stage is undone
   }
-  if (lane == 0) StoreState(nodes, rep, H);
+  if (lane == 0) {
+    StoreState(nodes, rep, H);
+    atomicAdd(&stats[24], (unsigned long long)n);   // spine edges absorbed
+  }
   for (int off = 32; off > 0; off >>= 1) {
     n_forced += __shfl_down(n_forced, off);
     n_regular += __shfl_down(n_regular, off);
@@ -1096,8 +1099,15 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
     }
   }
   Mark(5);
+  const int es0 = NextEvent(S);
+  if (es0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[es0], s));
   hipLaunchKernelGGL(k_spine, dim3(K), dim3(64 * (1 + kSpineReaders)), 0, s, K, comp_spine, root_vertex, sp_child, sp_is_a, wa.nodes,
                      wa.T, wa.optimistic, wa.violation, wa.stats);
+  const int es1 = NextEvent(S);
+  if (es1 >= 0) {
+    VSG_HIP(hipEventRecord((*S.ev_pool)[es1], s));
+    if (S.ev_spine) S.ev_spine->emplace_back(es0, es1);
+  }
   VSG_HIP(hipGetLastError());
   Mark(6);
   if (S.spine_debug) {

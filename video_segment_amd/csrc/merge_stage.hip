@@ -413,16 +413,6 @@ __global__ __launch_bounds__(256) void k_resolve_followers(int n, const int32_t*
 // ------------------------------------------------------------------------------------------
 static inline unsigned Blocks(int n) { return (unsigned)((n + 255) / 256); }
 
-static int NextEvent(MergeScratch& S) {
-  if (!S.ev_pool) return -1;
-  if (*S.ev_used >= (int)S.ev_pool->size()) {
-    hipEvent_t e;
-    VSG_HIP(hipEventCreate(&e));
-    S.ev_pool->push_back(e);
-  }
-  return (*S.ev_used)++;
-}
-
 void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const int32_t* bucket_base,
                     const uint32_t* list_slot_base, uint8_t* kept_all, NodeArrays nodes,
                     const MergeParams& P, int inert_mode, MergeScratch& S, hipStream_t s,
@@ -534,8 +524,6 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   const int wave_grid = n_work / (kSmallSegment + 1) < 1 ? 1
                         : (n_work / (kSmallSegment + 1) > 8192 ? 8192
                                                                : n_work / (kSmallSegment + 1));
-  const int ew0 = NextEvent(S);
-  if (ew0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ew0], s));
   WorkerArgs wa;
   wa.num_segs = S.num_segs;
   wa.seg_off = S.seg_off;
@@ -556,10 +544,18 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     hipLaunchKernelGGL(k_merge_small, dim3(Blocks(small_threads)), dim3(256), 0, s, w.num_segs,
                        w.seg_off, w.seg_cnt, w.s_ra, w.s_rb, w.s_gpos, w.nodes, w.kept_all, w.T,
                        w.optimistic, w.violation, w.stats);
+    // the wave worker is timed on the stream it runs on
+    const int ew0 = NextEvent(S);
+    if (ew0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ew0], s));
     if (S.wave_v1) {
       LaunchMergeWaveV1(grid, w, s);
     } else {
       LaunchMergeWave(grid, w, S.wave_debug != 0, S.wave_dbg, s);
+    }
+    const int ew1 = NextEvent(S);
+    if (ew1 >= 0) {
+      VSG_HIP(hipEventRecord((*S.ev_pool)[ew1], s));
+      S.ev_wave->emplace_back(ew0, ew1);
     }
   };
   if (!spine) {
@@ -582,11 +578,6 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       general_workers(w3, n_work, wave_grid, s);
     }
     VSG_HIP(hipStreamWaitEvent(s, S.aux_join, 0));
-  }
-  const int ew1 = NextEvent(S);
-  if (ew1 >= 0) {
-    VSG_HIP(hipEventRecord((*S.ev_pool)[ew1], s));
-    S.ev_wave->emplace_back(ew0, ew1);
   }
   hipLaunchKernelGGL(k_reset_cc, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, w_rb, S.cc);
   VSG_HIP(hipGetLastError());

@@ -387,6 +387,9 @@ void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
   last_timings_.wave_kernel_edges = gt.wave_edges;
   last_timings_.filter_kernel_ms = gt.filter_ms;
   last_timings_.filter_kernel_launches = gt.filter_launches;
+  last_timings_.spine_kernel_ms = gt.spine_ms;
+  last_timings_.spine_kernel_launches = gt.spine_launches;
+  last_timings_.spine_kernel_edges = gt.spine_edges;
   std::memset(&accum_, 0, sizeof(accum_));
 }
 
