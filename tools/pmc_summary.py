@@ -17,7 +17,7 @@ def summarise(path):
     launches = collections.defaultdict(set)
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
-            name = row["Kernel_Name"].split("(")[0]
+            name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             per[name][row["Counter_Name"]] += float(row["Counter_Value"])
             launches[name].add(row["Dispatch_Id"])
     return per, launches

@@ -360,6 +360,9 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.wave_v1 = getenv("VSG_WAVE_V1") ? 1 : 0;
   S.spine_min = getenv("VSG_SPINE_MIN") ? atoi(getenv("VSG_SPINE_MIN")) : 4096;
   S.spine_max_edges = getenv("VSG_SPINE_MAX_EDGES") ? atoi(getenv("VSG_SPINE_MAX_EDGES")) : (48 << 20);
+  S.spine_off = 0;
+  S.spine_limit_bucket = &spine_limit_bucket_;
+  S.spine_nested_factor = getenv("VSG_SPINE_NESTED") ? std::max(1, atoi(getenv("VSG_SPINE_NESTED"))) : 4;
   S.spine_debug = getenv("VSG_SPINE_DEBUG") ? 1 : 0;
   S.spine_check = getenv("VSG_SPINE_CHECK") ? 1 : 0;
   if (S.spine_min > 0) {

@@ -149,6 +149,7 @@ class DenseGraphHip {
   int64_t optimistic_stages_ = 0, rollbacks_ = 0;
   DevBuf<int32_t> scalars_;   // num_active, num_segs, misc
   DevBuf<int32_t> bucket_prefix_dev_;   // edges in the buckets before b
+  int spine_limit_bucket_ = 0x7fffffff;   // learned per stream: where the tree replay stops paying
   DevBuf<int32_t> spine_pool_;   // scratch of the Kruskal-tree replay (merge_spine.hip)
   DevBuf<unsigned long long> stats_;
   DevBuf<uint8_t> cub_temp_;

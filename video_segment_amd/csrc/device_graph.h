@@ -142,6 +142,9 @@ struct MergeScratch {
   const int32_t* bucket_prefix_host;   // the same table on the host
   // Kruskal-tree replay of the large components (merge_spine.hip)
   int spine_min;         // components of at least this many replayed edges; 0: never
+  int spine_off;             // the current stage is a replay without the tree replay
+  int* spine_limit_bucket;   // buckets from this one on skip the tree replay (its assumption failed there)
+  int spine_nested_factor;   // side clusters go one level down from spine_min * this many edges
   int spine_max_edges;   // at most this many edges per stage (scratch pool)
   int spine_debug, spine_check;
   int32_t* spine_pool;   // scratch, SpinePoolInts(spine_max_edges) ints

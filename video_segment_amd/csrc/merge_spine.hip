@@ -98,7 +98,11 @@ __global__ __launch_bounds__(256) void k_bor_min(int n, const int32_t* __restric
   const int e = i < n ? (list ? list[i] : i) : -1;
   bool live = false;
   int cu = -1, cv = -1;
-  if (e >= 0 && estate[e] == 0) {
+  if (e >= 0 && round == 0) {   // every vertex is its own component; the ends of an edge differ
+    cu = eu[e];
+    cv = ev[e];
+    live = true;
+  } else if (e >= 0 && estate[e] == 0) {
     cu = CcFind(cc, eu[e]);
     cv = CcFind(cc, ev[e]);
     if (cu == cv) {
@@ -126,6 +130,8 @@ __global__ __launch_bounds__(256) void k_bor_min(int n, const int32_t* __restric
 }
 
 __global__ __launch_bounds__(256) void k_bor_mark(int n, const int32_t* __restrict__ list, int round,
+                                                   const int32_t* __restrict__ eu,
+                                                   const int32_t* __restrict__ ev,
                                                    int32_t* __restrict__ estate,
                                                    const uint32_t* __restrict__ best,
                                                    const int32_t* __restrict__ ecu, const int32_t* __restrict__ ecv) {
@@ -134,7 +140,8 @@ __global__ __launch_bounds__(256) void k_bor_mark(int n, const int32_t* __restri
   const int e = list ? list[i] : i;
   if (estate[e] != 0) return;
   const uint32_t key = BorKey(round, e);
-  if (best[ecu[e]] == key || best[ecv[e]] == key) estate[e] = 3;
+  const int cu = round == 0 ? eu[e] : ecu[e], cv = round == 0 ? ev[e] : ecv[e];
+  if (best[cu] == key || best[cv] == key) estate[e] = 3;
 }
 
 __global__ __launch_bounds__(256) void k_bor_union(int n, const int32_t* __restrict__ list,
@@ -525,8 +532,8 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
   int rep = root_vertex[k];
   RState H = LoadState(nodes, rep);
   unsigned n_forced = 0, n_regular = 0, n_small = 0;   // per lane
-  bool violated = false;
-  for (int base = 0; base < n && !violated; base += 64) {
+  int violated = 0;   // 2: the structure assumed a merge; 1: a tentatively settled edge is no longer valid
+  for (int base = 0; base < n && violated == 0; base += 64) {
     const int cnt = n - base < 64 ? n - base : 64;
     const int fill = base / (kSpineFill * 64);
     while (__hip_atomic_load(&ring.ready[fill % kSpineFills], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) !=
@@ -642,14 +649,14 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
       int stat;
       const int out = DecideEdge(s1, s2, T, stat);
       if (out == kOutKeep) {   // the structure assumed a merge
-        violated = true;
+        violated = 2;
         break;
       }
       if (optimistic) {
         const bool vio = (out == kOutMerge1) ? TentativeViolated(o1, o2, s1, s1)
                                              : TentativeViolated(o1, o2, s2, s2);
         if (vio) {
-          violated = true;
+          violated = 1;
           break;
         }
       }
@@ -674,7 +681,7 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
   }
   if (violated) {
     if (lane == 0) {
-      *violation = 1;
+      if (violated == 1) *violation = 1; else atomicOr(violation, 2);
       __hip_atomic_store(&ring.abort, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     return;   // the stage is undone
@@ -957,8 +964,8 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
           n_list = alive;
         }
       }
-      hipLaunchKernelGGL(k_bor_mark, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, round, estate, best,
-                         side_key, spine_flag);
+      hipLaunchKernelGGL(k_bor_mark, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, round, eu, ev, estate,
+                         best, side_key, spine_flag);
       hipLaunchKernelGGL(k_bor_union, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, eu, ev, estate, cc);
       if (dbg_big) {
         const double tr1 = NowMs();
@@ -1082,10 +1089,10 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
     SpineInput nested;
     int32_t* d_list = pool.take(kSpineListInts);
     w2.wave_max = 0x7fffffff;
-    if (pool.ok && depth < 8 && n_side >= S.spine_min * 4) {
+    if (pool.ok && depth < 8 && n_side >= S.spine_min * S.spine_nested_factor) {
       const long long room = (long long)((S.spine_pool_ints - pool_used - pool.used) / 16);
       // (a level costs about a millisecond of launches: only for what the wave worker needs longer for)
-      w2.wave_max = SelectLargeSegments(n_side, d_nseg, seg_off, seg_cnt, S.spine_min * 4,
+      w2.wave_max = SelectLargeSegments(n_side, d_nseg, seg_off, seg_cnt, S.spine_min * S.spine_nested_factor,
                                         room < S.spine_max_edges ? room : S.spine_max_edges, d_list, s, &nested);
     }
     run_workers(w2, n_side);

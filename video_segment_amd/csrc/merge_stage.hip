@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
         n_regular += (stat == 2);
         n_small += (stat == 3);
         if (out == kOutKeep) {
-          if (T.side) *violation = 1;
+          if (T.side) atomicOr(violation, 2);
           kept_all[s_gpos[p]] = 1;
           StoreState(nodes, r1, s1);
           StoreState(nodes, r2, s2);
@@ -492,7 +492,8 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   // made on the host from the list of components above the threshold.
   SpineInput spine_in;
   int spine_thr = 0x7fffffff;
-  if (S.spine_min > 0 && inert_mode != 0 && !S.wave_v1 && n_work >= S.spine_min) {
+  if (S.spine_min > 0 && !S.spine_off && bucket < *S.spine_limit_bucket && inert_mode != 0 && !S.wave_v1 &&
+      n_work >= S.spine_min) {
     spine_thr = SelectLargeSegments(n_work, S.num_segs, S.seg_off, S.seg_cnt, S.spine_min,
                                     S.spine_max_edges, S.spine_pool, s, &spine_in);
   }
@@ -596,6 +597,18 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_gpos, kept_all);
       clear_marks();
       VSG_HIP(hipGetLastError());
+      if (spine && violated == 2 && !S.force_rollback) {
+        // Only the tree replay's assumption failed (an edge of a large component was kept): the
+        // same stage again with the ordinary workers.  From the third bucket on that is the rule
+        // rather than the exception, so the later buckets (of this and the next chunks) skip it.
+        if (bucket >= 2 && bucket < *S.spine_limit_bucket) *S.spine_limit_bucket = bucket;
+        const int off = S.spine_off;
+        S.spine_off = 1;
+        RunBucketStage(bucket, j0, n_b, lists, bucket_base, list_slot_base, kept_all, nodes, P, inert_mode, S,
+                       s, info);
+        S.spine_off = off;
+        return;
+      }
       if (bucket_hi > bucket + 1) {
         // A group of buckets: bucket by bucket (each optimistic again) -- the conservative replay
         // of everything the group holds would chain it into one huge component.

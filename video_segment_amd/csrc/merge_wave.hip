@@ -763,7 +763,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
       WaveSync();
 
       if (valid && my_kept) kept_all[gpos] = 1;
-      if (T.side && __ballot(my_kept) && lane == 0) *violation = 1;
+      if (T.side && __ballot(my_kept) && lane == 0) atomicOr(violation, 2);
       // ---- write the changed regions back, reset the table ---------------------------------------
 #pragma unroll
       for (int e = 0; e < 2; ++e) {

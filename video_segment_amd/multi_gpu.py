@@ -151,7 +151,8 @@ def run_chain_bench(args, rank, world, local_rank):
     dev = torch.device("cuda", local_rank)
     flow = torch.from_numpy(synth.const_flow(W, H)).to(dev)
     transport = DistTransport(dev)
-    acc = {"wave_ms": 0.0, "wave_launches": 0, "wave_edges": 0, "merge_ms": 0.0, "pre_ms": 0.0,
+    acc = {"wave_ms": 0.0, "wave_launches": 0, "wave_edges": 0, "spine_ms": 0.0, "spine_launches": 0,
+           "spine_edges": 0, "merge_ms": 0.0, "pre_ms": 0.0,
            "edges_ms": 0.0, "readout_ms": 0.0, "host_ms": 0.0, "filter_ms": 0.0,
            "filter_launches": 0, "edges_total": 0, "merges": 0}
 
@@ -194,6 +195,9 @@ def run_chain_bench(args, rank, world, local_rank):
                     acc["wave_ms"] += t.wave_kernel_ms
                     acc["wave_launches"] += t.wave_kernel_launches
                     acc["wave_edges"] += t.wave_kernel_edges
+                    acc["spine_ms"] += t.spine_kernel_ms
+                    acc["spine_launches"] += t.spine_kernel_launches
+                    acc["spine_edges"] += t.spine_kernel_edges
                     acc["filter_ms"] += t.filter_kernel_ms
                     acc["filter_launches"] += t.filter_kernel_launches
                     acc["merge_ms"] += t.merge_ms
