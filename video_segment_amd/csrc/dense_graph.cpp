@@ -362,6 +362,18 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.spine_max_edges = getenv("VSG_SPINE_MAX_EDGES") ? atoi(getenv("VSG_SPINE_MAX_EDGES")) : (48 << 20);
   S.spine_off = 0;
   S.spine_limit_bucket = &spine_limit_bucket_;
+  // The first two buckets hold the large components the tree replay is for; on an input where its
+  // assumption keeps failing there (two chunks in a row) it is skipped for eight chunks, then
+  // tried again.
+  int spine_low_failed[2] = {0, 0}, spine_low_skip[2] = {0, 0};
+  for (int b = 0; b < 2; ++b) {
+    if (spine_low_cooldown_[b] > 0) {
+      --spine_low_cooldown_[b];
+      spine_low_skip[b] = 1;
+    }
+  }
+  S.spine_low_failed = spine_low_failed;
+  S.spine_low_skip = spine_low_skip;
   S.spine_nested_factor = getenv("VSG_SPINE_NESTED") ? std::max(1, atoi(getenv("VSG_SPINE_NESTED"))) : 4;
   S.spine_debug = getenv("VSG_SPINE_DEBUG") ? 1 : 0;
   S.spine_check = getenv("VSG_SPINE_CHECK") ? 1 : 0;
@@ -484,6 +496,14 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
       } else if (group_active > 16384) {
         group_width = std::max(group_width / 4, 1);
       }
+    }
+  }
+  for (int b = 0; b < 2; ++b) {
+    if (spine_low_skip[b]) continue;
+    spine_low_fails_[b] = spine_low_failed[b] ? spine_low_fails_[b] + 1 : 0;
+    if (spine_low_fails_[b] >= 2) {
+      spine_low_fails_[b] = 0;
+      spine_low_cooldown_[b] = 8;
     }
   }
   timings_.optimistic_stages = optimistic_stages_;

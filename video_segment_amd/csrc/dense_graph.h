@@ -150,6 +150,7 @@ class DenseGraphHip {
   DevBuf<int32_t> scalars_;   // num_active, num_segs, misc
   DevBuf<int32_t> bucket_prefix_dev_;   // edges in the buckets before b
   int spine_limit_bucket_ = 0x7fffffff;   // learned per stream: where the tree replay stops paying
+  int spine_low_fails_[2] = {0, 0}, spine_low_cooldown_[2] = {0, 0};   // the same for buckets 0 and 1
   DevBuf<int32_t> spine_pool_;   // scratch of the Kruskal-tree replay (merge_spine.hip)
   DevBuf<unsigned long long> stats_;
   DevBuf<uint8_t> cub_temp_;

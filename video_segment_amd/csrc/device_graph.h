@@ -143,6 +143,8 @@ struct MergeScratch {
   // Kruskal-tree replay of the large components (merge_spine.hip)
   int spine_min;         // components of at least this many replayed edges; 0: never
   int spine_off;             // the current stage is a replay without the tree replay
+  int* spine_low_failed;     // [2] out: the assumption failed in bucket 0 / 1 during this chunk
+  const int* spine_low_skip; // [2] in: bucket 0 / 1 skip the tree replay in this chunk
   int* spine_limit_bucket;   // buckets from this one on skip the tree replay (its assumption failed there)
   int spine_nested_factor;   // side clusters go one level down from spine_min * this many edges
   int spine_max_edges;   // at most this many edges per stage (scratch pool)

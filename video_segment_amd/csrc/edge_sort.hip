@@ -296,13 +296,13 @@ __global__ __launch_bounds__(256) void k_scatter_slots(const uint16_t* __restric
   }
   __syncthreads();
   for (int b = threadIdx.x; b < kBucketSlots; b += 256) {
-    int run = scanned[(size_t)b * num_tiles + tile];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const int c = cnt[w][b];
-      cnt[w][b] = run;
-      run += c;
-    }
+    const int c0 = cnt[0][b], c1 = cnt[1][b], c2 = cnt[2][b], c3 = cnt[3][b];
+    if ((c0 | c1 | c2 | c3) == 0) continue;   // the matrix is bin-major: a read per bin is a cache line
+    const int run = scanned[(size_t)b * num_tiles + tile];
+    cnt[0][b] = run;
+    cnt[1][b] = run + c0;
+    cnt[2][b] = run + c0 + c1;
+    cnt[3][b] = run + c0 + c1 + c2;
   }
   __syncthreads();
   const uint32_t slot0 = (uint32_t)(px0 * kPerPx);

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
     const int ra = FindCompress(nodes.parent, a);
     const int rb = FindCompress(nodes.parent, b);
     const uint32_t gpos = list_slot_base[l] + (uint32_t)pos;
-    int active = 0;
+    int active = 0, settled = 0;
     const bool gone = P.spatial_survivors && L.type == 0 && !P.spatial_survivors[gpos];
     if (ra != rb && !gone) {
       bool inert = false;
@@ -143,16 +143,22 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
       }
       if (inert) {
         kept_all[gpos] = 1;
+        settled = 1;
       } else {
         active = 1;
         CcUnion(cc, ra, rb);
       }
     }
-    e_ra[j] = ra;
-    e_rb[j] = rb;
-    e_gpos[j] = gpos;
+    // Roots and position only where something reads them back (the compaction: active; the
+    // clearing of the marks: tentative; the rollback: every kept mark the filter set) -- most
+    // edges of a stage are internal.
+    if (active | settled) {
+      e_ra[j] = ra;
+      e_rb[j] = rb;
+      e_gpos[j] = gpos;
+    }
     e_active[j] = active;
-    e_ti[j] = (uint8_t)ti;
+    e_ti[j] = (uint8_t)(ti ? 1 : (settled ? 2 : (active ? 3 : 0)));   // 1 tentatively settled, 2 settled for good, 3 active
   }
   const unsigned long long m = __ballot(ti != 0);
   if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(num_ti, (int)__popcll(m));
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256) void k_clear_tentative(int n_b, const uint8_t*
                                                           const int32_t* __restrict__ e_rb,
                                                           NodeArrays nodes) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_b || !e_ti[j]) return;
+  if (j >= n_b || e_ti[j] != 1) return;
   int r[2] = {e_ra[j], e_rb[j]};
   for (int k = 0; k < 2; ++k) {
     int x = r[k];
@@ -215,10 +221,11 @@ __global__ __launch_bounds__(256) void k_restore_roots(int n, const int32_t* __r
   nodes.flags[rb] = bk_flags[2 * i + 1];
 }
 
-__global__ __launch_bounds__(256) void k_clear_kept(int n_b, const uint32_t* __restrict__ e_gpos,
+__global__ __launch_bounds__(256) void k_clear_kept(int n_b, const uint8_t* __restrict__ e_ti,
+                                                     const uint32_t* __restrict__ e_gpos,
                                                      uint8_t* __restrict__ kept_all) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j < n_b) kept_all[e_gpos[j]] = 0;
+  if (j < n_b && e_ti[j]) kept_all[e_gpos[j]] = 0;   // every edge whose kept mark the stage may have set
 }
 
 __global__ __launch_bounds__(256) void k_compact_active(int n_b, const int32_t* __restrict__ e_active,
@@ -492,8 +499,8 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   // made on the host from the list of components above the threshold.
   SpineInput spine_in;
   int spine_thr = 0x7fffffff;
-  if (S.spine_min > 0 && !S.spine_off && bucket < *S.spine_limit_bucket && inert_mode != 0 && !S.wave_v1 &&
-      n_work >= S.spine_min) {
+  if (S.spine_min > 0 && !S.spine_off && bucket < *S.spine_limit_bucket &&
+      !(bucket < 2 && S.spine_low_skip[bucket]) && inert_mode != 0 && !S.wave_v1 && n_work >= S.spine_min) {
     spine_thr = SelectLargeSegments(n_work, S.num_segs, S.seg_off, S.seg_cnt, S.spine_min,
                                     S.spine_max_edges, S.spine_pool, s, &spine_in);
   }
@@ -594,7 +601,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
                          nodes, S.bk_ds, S.bk_cons, S.bk_flags);
       VSG_HIP(hipMemcpyAsync(S.stats, S.stats + 8, 8 * sizeof(unsigned long long),
                              hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_gpos, kept_all);
+      hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_ti, S.e_gpos, kept_all);
       clear_marks();
       VSG_HIP(hipGetLastError());
       if (spine && violated == 2 && !S.force_rollback) {
@@ -602,6 +609,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
         // same stage again with the ordinary workers.  From the third bucket on that is the rule
         // rather than the exception, so the later buckets (of this and the next chunks) skip it.
         if (bucket >= 2 && bucket < *S.spine_limit_bucket) *S.spine_limit_bucket = bucket;
+        if (bucket < 2) S.spine_low_failed[bucket] = 1;   // the first two buckets: see SegmentLists
         const int off = S.spine_off;
         S.spine_off = 1;
         RunBucketStage(bucket, j0, n_b, lists, bucket_base, list_slot_base, kept_all, nodes, P, inert_mode, S,
