@@ -243,6 +243,18 @@ __device__ __forceinline__ RState ReadLaneState(const RState& s, int lane) {
   return r;
 }
 
+// c ? a : b, field by field (a conditional on the structs themselves goes through the stack).
+__device__ __forceinline__ RState SelectState(bool c, const RState& a, const RState& b) {
+  RState r;
+  r.d0 = c ? a.d0 : b.d0;
+  r.d1 = c ? a.d1 : b.d1;
+  r.d2 = c ? a.d2 : b.d2;
+  r.sz = c ? a.sz : b.sz;
+  r.cons = c ? a.cons : b.cons;
+  r.flags = c ? a.flags : b.flags;
+  return r;
+}
+
 __device__ __forceinline__ bool SameState(const RState& a, const RState& b) {
   return a.sz == b.sz && a.cons == b.cons && a.flags == b.flags;   // descriptor only changes with sz
 }

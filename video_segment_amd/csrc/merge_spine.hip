@@ -594,9 +594,10 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
           c = 0.0f;
         }
         float g0 = u0, g1 = u1, g2 = u2;
-        for (int s4 = 1; s4 < end - start; s4 += 4) {
+        const int steps = __builtin_amdgcn_readfirstlane(end - start);   // scalar loop control
+        for (int s8 = 1; s8 < steps; s8 += 8) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < 8; ++q) {
             g0 = u0 + c * DppWaveShr1Zero(g0);
             g1 = u1 + c * DppWaveShr1Zero(g1);
             g2 = u2 + c * DppWaveShr1Zero(g2);
@@ -643,8 +644,8 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
       const RState Ps = ReadLaneState(P, start);
       const int pid = ReadLaneI(p, start);
       const bool child_first = ReadLaneI(is_a, start) != 0;
-      RState s1 = child_first ? Ps : H;
-      RState s2 = child_first ? H : Ps;
+      RState s1 = SelectState(child_first, Ps, H);
+      RState s2 = SelectState(child_first, H, Ps);
       const RState o1 = s1, o2 = s2;
       int stat;
       const int out = DecideEdge(s1, s2, T, stat);
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
         }
       }
       if (partner_wins) rep = pid;
-      H = (out == kOutMerge1) ? s1 : s2;
+      H = SelectState(out == kOutMerge1, s1, s2);
       ++start;
     }
   }

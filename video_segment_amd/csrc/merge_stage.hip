@@ -1,4 +1,4 @@
-// merge_stage.hip -- the ordered union-find merge (K6), gfx950: the stage of one bucket.
+// merge_stage.hip -- the ordered union-find merge (K6), gfx950: one stage of the edge sequence.
 //
 // Reference semantics restated: FastSegmentationGraph::SegmentGraph / GetRegion / MergeRegions
 // (segmentation/segmentation_graph.h:339-463, 651-701) with ColorMeanDescriptorTraits
@@ -7,21 +7,25 @@
 // so the result is order dependent.  This file keeps that order *exactly* and extracts the
 // parallelism that is provably free:
 //
-//   stage = one bucket.  k_filter (all CUs): find both roots with path compression, drop edges
-//   that are already internal, settle edges between two finalized, large, unconstrained-graph
-//   regions as "kept" (they can never change state again), and hook the roots of the remaining
-//   *active* edges into a scratch union-find (ECL-CC style atomicCAS hooking).
+//   stage = a consecutive range of the edge sequence: a bucket, a rank window of a bucket, or a
+//   group of buckets with the same thresholds (the argument below never uses that the range is a
+//   bucket).  k_filter (all CUs): find both roots with path compression, drop edges that are
+//   already internal, settle edges between two finalized, large, unconstrained-graph regions as
+//   "kept" (they can never change state again), and hook the roots of the remaining *active*
+//   edges into a scratch union-find (ECL-CC style atomicCAS hooking).
 //   Two active edges can only influence each other if they are connected through active edges of
-//   the same bucket, so each connected component of that scratch graph is an independent
+//   the same stage, so each connected component of that scratch graph is an independent
 //   sequential sub-problem.  Active edges are stably sorted by component and every component is
-//   replayed in the reference's order by its own worker: one lane for a small component, one
-//   64-lane wavefront for a large one (lanes prefetch roots + region state for 64 edges, then the
-//   wave resolves them in order with readlane broadcasts, keeping region state in registers).
+//   replayed in the reference's order by its own worker: one lane for a small component
+//   (k_merge_small), a reader + a consumer wavefront for an ordinary one (merge_wave.hip), the
+//   Kruskal-tree replay for a large one (merge_spine.hip).  A stage that relies on an assumption
+//   (tentatively settled edges, run leaders, the tree structure) is undoable: region states are
+//   backed up, a worker that sees the assumption fail raises the violation flag, and the stage is
+//   restored and replayed without it.
 //
 // This is memory-latency / dependency bound integer + scalar float work: no MFMA, no LDS tiling;
 // what matters is coalesced streaming in the filter and keeping the serial chains in registers.
-// The workers of the large components live in merge_wave.hip (default)
-// and merge_wave_v1.hip (edge-by-edge reference); shared device helpers in merge_common.h.
+// merge_wave_v1.hip is the edge-by-edge debug worker; shared device helpers in merge_common.h.
 #include <algorithm>
 
 #include "merge_common.h"

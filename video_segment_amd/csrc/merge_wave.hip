@@ -150,9 +150,9 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
     if (!pend_mask) break;
     // The round's hot region: the larger end of the earliest pending edge.  That edge owns
     // its other end by construction, so the chain can always start, and the run of edges that
-    // depends on it (the growth front of its cluster) joins the chain in this round.  On the
-    // scheduler model (tools/sched_sim.cpp) this needs 2.6 M instead of 5.5 M rounds for the
-    // cluster bucket of the 1080p input, compared with one hot region per batch.
+    // depends on it (the growth front of its cluster) joins the chain in this round (2.6 M instead
+    // of 5.5 M rounds for the cluster bucket of the 1080p input, compared with one hot region
+    // per batch).
     {
       const int first = (int)__builtin_ctzll(pend_mask);
       const int fa = ReadLaneI(sa, first), fb = ReadLaneI(sb, first);
