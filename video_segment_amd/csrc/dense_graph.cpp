@@ -492,7 +492,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     }
     if (b >= first_plain) {
       if (group_active < 2048) {
-        group_width = std::min(group_width * 2, 256);
+        group_width = std::min(group_width * 4, 512);
       } else if (group_active > 16384) {
         group_width = std::max(group_width / 4, 1);
       }

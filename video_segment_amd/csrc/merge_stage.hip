@@ -622,18 +622,21 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
         return;
       }
       if (bucket_hi > bucket + 1) {
-        // A group of buckets: bucket by bucket (each optimistic again) -- the conservative replay
-        // of everything the group holds would chain it into one huge component.
+        // A group of buckets: its two halves (each optimistic again, split further if it fails
+        // again) -- the conservative replay of everything the group holds would chain it into one
+        // huge component, and bucket by bucket would cost a stage per bucket.
         const int group_hi = S.group_hi;
         const int64_t g0 = (int64_t)S.bucket_prefix_host[bucket] + j0, g1 = g0 + n_b;
+        const int mid = bucket + (bucket_hi - bucket) / 2;
+        const int halves[2][2] = {{bucket, mid}, {mid, bucket_hi}};
         int replayed = 0;
-        for (int bb = bucket; bb < bucket_hi; ++bb) {
-          const int64_t lo = std::max<int64_t>(g0, S.bucket_prefix_host[bb]);
-          const int64_t hi = std::min<int64_t>(g1, S.bucket_prefix_host[bb + 1]);
+        for (const auto& h : halves) {
+          const int64_t lo = std::max<int64_t>(g0, S.bucket_prefix_host[h[0]]);
+          const int64_t hi = std::min<int64_t>(g1, S.bucket_prefix_host[h[1]]);
           if (hi <= lo) continue;
-          S.group_hi = 0;
+          S.group_hi = h[1];
           StageInfo sub;
-          RunBucketStage(bb, (int)(lo - S.bucket_prefix_host[bb]), (int)(hi - lo), lists, bucket_base,
+          RunBucketStage(h[0], (int)(lo - S.bucket_prefix_host[h[0]]), (int)(hi - lo), lists, bucket_base,
                          list_slot_base, kept_all, nodes, P, inert_mode, S, s, info ? &sub : nullptr);
           replayed += sub.replayed;
         }
