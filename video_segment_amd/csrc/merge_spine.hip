@@ -171,13 +171,17 @@ __global__ __launch_bounds__(256) void k_bor_compact(int n, const int32_t* __res
 }
 
 // ---- R: the largest region of every component --------------------------------------------------------
+constexpr int kRootStride = 16;
 __global__ __launch_bounds__(256) void k_spine_pick_root(int mE, int K, const int32_t* __restrict__ eu,
                                                           const int32_t* __restrict__ ev,
                                                           const int32_t* __restrict__ comp_base, NodeArrays nodes,
                                                           unsigned long long* __restrict__ root_key) {
   __shared__ unsigned long long red[256];
   __shared__ int comp0;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  // Every kRootStride-th edge is looked at (R is an end of most edges of its component, any vertex
+  // would do), and the first edge of every component, so that none stays without a root.
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int e = i < K ? comp_base[i] : (i - K) * kRootStride;
   unsigned long long key = 0;
   int k = -1;
   if (e < mE) {
@@ -909,8 +913,8 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   VSG_HIP(hipMemsetAsync(root_key, 0, K * sizeof(unsigned long long), s));
   hipLaunchKernelGGL(k_spine_gather, dim3(Blocks(mE)), dim3(256), 0, s, mE, K, d_base, d_off, wa.s_ra,
                      wa.s_rb, eu, ev, estate, cc, best);
-  hipLaunchKernelGGL(k_spine_pick_root, dim3(Blocks(mE)), dim3(256), 0, s, mE, K, eu, ev, d_base, wa.nodes,
-                     root_key);
+  hipLaunchKernelGGL(k_spine_pick_root, dim3(Blocks((size_t)K + (mE + kRootStride - 1) / kRootStride)), dim3(256), 0,
+                     s, mE, K, eu, ev, d_base, wa.nodes, root_key);
   hipLaunchKernelGGL(k_spine_roots, dim3((K + 63) / 64), dim3(64), 0, s, K, root_key, root_vertex, childidx);
 
   // ---- tree edges ----------------------------------------------------------------------------------------
