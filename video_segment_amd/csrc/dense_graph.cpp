@@ -62,6 +62,7 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   scalars_.alloc(16);
   stats_.alloc(64);
   VSG_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
+  VSG_HIP(hipStreamCreateWithFlags(&aux2_stream_, hipStreamNonBlocking));
   VSG_HIP(hipEventCreateWithFlags(&aux_fork_, hipEventDisableTiming));
   VSG_HIP(hipEventCreateWithFlags(&aux_join_, hipEventDisableTiming));
 
@@ -75,6 +76,7 @@ DenseGraphHip::~DenseGraphHip() {
   if (aux_fork_) (void)hipEventDestroy(aux_fork_);
   if (aux_join_) (void)hipEventDestroy(aux_join_);
   if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
+  if (aux2_stream_) (void)hipStreamDestroy(aux2_stream_);
 }
 
 void DenseGraphHip::Reset(int max_frames) {
@@ -374,7 +376,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   }
   S.spine_low_failed = spine_low_failed;
   S.spine_low_skip = spine_low_skip;
-  S.spine_nested_factor = getenv("VSG_SPINE_NESTED") ? std::max(1, atoi(getenv("VSG_SPINE_NESTED"))) : 4;
+  S.spine_nested_factor = getenv("VSG_SPINE_NESTED") ? std::max(1, atoi(getenv("VSG_SPINE_NESTED"))) : 2;
   S.spine_debug = getenv("VSG_SPINE_DEBUG") ? 1 : 0;
   S.spine_check = getenv("VSG_SPINE_CHECK") ? 1 : 0;
   if (S.spine_min > 0) {
@@ -387,6 +389,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.nmap[1] = label_img_.get();
   S.nmap[2] = adjust_.get();
   S.aux_stream = aux_stream_;
+  S.aux2_stream = aux2_stream_;
   S.aux_fork = aux_fork_;
   S.aux_join = aux_join_;
   S.lead_pos = lead_pos_.get();

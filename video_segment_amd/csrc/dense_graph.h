@@ -104,6 +104,7 @@ class DenseGraphHip {
   bool l1_;
   hipStream_t stream_;
   hipStream_t aux_stream_ = nullptr;   // second stream of the merge stages (see RunBucketStage)
+  hipStream_t aux2_stream_ = nullptr;  // third: side clusters beside the next tree level (merge_spine.hip)
   hipEvent_t aux_fork_ = nullptr, aux_join_ = nullptr;
   int num_frames_ = 0;
   size_t wh_;

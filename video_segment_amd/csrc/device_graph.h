@@ -153,6 +153,7 @@ struct MergeScratch {
   size_t spine_pool_ints;
   int32_t* nmap[3];      // three more [N] scratch maps (free during the bucket stages)
   hipStream_t aux_stream;   // the ordinary workers run here while the trees are built on the main stream
+  hipStream_t aux2_stream;  // the ordinary side clusters of a tree level, beside the level below
   hipEvent_t aux_fork, aux_join;
   int wave_v1;           // debug hook: use the sequential wave worker (k_merge_wave_v1)
   int wave_debug;        // use the instrumented build of the wave worker (counters, self checks)

@@ -344,7 +344,7 @@ struct SpineInput {
   std::vector<SpineSeg> segs;
 };
 // Launches the ordinary workers (k_merge_small + wave worker) on the given segments.
-using SpineWorkers = std::function<void(const WorkerArgs&, int n_edges)>;
+using SpineWorkers = std::function<void(const WorkerArgs&, int n_edges, hipStream_t)>;
 // The head of the spine scratch pool holds the list SelectLargeSegments reads back.
 constexpr int kSpineListCap = 4095;
 constexpr size_t kSpineListInts = 8192;

@@ -1100,14 +1100,27 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
       w2.wave_max = SelectLargeSegments(n_side, d_nseg, seg_off, seg_cnt, S.spine_min * S.spine_nested_factor,
                                         room < S.spine_max_edges ? room : S.spine_max_edges, d_list, s, &nested);
     }
-    run_workers(w2, n_side);
-    if (!nested.segs.empty()) {
+    if (nested.segs.empty()) {
+      run_workers(w2, n_side, s);
+    } else {
+      // the ordinary side clusters on the third stream, beside the level below (disjoint regions)
+      const int ef = NextEvent(S), ej = NextEvent(S);
+      const bool fork = S.aux2_stream && ef >= 0 && ej >= 0;
+      if (fork) {
+        VSG_HIP(hipEventRecord((*S.ev_pool)[ef], s));
+        VSG_HIP(hipStreamWaitEvent(S.aux2_stream, (*S.ev_pool)[ef], 0));
+        run_workers(w2, n_side, S.aux2_stream);
+        VSG_HIP(hipEventRecord((*S.ev_pool)[ej], S.aux2_stream));
+      } else {
+        run_workers(w2, n_side, s);
+      }
       if (!RunSpineComponents(nested, w2, S, s, run_workers, pool_used + pool.used, depth + 1)) {
         WorkerArgs w3 = w2;   // no room: the wave worker replays them
         w3.wave_min = w2.wave_max - 1;
         w3.wave_max = 0x7fffffff;
-        run_workers(w3, n_side);
+        run_workers(w3, n_side, s);
       }
+      if (fork) VSG_HIP(hipStreamWaitEvent(s, (*S.ev_pool)[ej], 0));
     }
   }
   Mark(5);

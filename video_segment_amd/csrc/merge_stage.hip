@@ -579,9 +579,9 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     VSG_HIP(hipStreamWaitEvent(S.aux_stream, S.aux_fork, 0));
     general_workers(wa, n_work, wave_grid, S.aux_stream);
     VSG_HIP(hipEventRecord(S.aux_join, S.aux_stream));
-    const bool done = RunSpineComponents(spine_in, wa, S, s, [&](const WorkerArgs& w, int n) {
+    const bool done = RunSpineComponents(spine_in, wa, S, s, [&](const WorkerArgs& w, int n, hipStream_t st) {
       const int g = n / (kSmallSegment + 1) < 1 ? 1 : (n / (kSmallSegment + 1) > 8192 ? 8192 : n / (kSmallSegment + 1));
-      general_workers(w, n, g, s);
+      general_workers(w, n, g, st);
     }, kSpineListInts, 0);
     if (!done) {   // no room in the scratch pool: the wave worker replays them
       WorkerArgs w3 = wa;
