@@ -49,7 +49,8 @@ SPINE_BYTES_PER_EDGE = 4 + 4 + 4 + 21 + 4
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one per GPU); default: WORLD_SIZE when a launcher set it, else 1")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=1920)
@@ -130,6 +131,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    gpus_given = args.gpus is not None
+    if not gpus_given:
+        args.gpus = world      # `torchrun --nproc-per-node N bench.py` without --gpus
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves.
         os.execvp(sys.executable, [
@@ -137,7 +141,8 @@ def main():
             "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
             "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)]
             + sys.argv[1:])
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    if gpus_given:
+        assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -159,7 +164,7 @@ def main():
     K, Wm = args.steps, args.warmup
     dev = torch.device("cuda", local_rank)
 
-    if args.mode == "chain" and world > 1:
+    if args.mode == "chain":
         from video_segment_amd.multi_gpu import run_chain_bench
         result = run_chain_bench(args, rank, world, local_rank)
     else:
@@ -366,6 +371,8 @@ def main():
         }
         if result.get("pcie"):
             out["pcie_inclusive"] = result["pcie"]
+        if result.get("handoff"):
+            out["config"]["handoff"] = result["handoff"]
         if not args.no_cpu_baseline:
             out["cpu_baseline"], threaded, out["parity_checked"] = cpu_baseline(
                 W, H, chunk, args.cpu_frames, local_rank)

@@ -9,7 +9,8 @@
  *       called by DenseSegmentationUnit::ProcessFrame/PostProcess, segmentation_unit.cpp:118-161
  *
  *   vsg_graph_*   <->  segmentation::DenseSegGraphInterface       (seam 3)
- *       segmentation/dense_seg_graph_interface.h:107-159 (13 pure virtuals, all mirrored)
+ *       segmentation/dense_seg_graph_interface.h:107-159 (13 pure virtuals, all mirrored; the
+ *       RegionInfoList they fill is read back with vsg_graph_get_regions / _get_intervals)
  *       obtained through DenseSegmentation::CreateDenseSegGraph, dense_segmentation.cpp:253-266
  *
  * Results cross the boundary as serialized segmentation.proto `SegmentationDesc` messages
@@ -157,16 +158,28 @@ int vsg_stream_restart(vsg_stream* s);
 
 /* Chunk hand-off between GPUs over RCCL (point-to-point ncclSend / ncclRecv over xGMI), for a
  * host that shards ONE video chunk-wise over the GPUs of a node: one process per
- * GPU, one vsg_chain per process.  id_file: a path all ranks can read; rank 0 creates it (the
- * NCCL unique id), the others wait for it.  send_halo ships what vsg_stream_export_halo
- * describes (two W*H int32 label planes + 4 counters) to rank dst; recv_halo receives it from
- * rank src and imports it into the stream (vsg_stream_import_halo semantics, including the
- * overlapped order above).  Both block until the transfer has completed. */
+ * GPU, one vsg_chain per process.
+ *   id_file : a path all ranks can read and rank 0 can write.  Rank 0 removes whatever is there,
+ *             publishes {magic, nonce, ncclUniqueId} atomically and removes the file again once
+ *             the communicator exists; the others poll (two minutes) for a record with THEIR nonce.
+ *   nonce   : any value the ranks of this run share and earlier runs did not use (launch time,
+ *             a hash of the launcher's run id ...): a record left behind by another run is
+ *             ignored instead of joined.
+ * send_halo ships what vsg_stream_export_halo describes (two W*H int32 label planes + 4 counters)
+ * to rank dst; recv_halo receives it from rank src and imports it into the stream
+ * (vsg_stream_import_halo semantics, including the overlapped order above).  exchange_halo does
+ * both in one RCCL group (either stream may be NULL); with dst == src == the own rank it is the
+ * hand-off between two handles of ONE GPU through the same RCCL calls.  All three block until
+ * the transfer has completed; the streams have to live on the chain's device. */
 typedef struct vsg_chain vsg_chain;
-int vsg_chain_create(int rank, int world, const char* id_file, int device, vsg_chain** out);
+int vsg_chain_create(int rank, int world, const char* id_file, uint64_t nonce, int device,
+                     vsg_chain** out);
 void vsg_chain_destroy(vsg_chain* c);
+/* Rank and size as the RCCL communicator reports them (ncclCommUserRank / ncclCommCount). */
+int vsg_chain_info(const vsg_chain* c, int* rank, int* world);
 int vsg_chain_send_halo(vsg_chain* c, vsg_stream* from, int dst);
 int vsg_chain_recv_halo(vsg_chain* c, vsg_stream* into, int src);
+int vsg_chain_exchange_halo(vsg_chain* c, vsg_stream* from, int dst, vsg_stream* into, int src);
 
 /* ---- seam 3: DenseSegGraphInterface ------------------------------------------------------- */
 /* CreateDenseSegGraph(frame_width, frame_height, max_frames) + InitializeGraph(),
@@ -205,6 +218,27 @@ int64_t vsg_graph_num_neighbor_links(const vsg_graph* g);
 int vsg_graph_region_sizes(const vsg_graph* g, int32_t* sizes, int32_t* constrained_ids);
 /* Per-pixel RegionInformation index of slice t from the rasterizations (host, W*H int32). */
 int vsg_graph_index_image(const vsg_graph* g, int t, int32_t* out);
+/* The RegionInfoList that ObtainResults / DetermineNeighborIds fill
+ * (dense_seg_graph_interface.h:147-158; RegionInformation, segmentation_common.h:39-116), as
+ * plain arrays an adapter rebuilds the reference's objects from.  Library-owned, valid until the
+ * next call on the handle.
+ *   regions[i]  : RegionInformation with index == i: size, constrained_id, first / last frame of
+ *                 its Rasterization3D (-1, -1: raster == nullptr, a representative that only
+ *                 appears as a neighbour).
+ *   nbr_csr_ptr : num_regions + 1 offsets into nbr_csr_idx; nbr_csr_idx[ptr[i] .. ptr[i+1]) =
+ *                 RegionInformation::neighbor_idx of region i (sorted, unique region indices).
+ *   intervals   : the scan intervals of slice `frame`, region after region in index order, each
+ *                 region's in the order of its Rasterization (scan order; merged tubes: sorted by
+ *                 MergeRasterization) -- exactly what raster->find(frame)->second holds. */
+typedef struct vsg_region {
+  int32_t index, size, constrained_id, first_frame, last_frame;
+} vsg_region;
+typedef struct vsg_interval {
+  int32_t region_index, y, left_x, right_x;
+} vsg_interval;
+int vsg_graph_get_regions(vsg_graph* g, const vsg_region** regions, size_t* num_regions,
+                          const int32_t** nbr_csr_ptr, const int32_t** nbr_csr_idx);
+int vsg_graph_get_intervals(vsg_graph* g, int frame, const vsg_interval** intervals, size_t* n);
 /* Parity hooks (host memory outputs). */
 int vsg_graph_smoothed(vsg_graph* g, int t, float* out /* W*H*3 interleaved */);
 int vsg_graph_spatial_buckets(vsg_graph* g, int t, uint16_t* out /* 4*W*H, plane k */);

@@ -2088,6 +2088,47 @@ void vso_graph_region_sizes(const vso_graph* g, int32_t* sizes, int32_t* constra
     constrained[i] = g->regions[i]->constrained_id;
   }
 }
+int64_t vso_graph_get_regions(const vso_graph* g, int32_t* regions5, int32_t* nbr_ptr, int32_t* nbr_idx) {
+  int64_t total = 0;
+  for (size_t i = 0; i < g->regions.size(); ++i) {
+    const vso::RegionInformation& r = *g->regions[i];
+    if (regions5) {
+      const bool has = r.raster && !r.raster->empty();
+      regions5[5 * i + 0] = r.index;
+      regions5[5 * i + 1] = r.size;
+      regions5[5 * i + 2] = r.constrained_id;
+      regions5[5 * i + 3] = has ? r.raster->front().first : -1;
+      regions5[5 * i + 4] = has ? r.raster->back().first : -1;
+    }
+    if (nbr_ptr) nbr_ptr[i] = (int32_t)total;
+    if (nbr_idx) {
+      for (int n : r.neighbor_idx) nbr_idx[total++] = n;
+    } else {
+      total += (int64_t)r.neighbor_idx.size();
+    }
+  }
+  if (nbr_ptr) nbr_ptr[g->regions.size()] = (int32_t)total;
+  return total;
+}
+int64_t vso_graph_get_intervals(const vso_graph* g, int frame, int32_t* out4) {
+  int64_t n = 0;
+  for (const auto& r : g->regions) {
+    if (!r->raster) continue;
+    for (const auto& slice : *r->raster) {
+      if (slice.first != frame) continue;
+      for (const vso::ScanInterval& s : *slice.second) {
+        if (out4) {
+          out4[4 * n + 0] = r->index;
+          out4[4 * n + 1] = s.y;
+          out4[4 * n + 2] = s.left_x;
+          out4[4 * n + 3] = s.right_x;
+        }
+        ++n;
+      }
+    }
+  }
+  return n;
+}
 void vso_graph_merge_stats(const vso_graph* g, int64_t* stats3) { g->g->MergeStats(stats3); }
 void vso_graph_bucket_census(const vso_graph* g, int64_t* out) {
   const auto& c = g->g->census();

@@ -120,6 +120,14 @@ void vso_graph_node_roots(vso_graph* g, int32_t* out);
 void vso_graph_index_image(const vso_graph* g, int t, int32_t* out);
 /* Region table: index -> size, constrained_id, #neighbors; neighbor ids concatenated. */
 void vso_graph_region_sizes(const vso_graph* g, int32_t* sizes, int32_t* constrained);
+/* The RegionInfoList itself (mirrors vsg_graph_get_regions / vsg_graph_get_intervals):
+ * regions5: num_regions x {index, size, constrained_id, first_frame, last_frame} (-1, -1 without
+ * a rasterization); nbr_ptr: num_regions + 1 offsets; nbr_idx: neighbor_idx lists concatenated
+ * (call with NULL outputs first: returns the total number of neighbour entries). */
+int64_t vso_graph_get_regions(const vso_graph* g, int32_t* regions5, int32_t* nbr_ptr, int32_t* nbr_idx);
+/* Scan intervals of slice `frame`: {region index, y, left_x, right_x}, regions in index order,
+ * each in the order of its Rasterization.  out NULL: returns the count only. */
+int64_t vso_graph_get_intervals(const vso_graph* g, int frame, int32_t* out4);
 void vso_graph_merge_stats(const vso_graph* g, int64_t* stats3);
 /* Per bucket event census of the last vso_graph_segment: for each of 2048 buckets
  * {edges, internal, regular_merge, fail_finalize, small_merge, kept, forced_merge}. */

@@ -93,6 +93,10 @@ def lib():
     L.vso_graph_index_image.argtypes = [vp, C.c_int, vp]
     L.vso_graph_region_sizes.argtypes = [vp, vp, vp]
     L.vso_graph_merge_stats.argtypes = [vp, vp]
+    L.vso_graph_get_regions.restype = C.c_int64
+    L.vso_graph_get_regions.argtypes = [vp, vp, vp, vp]
+    L.vso_graph_get_intervals.restype = C.c_int64
+    L.vso_graph_get_intervals.argtypes = [vp, C.c_int, vp]
     L.vso_graph_bucket_census.argtypes = [vp, vp]
     _lib = L
     return L
@@ -336,6 +340,24 @@ class OracleGraph:
         s = np.zeros(3, np.int64)
         lib().vso_graph_merge_stats(self.h, _ptr(s))
         return s
+
+    def get_regions(self):
+        """RegionInfoList: (regions [n,5] = index, size, constrained_id, first, last frame;
+        nbr_ptr [n+1]; nbr_idx)."""
+        n = self.num_regions()
+        total = lib().vso_graph_get_regions(self.h, None, None, None)
+        regs = np.empty((n, 5), np.int32)
+        ptr = np.empty(n + 1, np.int32)
+        idx = np.empty(max(total, 1), np.int32)
+        lib().vso_graph_get_regions(self.h, _ptr(regs), _ptr(ptr), _ptr(idx))
+        return regs, ptr, idx[:total]
+
+    def get_intervals(self, t):
+        """Scan intervals of slice t: [m,4] = region index, y, left_x, right_x."""
+        m = lib().vso_graph_get_intervals(self.h, t, None)
+        out = np.empty((max(m, 1), 4), np.int32)
+        lib().vso_graph_get_intervals(self.h, t, _ptr(out))
+        return out[:m]
 
     def bucket_census(self):
         out = np.zeros((2048, 7), np.int64)

@@ -43,10 +43,11 @@ def test_chunk_plan():
 
 def test_chain_single_process_matches_single_stream():
     """Fresh engine per chunk + halo import/export == one continuous stream."""
-    from video_segment_amd.multi_gpu import run_chain
+    from video_segment_amd.multi_gpu import local_transport, run_chain
     fl = synth.const_flow(W, H)
     got = run_chain(lambda: ol.OracleStream(W, H, ol.default_options(chunk_size=CHUNK), has_flow=True),
-                    lambda k: synth.bench_frame(W, H, k), lambda k: fl, N, CHUNK, W, H, 0, 1, None)
+                    lambda k: synth.bench_frame(W, H, k), lambda k: fl, N, CHUNK, W, H, 0, 1,
+                    local_transport(W, H))
     want = single_stream()
     assert [k for k, _ in got] == list(range(N))
     assert [b for _, b in got] == want
@@ -54,11 +55,11 @@ def test_chain_single_process_matches_single_stream():
 
 def test_chain_halo_first_order_matches_single_stream():
     """The halo-then-frames order (vsg_stream_import_halo on a fresh stream) gives the same bytes."""
-    from video_segment_amd.multi_gpu import run_chain
+    from video_segment_amd.multi_gpu import local_transport, run_chain
     fl = synth.const_flow(W, H)
     got = run_chain(lambda: ol.OracleStream(W, H, ol.default_options(chunk_size=CHUNK), has_flow=True),
-                    lambda k: synth.bench_frame(W, H, k), lambda k: fl, N, CHUNK, W, H, 0, 1, None,
-                    overlapped=False)
+                    lambda k: synth.bench_frame(W, H, k), lambda k: fl, N, CHUNK, W, H, 0, 1,
+                    local_transport(W, H), overlapped=False)
     assert [b for _, b in got] == single_stream()
 
 
@@ -72,10 +73,10 @@ def _worker(rank, world, port, outfile):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     fl = synth.const_flow(W, H)
-    tr = DistTransport(torch.device("cpu"))
+    tr = DistTransport(torch.device("cpu"), W, H, to_labels=lambda t: t.cpu().numpy())
     got = run_chain(lambda: ol.OracleStream(W, H, ol.default_options(chunk_size=CHUNK), has_flow=True),
                     lambda k: synth.bench_frame(W, H, k), lambda k: fl, N, CHUNK, W, H, rank, world,
-                    tr, to_engine_labels=lambda t: t.cpu().numpy())
+                    tr)
     with open(outfile, "wb") as f:
         pickle.dump(got, f)
     dist.barrier()

@@ -3,11 +3,13 @@
 * configs[2] (the bench workload): 1920x1080 bench generator + flow, chunk 20, 41 frames = the
   unconstrained first chunk, one steady-state constrained chunk and a flushed tail -- every
   SegmentationDesc byte and the merge statistics of every chunk against the CPU oracle.
-* configs[3] shape: 1920x1080, chunk 32, >= 3 chunks through the chunk chain (run_chain, one
-  device) against the continuous stream, plus the size-independent partition property.
+* configs[3] at full size: 1920x1080, 256 frames, chunk 32 through the chunk chain (run_chain, one
+  device) against the continuous stream (sha256 of all 256 messages), the first two chunks against
+  the oracle, plus the size-independent partition property.
 * configs[0] stand-in: 272x480x120 stream with the source's row stride (width_step 816, SURVEY
   A.7-9) against the oracle.
-* configs[4] over-segmentation half: 3840x2160 two-chunk property run (determinism, partition).
+* configs[4] over-segmentation half at the survey's C5 size: 3840x2160, N = 40, chunk 20 --
+  determinism, partition property, and the first chunk against the oracle.
 """
 import hashlib
 
@@ -90,41 +92,69 @@ def _check_partition(msg, W, H):
     assert (cover == 1).all()
 
 
-def test_config3_shape_chain_vs_stream(vsg):
-    """configs[3] shape on one device: 1080p, chunk 32, 3 full chunks + tail; the chunk chain
-    (what N GPUs run, here world = 1) reproduces the continuous stream byte for byte."""
+def test_config3_full_size_chain_stream_oracle(vsg):
+    """BASELINE configs[3] at full size on one device: 1920x1080 + flow, 256 frames, chunk 32
+    (8 full chunks + the flushed tail).  (a) the chunk chain -- what the 8 GPUs run,
+    here world = 1 with the overlapped order -- reproduces the continuous stream: sha256 of all 256
+    messages; (b) the first two chunks (62 output frames) are byte-identical to the CPU oracle;
+    (c) partition property and chunk fields on decoded frames."""
     import torch
-    from video_segment_amd.multi_gpu import product_halo, run_chain
-    W, H, chunk = 1920, 1080, 32
-    N = 31 * 3 + 6
+    from video_segment_amd.multi_gpu import chunk_plan, local_transport, run_chain
+    W, H, chunk, N = 1920, 1080, 32, 256
+    assert len(chunk_plan(N, chunk)) == 9
+    n_oracle = 63                      # frames 0..62 complete the second chunk (outputs 0..61)
     fl = synth.const_flow(W, H)
-    s = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=True)
-    sha = []
-    for k in range(N):
-        n = s.process_frame(synth.bench_frame(W, H, k), fl if k > 0 else None, flush=(k == N - 1))
-        sha += [hashlib.sha256(s.result_bytes(i)).hexdigest() for i in range(n)]
-    s.close()
-    assert len(sha) == N
+    frames = [synth.bench_frame(W, H, k) for k in range(N)]
+    ol.set_threads(8)
+    try:
+        o = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
+        s = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=True)
+        sha, compared = [], 0
+        for k in range(N):
+            f = fl if k > 0 else None
+            n = s.process_frame(frames[k], f, flush=(k == N - 1))
+            if k < n_oracle:
+                no = o.process_frame(frames[k], f, flush=False)
+                assert n == no, (k, n, no)
+                if n:
+                    assert np.array_equal(s.last_merge_stats(), o.last_merge_stats()), k
+                for i in range(n):
+                    assert s.result_bytes(i) == o.result_bytes(i), "differs from the oracle at %d/%d" % (k, i)
+                compared += n
+            sha += [hashlib.sha256(s.result_bytes(i)).hexdigest() for i in range(n)]
+        s.close()
+        o.close()
+    finally:
+        ol.set_threads(1)
+    assert compared == 62 and len(sha) == N
     dev = torch.device("cuda", 0)
     got = run_chain(
         lambda: vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=True),
-        lambda k: synth.bench_frame(W, H, k), lambda k: fl, N, chunk, W, H, 0, 1, None,
-        from_engine_halo=lambda e: product_halo(e, W, H, dev))
+        lambda k: frames[k], lambda k: fl, N, chunk, W, H, 0, 1,
+        local_transport(W, H, dev))
+    assert [k for k, _ in got] == list(range(N))
     assert [hashlib.sha256(b).hexdigest() for _, b in got] == sha
-    for idx in (0, 40, 95):
+    for idx in (0, 40, 95, 250):
         _check_partition(_decode(got[idx][1]), W, H)
     m = _decode(got[31][1])          # first frame of the second chunk carries its hierarchy
     assert m.chunk_size == 31 and m.hierarchy_frame_idx == 31 and len(m.hierarchy) == 1
+    m = _decode(got[248][1])         # the flushed tail: frames 248..255
+    assert m.hierarchy_frame_idx == 248 and len(m.hierarchy) == 1
 
 
-def test_config4_overseg_3840x2160_properties(vsg):
-    """configs[4], over-segmentation half: 4K + flow, two chunk boundaries; determinism and the
-    partition property (the oracle needs minutes at this size)."""
+def test_config4_overseg_3840x2160_c5(vsg):
+    """BASELINE configs[4], over-segmentation half, at the survey's C5 size: 3840x2160 + flow,
+    N = 40, chunk 20 (the unconstrained chunk, one constrained chunk and the flushed tail).  The
+    first chunk (19 output frames) is byte-identical to the CPU oracle; the whole run is
+    deterministic and every frame checked is a partition with consistent sizes.  (The
+    hierarchical RegionSegmentation on top of it: tests/test_region_segmentation.py.)"""
     import torch
-    W, H, N, chunk = 3840, 2160, 24, 12
+    W, H, N, chunk = 3840, 2160, 40, 20
     dev = torch.device("cuda", 0)
-    fl = torch.from_numpy(synth.const_flow(W, H)).to(dev)
-    frames = [torch.from_numpy(synth.bench_frame(W, H, k)).to(dev) for k in range(N)]
+    fl_h = synth.const_flow(W, H)
+    fl = torch.from_numpy(fl_h).to(dev)
+    frames_h = [synth.bench_frame(W, H, k) for k in range(N)]
+    frames = [torch.from_numpy(f).to(dev) for f in frames_h]
     runs = []
     for _ in range(2):
         s = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=True)
@@ -135,5 +165,19 @@ def test_config4_overseg_3840x2160_properties(vsg):
         s.close()
         runs.append(out)
     assert len(runs[0]) == N and runs[0] == runs[1]
-    _check_partition(_decode(runs[0][0]), W, H)
-    _check_partition(_decode(runs[0][15]), W, H)
+    for idx in (0, 19, 39):
+        _check_partition(_decode(runs[0][idx]), W, H)
+    m = _decode(runs[0][19])
+    assert m.chunk_size == 19 and m.hierarchy_frame_idx == 19 and len(m.hierarchy) == 1
+    ol.set_threads(8)
+    try:
+        o = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
+        want = []
+        for k in range(chunk):
+            n = o.process_frame(frames_h[k], fl_h if k > 0 else None, flush=False)
+            want += [o.result_bytes(i) for i in range(n)]
+        o.close()
+    finally:
+        ol.set_threads(1)
+    assert len(want) == chunk - 1
+    assert runs[0][:chunk - 1] == want

@@ -73,7 +73,7 @@ def test_1080p_bench_properties(vsg):
     """No oracle at this size: determinism, chain == continuous stream, and every output is a
     partition of the frame with consistent sizes."""
     import torch
-    from video_segment_amd.multi_gpu import product_halo, run_chain
+    from video_segment_amd.multi_gpu import local_transport, run_chain
     W, H, N, chunk = 1920, 1080, 41, 20
     _, sha1 = hip_probe(vsg, W, H, N, True, synth.bench_frame, chunk)
     _, sha2 = hip_probe(vsg, W, H, N, True, synth.bench_frame, chunk)
@@ -82,8 +82,8 @@ def test_1080p_bench_properties(vsg):
     dev = torch.device("cuda", 0)
     got = run_chain(
         lambda: vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=True),
-        lambda k: synth.bench_frame(W, H, k), lambda k: fl, N, chunk, W, H, 0, 1, None,
-        from_engine_halo=lambda e: product_halo(e, W, H, dev))
+        lambda k: synth.bench_frame(W, H, k), lambda k: fl, N, chunk, W, H, 0, 1,
+        local_transport(W, H, dev))
     assert [hashlib.sha256(b).hexdigest() for _, b in got] == sha1
     # partition property on a decoded frame of the second chunk
     from test_proto_wire import build_schema

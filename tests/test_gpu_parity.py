@@ -130,6 +130,76 @@ def test_graph_merge_and_readout(vsg, W, H, F, kind, flow):
     assert gg.num_neighbor_links() == og.num_neighbor_links()
 
 
+def assert_region_lists_equal(gg, og, F):
+    """The whole RegionInfoList through the C ABI (vsg_graph_get_regions / _get_intervals) against the
+    oracle's: index, size, constrained id, frame span, sorted neighbour lists, per-frame scan
+    intervals in rasterization order (dense_seg_graph_interface.h:147-158)."""
+    gr, gp, gi = gg.get_regions()
+    orr, op, oi = og.get_regions()
+    assert gr.shape == orr.shape and np.array_equal(gr, orr)
+    assert np.array_equal(gp, op) and np.array_equal(gi, oi)
+    n = len(gr)
+    assert np.array_equal(gr[:, 0], np.arange(n))
+    for i in range(n):   # neighbour lists: sorted, unique, symmetric
+        nb = gi[gp[i]:gp[i + 1]]
+        assert np.all(np.diff(nb) > 0)
+    sym = set()
+    for i in range(n):
+        for j in gi[gp[i]:gp[i + 1]]:
+            sym.add((i, int(j)))
+    assert all((j, i) in sym for (i, j) in sym)
+    for t in range(F):
+        a, b = gg.get_intervals(t), og.get_intervals(t)
+        assert a.shape == b.shape and np.array_equal(a, b), t
+        if len(a):   # consistent with the region table's frame spans
+            spans = gr[a[:, 0]]
+            assert np.all(spans[:, 3] <= t) and np.all(spans[:, 4] >= t)
+
+
+@pytest.mark.parametrize("W,H,F,kind,flow", [(64, 48, 6, "probe", True), (48, 40, 5, "noise", True),
+                                             (96, 64, 4, "smooth", False), (40, 30, 3, "const", False)])
+def test_seam3_region_list_through_c_abi(vsg, W, H, F, kind, flow):
+    gg, og, minsz, flows = build_pair(vsg, W, H, F, kind, flow, seed=11)
+    gg.segment(minsz, False)
+    og.segment(minsz, False)
+    gg.obtain_results(use_flows=flow)
+    og.obtain_results(flows)
+    assert_region_lists_equal(gg, og, F)
+
+
+def test_seam3_region_list_constrained_chunk(vsg):
+    """A second-chunk graph (virtual slice + constrained slice + virtual temporal edges) driven
+    through seam 3 the way DenseSegmentation drives it (dense_segmentation.cpp:291-331): regions
+    carry constrained ids, the virtual slice has no rasterization."""
+    W, H = 64, 48
+    rng = np.random.default_rng(4)
+    labels_v = (np.arange(W * H).reshape(H, W) // (W * 6) * 4 + (np.arange(W)[None, :] // 16)).astype(np.int32)
+    labels_c = np.roll(labels_v, 2, axis=1).astype(np.int32)
+    gg = vsg.DenseSegGraph(W, H, 5)
+    og = ol.OracleGraph(W, H, 5)
+    gg.add_virtual_frame(labels_v)
+    og.add_virtual_frame(labels_v)
+    fl = synth.const_flow(W, H)
+    prev = None
+    for t in range(4):
+        frame = synth.probe_frame(W, H, t)
+        feat = ol.preprocess(frame)
+        gg.add_frame_bgr(frame, constraint_ids=labels_c if t == 0 else None)
+        og.add_frame(feat, labels_c if t == 0 else None)
+        gg.add_temporal(fl, is_virtual=(t == 0))
+        og.add_temporal(feat if t else None, prev, fl, is_virtual=(t == 0))
+        prev = feat
+    gg.segment(30, True)
+    og.segment(30, True)
+    assert np.array_equal(gg.merge_stats(), og.merge_stats())
+    gg.obtain_results(use_flows=True)
+    og.obtain_results([None, fl, fl, fl, fl])
+    assert_region_lists_equal(gg, og, 5)
+    regs, _, _ = gg.get_regions()
+    assert (regs[:, 2] >= 0).any()
+    assert len(gg.get_intervals(0)) == 0   # the virtual slice is never rasterized
+
+
 def run_streams(vsg, W, H, N, kind, flow, chunk, seed=5, frames=None):
     rng = np.random.default_rng(seed)
     go = vsg.default_options(chunk_size=chunk)
@@ -232,14 +302,14 @@ def test_chain_protocol_on_gpu(vsg):
     """Fresh HIP engine per chunk + label-plane halo hand-off == one continuous oracle stream
     (the multi-GPU chain mode, run on one device)."""
     import torch
-    from video_segment_amd.multi_gpu import product_halo, run_chain
+    from video_segment_amd.multi_gpu import local_transport, run_chain
     W, H, N, chunk = 64, 48, 40, 8
     dev = torch.device("cuda", 0)
     fl = synth.const_flow(W, H)
     got = run_chain(
         lambda: vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=True),
-        lambda k: synth.bench_frame(W, H, k), lambda k: fl, N, chunk, W, H, 0, 1, None,
-        from_engine_halo=lambda e: product_halo(e, W, H, dev))
+        lambda k: synth.bench_frame(W, H, k), lambda k: fl, N, chunk, W, H, 0, 1,
+        local_transport(W, H, dev))
     o = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
     want = []
     for k in range(N):

@@ -65,12 +65,14 @@ EXPORTED_SYMBOLS = [
     "vsg_stream_result_bytes", "vsg_stream_result_id_image", "vsg_stream_last_merge_stats",
     "vsg_stream_last_timings", "vsg_stream_last_smoothed", "vsg_stream_export_halo",
     "vsg_stream_import_halo", "vsg_stream_expect_halo", "vsg_stream_restart",
-    "vsg_chain_create", "vsg_chain_destroy", "vsg_chain_send_halo", "vsg_chain_recv_halo",
+    "vsg_chain_create", "vsg_chain_destroy", "vsg_chain_info", "vsg_chain_send_halo",
+    "vsg_chain_recv_halo", "vsg_chain_exchange_halo",
     "vsg_graph_create", "vsg_graph_destroy", "vsg_graph_add_frame_bgr",
     "vsg_graph_add_frame_features", "vsg_graph_add_virtual_frame", "vsg_graph_add_temporal",
     "vsg_graph_finish_building", "vsg_graph_segment_spatially", "vsg_graph_segment", "vsg_graph_obtain_results",
     "vsg_graph_num_frames", "vsg_graph_num_regions", "vsg_graph_num_neighbor_links",
-    "vsg_graph_region_sizes", "vsg_graph_index_image", "vsg_graph_smoothed",
+    "vsg_graph_region_sizes", "vsg_graph_index_image", "vsg_graph_get_regions",
+    "vsg_graph_get_intervals", "vsg_graph_smoothed",
     "vsg_graph_spatial_buckets", "vsg_graph_temporal_buckets", "vsg_graph_node_roots",
     "vsg_graph_merge_stats", "vsg_graph_timings",
 ]
@@ -125,7 +127,9 @@ def lib():
     L.vsg_stream_import_halo.argtypes = [vp, vp, vp, C.c_int, vp]
     L.vsg_stream_expect_halo.argtypes = [vp]
     L.vsg_stream_restart.argtypes = [vp]
-    L.vsg_chain_create.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.vsg_chain_create.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.c_int, C.POINTER(vp)]
+    L.vsg_chain_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.vsg_chain_exchange_halo.argtypes = [vp, vp, C.c_int, vp, C.c_int]
     L.vsg_chain_destroy.argtypes = [vp]
     L.vsg_chain_send_halo.argtypes = [vp, vp, C.c_int]
     L.vsg_chain_recv_halo.argtypes = [vp, vp, C.c_int]
@@ -145,6 +149,9 @@ def lib():
     L.vsg_graph_num_neighbor_links.restype = C.c_int64
     L.vsg_graph_region_sizes.argtypes = [vp, vp, vp]
     L.vsg_graph_index_image.argtypes = [vp, C.c_int, vp]
+    L.vsg_graph_get_regions.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
+                                        C.POINTER(vp)]
+    L.vsg_graph_get_intervals.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.vsg_graph_smoothed.argtypes = [vp, C.c_int, vp]
     L.vsg_graph_spatial_buckets.argtypes = [vp, C.c_int, vp]
     L.vsg_graph_temporal_buckets.argtypes = [vp, C.c_int, vp, vp]

@@ -98,6 +98,10 @@ struct vsg_graph {
   vsg::DevBuf<float> staging_f32;
   vsg::DevBuf<int32_t> staging_ids;
   vsg_timings timings;
+  // backing store of vsg_graph_get_regions / vsg_graph_get_intervals
+  std::vector<vsg_region> out_regions;
+  std::vector<int32_t> out_nbr_ptr, out_nbr_idx;
+  std::vector<vsg_interval> out_intervals;
   ~vsg_graph() {
     if (stream) (void)hipStreamSynchronize(stream);
     g.reset();
@@ -302,12 +306,29 @@ struct vsg_chain {
   int rank = 0, world = 1, device = 0;
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;
-  vsg::DevBuf<int32_t> staging;   // [2 * W*H label planes | 4 int64 scalars as 8 int32]
+  // [2 * W*H label planes | 4 int64 scalars as 8 int32], one buffer per direction
+  vsg::DevBuf<int32_t> send_staging, recv_staging;
 };
+
+namespace {
+
+// What rank 0 publishes for the others: the id of THIS run's communicator.  The nonce is chosen by
+// the caller (the same on every rank of a run, different from earlier runs); a reader that finds
+// a file with another nonce -- left behind by an earlier run, or by a crashed one -- keeps polling
+// instead of joining a communicator nobody else will ever join.
+struct ChainIdFile {
+  char magic[8];
+  uint64_t nonce;
+  ncclUniqueId id;
+};
+const char kChainMagic[8] = {'V', 'S', 'G', 'C', 'H', 'A', 'I', 'N'};
+
+}  // namespace
 
 extern "C" {
 
-int vsg_chain_create(int rank, int world, const char* id_file, int device, vsg_chain** out) {
+int vsg_chain_create(int rank, int world, const char* id_file, uint64_t nonce, int device,
+                     vsg_chain** out) {
   return Guard([&] {
     VSG_REQUIRE(out && id_file && world >= 1 && rank >= 0 && rank < world, VSG_ERR_INVALID,
                 "bad argument");
@@ -317,16 +338,19 @@ int vsg_chain_create(int rank, int world, const char* id_file, int device, vsg_c
     c->world = world;
     c->device = ResolveDevice(device);
     DeviceGuard dg(c->device);
-    // The communicator id travels through a file every rank can read: rank 0 writes it
-    // (temporary name + rename, so that a reader never sees half an id), the others poll.
-    ncclUniqueId id;
+    ChainIdFile rec;
     const std::string path(id_file);
     if (rank == 0) {
-      VSG_NCCL(ncclGetUniqueId(&id));
+      // Whatever an earlier run left under this name goes first; the record appears atomically
+      // (temporary name + rename), so a reader never sees half of it.
+      (void)std::remove(path.c_str());
+      std::memcpy(rec.magic, kChainMagic, sizeof(rec.magic));
+      rec.nonce = nonce;
+      VSG_NCCL(ncclGetUniqueId(&rec.id));
       const std::string tmp = path + ".tmp";
       {
         std::ofstream f(tmp.c_str(), std::ios::binary | std::ios::trunc);
-        f.write(reinterpret_cast<const char*>(&id), sizeof(id));
+        f.write(reinterpret_cast<const char*>(&rec), sizeof(rec));
         VSG_REQUIRE(f.good(), VSG_ERR_INVALID, "cannot write the communicator id file");
       }
       VSG_REQUIRE(std::rename(tmp.c_str(), path.c_str()) == 0, VSG_ERR_INVALID,
@@ -336,14 +360,19 @@ int vsg_chain_create(int rank, int world, const char* id_file, int device, vsg_c
       for (int attempt = 0; attempt < 1200 && !got; ++attempt) {   // up to two minutes
         std::ifstream f(path.c_str(), std::ios::binary);
         if (f.good()) {
-          f.read(reinterpret_cast<char*>(&id), sizeof(id));
-          got = f.gcount() == (std::streamsize)sizeof(id);
+          f.read(reinterpret_cast<char*>(&rec), sizeof(rec));
+          got = f.gcount() == (std::streamsize)sizeof(rec) &&
+                std::memcmp(rec.magic, kChainMagic, sizeof(rec.magic)) == 0 && rec.nonce == nonce;
         }
         if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
       }
-      VSG_REQUIRE(got, VSG_ERR_STATE, "timed out waiting for the communicator id file");
+      VSG_REQUIRE(got, VSG_ERR_STATE,
+                  "timed out waiting for the communicator id file of this run (nonce mismatch or "
+                  "rank 0 never started)");
     }
-    VSG_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
+    VSG_NCCL(ncclCommInitRank(&c->comm, world, rec.id, rank));
+    // ncclCommInitRank is collective: once it has returned here every rank has read the record.
+    if (rank == 0) (void)std::remove(path.c_str());
     VSG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     *out = c.release();
   });
@@ -356,45 +385,89 @@ void vsg_chain_destroy(vsg_chain* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    c->staging.release();
+    c->send_staging.release();
+    c->recv_staging.release();
   });
   delete c;
 }
 
-int vsg_chain_send_halo(vsg_chain* c, vsg_stream* from, int dst) {
+int vsg_chain_info(const vsg_chain* c, int* rank, int* world) {
   return Guard([&] {
-    VSG_REQUIRE(c && from && dst >= 0 && dst < c->world && dst != c->rank, VSG_ERR_INVALID,
-                "bad argument");
+    VSG_REQUIRE(c && rank && world, VSG_ERR_INVALID, "null argument");
     DeviceGuard dg(c->device);
-    const size_t wh = (size_t)from->impl->W() * from->impl->H();
-    const int32_t *virt = nullptr, *cons = nullptr;
-    int64_t scalars[4];
-    from->impl->ExportHalo(&virt, &cons, scalars);
-    c->staging.ensure(2 * wh + 8);
-    VSG_HIP(hipMemcpyAsync(c->staging.get(), virt, wh * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
-    VSG_HIP(hipMemcpyAsync(c->staging.get() + wh, cons, wh * sizeof(int32_t), hipMemcpyDeviceToDevice,
-                           c->stream));
-    VSG_HIP(hipMemcpyAsync(c->staging.get() + 2 * wh, scalars, sizeof(scalars), hipMemcpyHostToDevice,
-                           c->stream));
-    VSG_NCCL(ncclSend(c->staging.get(), 2 * wh + 8, ncclInt32, dst, c->comm, c->stream));
-    VSG_HIP(hipStreamSynchronize(c->stream));
+    VSG_NCCL(ncclCommUserRank(c->comm, rank));
+    VSG_NCCL(ncclCommCount(c->comm, world));
   });
 }
 
-int vsg_chain_recv_halo(vsg_chain* c, vsg_stream* into, int src) {
+int vsg_chain_exchange_halo(vsg_chain* c, vsg_stream* from, int dst, vsg_stream* into, int src) {
   return Guard([&] {
-    VSG_REQUIRE(c && into && src >= 0 && src < c->world && src != c->rank, VSG_ERR_INVALID,
-                "bad argument");
+    VSG_REQUIRE(c && (from || into), VSG_ERR_INVALID, "bad argument");
+    VSG_REQUIRE(!from || (dst >= 0 && dst < c->world), VSG_ERR_INVALID, "destination rank");
+    VSG_REQUIRE(!into || (src >= 0 && src < c->world), VSG_ERR_INVALID, "source rank");
+    // A rank may hand a halo to itself (two handles on one GPU), but only as one exchange: a lone
+    // send to oneself would never find its receive.
+    VSG_REQUIRE(!from || dst != c->rank || (into && src == c->rank), VSG_ERR_INVALID,
+                "a send to the own rank needs the matching receive in the same call");
+    VSG_REQUIRE(!into || src != c->rank || (from && dst == c->rank), VSG_ERR_INVALID,
+                "a receive from the own rank needs the matching send in the same call");
+    VSG_REQUIRE(from != into, VSG_ERR_INVALID, "a stream cannot hand the halo to itself");
+    // The staging buffers, the communicator's stream and the streams' halo planes all have to
+    // live on the chain's device (no peer copies, no ImportHalo on a foreign current device).
+    VSG_REQUIRE(!from || from->device == c->device, VSG_ERR_INVALID,
+                "the sending stream lives on another device than the chain");
+    VSG_REQUIRE(!into || into->device == c->device, VSG_ERR_INVALID,
+                "the receiving stream lives on another device than the chain");
     DeviceGuard dg(c->device);
-    const size_t wh = (size_t)into->impl->W() * into->impl->H();
-    c->staging.ensure(2 * wh + 8);
-    VSG_NCCL(ncclRecv(c->staging.get(), 2 * wh + 8, ncclInt32, src, c->comm, c->stream));
-    int64_t scalars[4];
-    VSG_HIP(hipMemcpyAsync(scalars, c->staging.get() + 2 * wh, sizeof(scalars), hipMemcpyDeviceToHost,
-                           c->stream));
+    size_t wh_send = 0, wh_recv = 0;
+    if (from) {
+      wh_send = (size_t)from->impl->W() * from->impl->H();
+      const int32_t *virt = nullptr, *cons = nullptr;
+      int64_t scalars[4];
+      from->impl->ExportHalo(&virt, &cons, scalars);
+      c->send_staging.ensure(2 * wh_send + 8);
+      int32_t* st = c->send_staging.get();
+      VSG_HIP(hipMemcpyAsync(st, virt, wh_send * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+      VSG_HIP(hipMemcpyAsync(st + wh_send, cons, wh_send * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                             c->stream));
+      VSG_HIP(hipMemcpyAsync(st + 2 * wh_send, scalars, sizeof(scalars), hipMemcpyHostToDevice, c->stream));
+      // `scalars` is a stack buffer: the copy has to be done before it goes out of scope
+      VSG_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (into) {
+      wh_recv = (size_t)into->impl->W() * into->impl->H();
+      c->recv_staging.ensure(2 * wh_recv + 8);
+    }
+    VSG_NCCL(ncclGroupStart());
+    if (from) VSG_NCCL(ncclSend(c->send_staging.get(), 2 * wh_send + 8, ncclInt32, dst, c->comm, c->stream));
+    if (into) VSG_NCCL(ncclRecv(c->recv_staging.get(), 2 * wh_recv + 8, ncclInt32, src, c->comm, c->stream));
+    VSG_NCCL(ncclGroupEnd());
+    int64_t scalars[4] = {0, 0, 0, 0};
+    if (into) {
+      VSG_HIP(hipMemcpyAsync(scalars, c->recv_staging.get() + 2 * wh_recv, sizeof(scalars),
+                             hipMemcpyDeviceToHost, c->stream));
+    }
     VSG_HIP(hipStreamSynchronize(c->stream));
-    into->impl->ImportHalo(c->staging.get(), c->staging.get() + wh, VSG_MEM_DEVICE, scalars);
+    if (into) {
+      into->impl->ImportHalo(c->recv_staging.get(), c->recv_staging.get() + wh_recv, VSG_MEM_DEVICE, scalars);
+    }
   });
+}
+
+int vsg_chain_send_halo(vsg_chain* c, vsg_stream* from, int dst) {
+  if (!from) {
+    g_last_error = "null argument";
+    return VSG_ERR_INVALID;
+  }
+  return vsg_chain_exchange_halo(c, from, dst, nullptr, -1);
+}
+
+int vsg_chain_recv_halo(vsg_chain* c, vsg_stream* into, int src) {
+  if (!into) {
+    g_last_error = "null argument";
+    return VSG_ERR_INVALID;
+  }
+  return vsg_chain_exchange_halo(c, nullptr, -1, into, src);
 }
 
 // ---- graph -------------------------------------------------------------------------------
@@ -612,6 +685,56 @@ int vsg_graph_index_image(const vsg_graph* g, int t, int32_t* out) {
         }
       }
     }
+  });
+}
+
+int vsg_graph_get_regions(vsg_graph* g, const vsg_region** regions, size_t* num_regions,
+                          const int32_t** nbr_csr_ptr, const int32_t** nbr_csr_idx) {
+  return Guard([&] {
+    VSG_REQUIRE(g && regions && num_regions && nbr_csr_ptr && nbr_csr_idx, VSG_ERR_INVALID,
+                "null argument");
+    const auto& regs = g->g->regions();
+    g->out_regions.resize(regs.size());
+    g->out_nbr_ptr.assign(regs.size() + 1, 0);
+    g->out_nbr_idx.clear();
+    for (size_t i = 0; i < regs.size(); ++i) {
+      const vsg::RegionInfo& r = regs[i];
+      VSG_REQUIRE(r.index == (int)i, VSG_ERR_INTERNAL, "region table out of order");
+      vsg_region& o = g->out_regions[i];
+      o.index = r.index;
+      o.size = r.size;
+      o.constrained_id = r.constrained_id;
+      const bool has = r.has_raster && !r.raster.empty();
+      o.first_frame = has ? r.raster.front().frame : -1;
+      o.last_frame = has ? r.raster.back().frame : -1;
+      g->out_nbr_idx.insert(g->out_nbr_idx.end(), r.neighbors.begin(), r.neighbors.end());
+      g->out_nbr_ptr[i + 1] = (int32_t)g->out_nbr_idx.size();
+    }
+    if (g->out_nbr_idx.empty()) g->out_nbr_idx.push_back(0);   // a valid pointer for an empty list
+    *regions = g->out_regions.data();
+    *num_regions = regs.size();
+    *nbr_csr_ptr = g->out_nbr_ptr.data();
+    *nbr_csr_idx = g->out_nbr_idx.data();
+  });
+}
+
+int vsg_graph_get_intervals(vsg_graph* g, int frame, const vsg_interval** intervals, size_t* n) {
+  return Guard([&] {
+    VSG_REQUIRE(g && intervals && n, VSG_ERR_INVALID, "null argument");
+    VSG_REQUIRE(frame >= 0 && frame < g->g->num_frames(), VSG_ERR_INVALID, "slice index");
+    g->out_intervals.clear();
+    for (const vsg::RegionInfo& r : g->g->regions()) {
+      if (!r.has_raster) continue;
+      auto it = std::lower_bound(r.raster.begin(), r.raster.end(), frame,
+                                 [](const vsg::RasterSlice& s, int f) { return s.frame < f; });
+      if (it == r.raster.end() || it->frame != frame) continue;
+      for (const vsg::Interval& iv : it->raster) {
+        g->out_intervals.push_back(vsg_interval{r.index, iv.y, iv.lx, iv.rx});
+      }
+    }
+    *n = g->out_intervals.size();
+    if (g->out_intervals.empty()) g->out_intervals.push_back(vsg_interval{-1, 0, 0, 0});
+    *intervals = g->out_intervals.data();
   });
 }
 

@@ -97,6 +97,12 @@ void DenseGraphHip::Reset(int max_frames) {
   timings_ = GraphTimings();
 }
 
+void DenseGraphHip::ForgetLearned() {
+  spine_limit_bucket_ = 0x7fffffff;
+  spine_limit_age_ = 0;
+  for (int b = 0; b < 2; ++b) spine_low_fails_[b] = spine_low_cooldown_[b] = 0;
+}
+
 void DenseGraphHip::SortList(ListBuf& lb, int per_px) {
   const int n = (int)(per_px * wh_);
   lb.slots.ensure((size_t)n);
@@ -363,6 +369,10 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.spine_min = getenv("VSG_SPINE_MIN") ? atoi(getenv("VSG_SPINE_MIN")) : 4096;
   S.spine_max_edges = getenv("VSG_SPINE_MAX_EDGES") ? atoi(getenv("VSG_SPINE_MAX_EDGES")) : (48 << 20);
   S.spine_off = 0;
+  if (spine_limit_bucket_ != 0x7fffffff && ++spine_limit_age_ > 8) {   // probe again
+    spine_limit_bucket_ = 0x7fffffff;
+    spine_limit_age_ = 0;
+  }
   S.spine_limit_bucket = &spine_limit_bucket_;
   // The first two buckets hold the large components the tree replay is for; on an input where its
   // assumption keeps failing there (two chunks in a row) it is skipped for eight chunks, then

@@ -36,6 +36,9 @@ class DenseGraphHip {
   // Starts a new (empty) graph reusing all device buffers.  max_frames may shrink/grow up to the
   // capacity given at construction.
   void Reset(int max_frames);
+  // Forgets what the handle learned about its input (where the tree replay pays): a handle that
+  // is restarted for another video starts like a fresh one.
+  void ForgetLearned();
 
   // AddNodesAndSpatialEdges[Constrained].  feat: 3 planes of W*H f32 (B,G,R) in device memory,
   // must stay valid until the stream has executed the call.  cons: W*H int32 device or nullptr.
@@ -151,6 +154,8 @@ class DenseGraphHip {
   DevBuf<int32_t> scalars_;   // num_active, num_segs, misc
   DevBuf<int32_t> bucket_prefix_dev_;   // edges in the buckets before b
   int spine_limit_bucket_ = 0x7fffffff;   // learned per stream: where the tree replay stops paying
+  int spine_limit_age_ = 0;               // chunks since it was learned (forgotten after 8: one atypical
+                                          // chunk must not switch the tree replay off for good)
   int spine_low_fails_[2] = {0, 0}, spine_low_cooldown_[2] = {0, 0};   // the same for buckets 0 and 1
   DevBuf<int32_t> spine_pool_;   // scratch of the Kruskal-tree replay (merge_spine.hip)
   DevBuf<unsigned long long> stats_;

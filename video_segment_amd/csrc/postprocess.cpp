@@ -414,9 +414,15 @@ void TubeSplitter::Finish(int W, int H, const float* flow_xy, TubeResult* out) {
   const float inv_diam = (float)(1.0f / std::hypot((double)W, (double)H));
   size_t sample = 0;
 
+  bool first_slice = true;
   for (std::vector<TSlice>& slices : impl_->slices) {
     const int frame = slices.empty() ? -1 : slices[0].frame;
+    // Prepare listed one flow sample per component of every slice after the first, whether or
+    // not the matching reads it: the cursor advances with the slices, not with the decisions.
+    const bool had_requests = !first_slice;
+    first_slice = false;
     if (active.empty()) {
+      if (had_requests) sample += slices.size();
       for (TSlice& s : slices) active.push_back(Tube{std::move(s)});
       continue;
     }

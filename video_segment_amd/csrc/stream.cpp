@@ -526,6 +526,7 @@ void DenseSegmentationHip::Restart() {
   halo_valid_ = false;
   flow_stream_seen_ = false;
   frames_fed_ = 0;
+  graph_->ForgetLearned();
   std::memset(&accum_, 0, sizeof(accum_));
 }
 

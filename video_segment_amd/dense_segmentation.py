@@ -170,11 +170,14 @@ class DenseSegmentation:
 
 
 class ChunkChain:
-    """RCCL hand-off of the chunk halo between the GPUs of a node (vsg_chain_*, include/vsg.h)."""
+    """RCCL hand-off of the chunk halo between the GPUs of a node (vsg_chain_*, include/vsg.h).
 
-    def __init__(self, rank, world, id_file, device=-1):
+    nonce: a value shared by the ranks of this run and not used by earlier runs (see vsg.h)."""
+
+    def __init__(self, rank, world, id_file, nonce=0, device=-1):
         h = C.c_void_p()
-        check(lib().vsg_chain_create(rank, world, id_file.encode(), device, C.byref(h)))
+        check(lib().vsg_chain_create(rank, world, id_file.encode(), C.c_uint64(nonce), device,
+                                     C.byref(h)))
         self.h = h
         self._destroy = lib().vsg_chain_destroy
 
@@ -186,11 +189,21 @@ class ChunkChain:
     def __del__(self):
         self.close()
 
+    def info(self):
+        """(rank, world) as the RCCL communicator reports them."""
+        r, w = C.c_int(), C.c_int()
+        check(lib().vsg_chain_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
     def send_halo(self, stream, dst):
         check(lib().vsg_chain_send_halo(self.h, stream.h, dst))
 
     def recv_halo(self, stream, src):
         check(lib().vsg_chain_recv_halo(self.h, stream.h, src))
+
+    def exchange_halo(self, from_stream, dst, into_stream, src):
+        check(lib().vsg_chain_exchange_halo(self.h, from_stream.h if from_stream else None, dst,
+                                            into_stream.h if into_stream else None, src))
 
 
 class DenseSegGraph:
@@ -279,6 +292,28 @@ class DenseSegGraph:
         out = np.empty((self.H, self.W), np.int32)
         check(lib().vsg_graph_index_image(self.h, t, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def get_regions(self):
+        """The RegionInfoList of ObtainResults + DetermineNeighborIds as arrays: (regions [n,5] =
+        index, size, constrained_id, first frame, last frame; nbr_ptr [n+1]; nbr_idx)."""
+        regs, n = C.c_void_p(), C.c_size_t()
+        ptr, idx = C.c_void_p(), C.c_void_p()
+        check(lib().vsg_graph_get_regions(self.h, C.byref(regs), C.byref(n), C.byref(ptr), C.byref(idx)))
+        n = n.value
+        r = np.ctypeslib.as_array(C.cast(regs, C.POINTER(C.c_int32)), shape=(max(n, 1) * 5,))[:n * 5]
+        r = r.reshape(n, 5).copy()
+        p = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), shape=(n + 1,)).copy()
+        total = int(p[n])
+        i = np.ctypeslib.as_array(C.cast(idx, C.POINTER(C.c_int32)), shape=(max(total, 1),))[:total].copy()
+        return r, p, i
+
+    def get_intervals(self, t):
+        """Scan intervals of slice t: [m,4] = region index, y, left_x, right_x."""
+        iv, m = C.c_void_p(), C.c_size_t()
+        check(lib().vsg_graph_get_intervals(self.h, t, C.byref(iv), C.byref(m)))
+        m = m.value
+        a = np.ctypeslib.as_array(C.cast(iv, C.POINTER(C.c_int32)), shape=(max(m, 1) * 4,))[:m * 4]
+        return a.reshape(m, 4).copy()
 
     def smoothed(self, t):
         out = np.empty((self.H, self.W, 3), np.float32)

@@ -37,46 +37,108 @@ def chunk_plan(num_frames, chunk):
 
 
 class DistTransport:
-    """torch.distributed point-to-point transport (backend nccl = RCCL on GPUs, gloo on CPU)."""
+    """torch.distributed point-to-point transport (backend nccl = RCCL on GPUs, gloo on CPU).
 
-    def __init__(self, device):
+    halo_of(engine) -> (labels_virtual, labels_constrained, scalars): what is sent (default:
+    engine.export_halo(), host arrays -- the oracle engine of the CPU tests; for the product engine
+    pass lambda e: product_halo(e, W, H, dev)).  to_labels(x): converts a received plane to what
+    engine.import_halo accepts."""
+    name = "torch.distributed send/recv"
+
+    def __init__(self, device, width, height, halo_of=None, to_labels=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.device = torch, dist, device
+        self.W, self.H = width, height
+        self.halo_of, self.to_labels = halo_of, to_labels
+        self._local = None
 
-    def send(self, dst, tag, arrays):
-        for a in arrays:
+    def _halo(self, engine):
+        halo = self.halo_of(engine) if self.halo_of is not None else engine.export_halo()
+        if isinstance(halo[0], int):
+            # DenseSegmentation.export_halo() hands out library-owned device pointers that die
+            # with the engine's next chunk: they have to be copied first (product_halo does).
+            raise TypeError("product engine: pass halo_of=lambda e: product_halo(e, W, H, dev)")
+        return halo
+
+    def send_halo(self, engine, dst, rank):
+        halo = self._halo(engine)
+        if dst == rank:
+            self._local = halo
+            return
+        for a in halo:
             t = a if self.torch.is_tensor(a) else self.torch.from_numpy(np.ascontiguousarray(a))
             self.dist.send(t.to(self.device).contiguous(), dst=dst)
 
-    def recv(self, src, tag, shapes_dtypes):
-        out = []
-        for shape, dtype in shapes_dtypes:
-            t = self.torch.empty(shape, dtype=dtype, device=self.device)
-            self.dist.recv(t, src=src)
-            out.append(t)
-        return out
+    def recv_halo(self, engine, src, rank):
+        torch = self.torch
+        if src == rank:
+            virt, cons, scal = self._local
+        else:
+            out = []
+            for shape, dtype in (((self.H, self.W), torch.int32), ((self.H, self.W), torch.int32),
+                                 ((4,), torch.int64)):
+                t = torch.empty(shape, dtype=dtype, device=self.device)
+                self.dist.recv(t, src=src)
+                out.append(t)
+            virt, cons, scal = out
+        if self.to_labels is not None:
+            virt, cons = self.to_labels(virt), self.to_labels(cons)
+        scal_np = scal.cpu().numpy() if torch.is_tensor(scal) else np.asarray(scal)
+        engine.import_halo(virt, cons, scal_np)
+
+
+class ChainTransport:
+    """The hand-off inside the library: vsg_chain_send_halo / vsg_chain_recv_halo (ncclSend /
+    ncclRecv on the chain's own stream, include/vsg.h) -- what a C++ host uses; product engine
+    only.  A rank that owns two consecutive chunks (world == 1, or the tail) keeps a copy of the
+    halo planes on its device and imports it without a transfer."""
+    name = "vsg_chain (ncclSend / ncclRecv inside libvsg_hip)"
+
+    def __init__(self, chain, width, height, device):
+        self.chain, self.W, self.H, self.device = chain, width, height, device
+        self._local = None
+
+    def send_halo(self, engine, dst, rank):
+        if dst == rank:
+            self._local = product_halo(engine, self.W, self.H, self.device)
+        else:
+            self.chain.send_halo(engine, dst)
+
+    def recv_halo(self, engine, src, rank):
+        if src == rank:
+            virt, cons, scal = self._local
+            engine.import_halo(virt, cons, scal.cpu().numpy())
+        else:
+            self.chain.recv_halo(engine, src)
+
+
+def local_transport(width, height, device=None):
+    """Transport of a single process (world 1): the halo stays on the rank.  device: a torch cuda
+    device for the product engine (its library-owned planes are copied), None for host engines."""
+    if device is None:
+        return DistTransport(None, width, height)
+    return DistTransport(device, width, height,
+                         halo_of=lambda e: product_halo(e, width, height, device))
 
 
 def run_chain(engine_factory, get_frame, get_flow, num_frames, chunk, width, height, rank, world,
-              transport, to_engine_labels=None, from_engine_halo=None, overlapped=True):
+              transport, overlapped=True):
     """Segments the chunks owned by `rank` and returns [(frame_index, SegmentationDesc bytes)].
 
     engine_factory(): the rank's engine (has_flow must match get_flow); ONE engine serves all the
     rank's chunks (engine.restart() between them).
     get_frame(k), get_flow(k): inputs of global frame k in the engine's memory kind (flow(0) unused).
-    to_engine_labels(x): converts a received label plane to what engine.import_halo accepts.
-    from_engine_halo(engine): returns (labels_virtual, labels_constrained, scalars) ready to send.
+    transport: DistTransport or ChainTransport (send_halo(engine, dst, rank) / recv_halo(engine,
+    src, rank)).
     overlapped: the SURVEY 8(e) order -- the rank feeds the frames of its chunk first (features,
     edges and the bucket sort do not depend on the previous chunk: all ranks build concurrently)
     and only then blocks in the receive of the halo, right before the frame that completes the
     chunk.  False: receive first (the halo-then-frames order of vsg_stream_import_halo).
     """
-    import torch
     plan = chunk_plan(num_frames, chunk)
     out = []
     eng = None
-    pending_local = None
     for c, (first, last) in enumerate(plan):
         if c % world != rank:
             continue
@@ -84,29 +146,16 @@ def run_chain(engine_factory, get_frame, get_flow, num_frames, chunk, width, hei
             eng = engine_factory()
         else:
             eng.restart()
-
-        def take_halo():
-            src = (c - 1) % world
-            if src == rank:
-                virt, cons, scal = pending_local
-            else:
-                virt, cons, scal = transport.recv(
-                    src, c, [((height, width), torch.int32), ((height, width), torch.int32),
-                             ((4,), torch.int64)])
-            if to_engine_labels is not None:
-                virt, cons = to_engine_labels(virt), to_engine_labels(cons)
-            scal_np = scal.cpu().numpy() if torch.is_tensor(scal) else np.asarray(scal)
-            eng.import_halo(virt, cons, scal_np)
-
         if c > 0:
             if overlapped:
                 eng.expect_halo()
             else:
-                take_halo()
+                transport.recv_halo(eng, (c - 1) % world, rank)
         next_frame_out = None
         for k in range(first, last + 1):
             if c > 0 and overlapped and k == last:
-                take_halo()   # the merge needs the labels; everything before it did not
+                # the merge needs the labels; everything before it did not
+                transport.recv_halo(eng, (c - 1) % world, rank)
             flush = (k == num_frames - 1)
             flow = get_flow(k) if (get_flow is not None and k > 0) else None
             n = eng.process_frame(get_frame(k), flow, flush=flush)
@@ -117,29 +166,33 @@ def run_chain(engine_factory, get_frame, get_flow, num_frames, chunk, width, hei
                     out.append((base + i, eng.result_bytes(i)))
                 next_frame_out = base + n
         if c + 1 < len(plan):
-            halo = from_engine_halo(eng) if from_engine_halo is not None else eng.export_halo()
-            if isinstance(halo[0], int):
-                # DenseSegmentation.export_halo() hands out library-owned device pointers that die
-                # with the engine's next chunk: they have to be copied first (product_halo does).
-                raise TypeError("product engine: pass from_engine_halo=lambda e: product_halo(e, W, H, dev)")
-            dst = (c + 1) % world
-            if dst == rank:
-                pending_local = halo
-            else:
-                transport.send(dst, c + 1, list(halo))
+            transport.send_halo(eng, (c + 1) % world, rank)
     if eng is not None:
         eng.close()
     return out
 
 
+def chain_nonce():
+    """A nonce the ranks of one launch share (see vsg_chain_create): from the launcher's
+    environment, which torchrun gives every rank of a run and changes between runs."""
+    import hashlib
+    import os
+    key = "|".join(os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT",
+                                                    "VSG_CHAIN_NONCE"))
+    return int.from_bytes(hashlib.sha256(key.encode()).digest()[:8], "little")
+
+
 def run_chain_bench(args, rank, world, local_rank):
-    """bench.py --mode chain: one long video sharded chunk-wise over the ranks (RCCL hand-off).
+    """bench.py --mode chain: one long video sharded chunk-wise over the ranks; the halo travels
+    through the library's own RCCL hand-off (vsg_chain_send_halo / vsg_chain_recv_halo).
 
     The chain is a pipeline (rank r cannot start chunk c before rank r-1 has finished chunk c-1),
     so a barrier in the middle of a video would deadlock against the blocking hand-off.  Warm-up
     and measurement are therefore two separate videos: `warmup` chunks per rank, barrier, then
     `steps` chunks per rank timed between two barriers (weak scaling: the video grows with the
     number of ranks)."""
+    import os
+    import tempfile
     import time
     import torch
     import torch.distributed as dist
@@ -150,7 +203,19 @@ def run_chain_bench(args, rank, world, local_rank):
     K, Wm = args.steps, args.warmup
     dev = torch.device("cuda", local_rank)
     flow = torch.from_numpy(synth.const_flow(W, H)).to(dev)
-    transport = DistTransport(dev)
+    # every rank of the launch derives the same path and nonce from the launcher's environment
+    chain = None
+    if args.dist_backend == "nccl" and not args.share_gpu:
+        nonce = chain_nonce()
+        id_file = os.path.join(tempfile.gettempdir(), "vsg_chain_%016x.id" % nonce)
+        chain = vsg.ChunkChain(rank, world, id_file, nonce=nonce, device=local_rank)
+        rccl_rank, rccl_world = chain.info()
+        assert (rccl_rank, rccl_world) == (rank, world), (rccl_rank, rccl_world, rank, world)
+        transport = ChainTransport(chain, W, H, dev)
+    else:
+        # testing only (--share-gpu / gloo: RCCL refuses two ranks on one device)
+        rccl_world = 0
+        transport = DistTransport(dev, W, H, halo_of=lambda e: product_halo(e, W, H, dev))
     acc = {"wave_ms": 0.0, "wave_launches": 0, "wave_edges": 0, "spine_ms": 0.0, "spine_launches": 0,
            "spine_edges": 0, "merge_ms": 0.0, "pre_ms": 0.0,
            "edges_ms": 0.0, "readout_ms": 0.0, "host_ms": 0.0, "filter_ms": 0.0,
@@ -181,10 +246,7 @@ def run_chain_bench(args, rank, world, local_rank):
                 eng.expect_halo()   # build first, receive the labels right before the merge
             for k in range(first, last + 1):
                 if c > 0 and k == last:
-                    virt, cons, scal = transport.recv((c - 1) % world, c,
-                                                      [((H, W), torch.int32), ((H, W), torch.int32),
-                                                       ((4,), torch.int64)])
-                    eng.import_halo(virt, cons, scal.cpu().numpy())
+                    transport.recv_halo(eng, (c - 1) % world, rank)
                 n = eng.process_frame(frames[k], flow if k > 0 else None, flush=(k == num_frames - 1))
                 if n:
                     fetched = sum(len(eng.result_bytes(i)) for i in range(n))   # consumer side
@@ -208,31 +270,38 @@ def run_chain_bench(args, rank, world, local_rank):
                     acc["edges_total"] += t.edges_total
                     acc["merges"] += t.merges
             if c + 1 < len(plan):
-                ta, tb, scal = product_halo(eng, W, H, dev)
-                transport.send((c + 1) % world, c + 1, [ta, tb, scal.to(dev)])
+                transport.send_halo(eng, (c + 1) % world, rank)
         return frames_out
 
     warm = load(Wm * world) if Wm > 0 else None
     timed = load(K * world)
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
     if warm is not None:
         run_video(warm, False)
-    torch.cuda.synchronize()
-    dist.barrier()
+    barrier()
     t0 = time.perf_counter()
     frames_out = run_video(timed, True)
-    torch.cuda.synchronize()
-    dist.barrier()
+    barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     fo = torch.tensor([frames_out], dtype=torch.float64, device=dev)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dist.all_reduce(fo, op=dist.ReduceOp.SUM)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(fo, op=dist.ReduceOp.SUM)
     engine.close()
+    if chain is not None:
+        chain.close()
     return {"dt": float(tt.item()), "frames": float(fo.item()), "acc": acc,
+            "handoff": {"transport": transport.name, "rccl_ranks": rccl_world},
             "parallelism": "chain: ONE video, chunks round-robin over %d GPUs, every rank builds its "
                            "chunk graph before it blocks in the receive of the label-plane halo "
-                           "(send/recv over the process group: RCCL on GPUs); a pipeline, not "
-                           "data parallel" % world}
+                           "(vsg_chain_send_halo / vsg_chain_recv_halo: ncclSend / ncclRecv inside "
+                           "the library; the RCCL communicator reports %d ranks); a pipeline, not "
+                           "data parallel" % (world, rccl_world)}
 
 
 def _wrap_device_int32(ptr, n, dev):
