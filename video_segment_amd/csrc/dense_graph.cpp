@@ -199,7 +199,10 @@ void DenseGraphHip::EnsureScratch(size_t n) {
   seg_key_.alloc(n);
   seg_cnt_.alloc(n);
   seg_off_.alloc(n);
-  e_ti_.alloc(n);
+  // three mask words per 64 edges (rounded up to whole workgroups of 256 edges)
+  filter_masks_.alloc(3 * (4 * ((n + 255) / 256) + 4));
+  block_cnt_.alloc((n + 255) / 256 + 2);
+  block_off_.alloc((n + 255) / 256 + 2);
   lead_pos_.alloc(n);
   l_ra_.alloc(n);
   l_rb_.alloc(n);
@@ -360,7 +363,14 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.seg_off = seg_off_.get();
   S.num_active = scalars_.get();
   S.num_segs = scalars_.get() + 1;
-  S.e_ti = e_ti_.get();
+  {
+    const size_t words = 4 * ((scratch_edges_ + 255) / 256) + 4;
+    S.masks.active = filter_masks_.get();
+    S.masks.settled = filter_masks_.get() + words;
+    S.masks.tentative = filter_masks_.get() + 2 * words;
+    S.masks.block_cnt = block_cnt_.get();
+    S.block_off = block_off_.get();
+  }
   S.bk_ds = bk_ds_.get();
   S.bk_cons = bk_cons_.get();
   S.bk_flags = bk_flags_.get();
@@ -647,51 +657,54 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
   }
   if (cursor < N) nvranges.emplace_back(cursor, N);
 
-  // scratch: label_uf_ = flags, label_img_ = roots, adjust_ = offsets (all N ints)
+  // scratch: label_uf_ = flags, label_img_ = values, adjust_ = offsets (all N ints)
   int32_t* d_flags = label_uf_.get();
-  int32_t* d_roots = label_img_.get();
+  int32_t* d_vals = label_img_.get();
   int32_t* d_offs = adjust_.get();
-  // Flagged nodes (own constraint >= 0) with their representative, in node order.
-  auto collect = [&](int begin, int end, std::vector<int32_t>* node_ids,
-                     std::vector<int32_t>* node_roots) {
+  // Run heads (readout_kernels.hip: LaunchConstrainedRuns) of a node range, in node order:
+  // (first node, value) with value = representative / -2 unconstrained representative / -1
+  // terminator; a run ends where the next entry starts.
+  struct Runs {
+    std::vector<int32_t> node, value;
+  };
+  auto collect = [&](int begin, int end, Runs* out) {
     const int n = end - begin;
     if (n <= 0) return;
-    LaunchConstrainedRoots(nodes(), begin, end, d_flags, d_roots, stream_);
+    LaunchConstrainedRuns(nodes(), begin, end, d_vals, d_flags, stream_);
     ExclusiveSumI32(cub_temp_.get(), cub_temp_.size(), d_flags, d_offs, n, stream_);
     int last_off = 0, last_flag = 0;
     D2H(&last_off, d_offs + (n - 1), 1, stream_);
     D2H(&last_flag, d_flags + (n - 1), 1, stream_);
     VSG_HIP(hipStreamSynchronize(stream_));
     const int k = last_off + last_flag;
-    if (k == 0) return;
-    EnsureScratch((size_t)k);
-    LaunchCompactIndexValue(d_flags, d_offs, d_roots, n, a_ra_.get(), a_rb_.get(), stream_);
-    const size_t old = node_ids->size();
-    node_ids->resize(old + k);
-    node_roots->resize(old + k);
-    D2H(node_ids->data() + old, a_ra_.get(), (size_t)k, stream_);
-    D2H(node_roots->data() + old, a_rb_.get(), (size_t)k, stream_);
-    VSG_HIP(hipStreamSynchronize(stream_));
-    for (size_t i = old; i < old + (size_t)k; ++i) (*node_ids)[i] += begin;
+    const size_t old = out->node.size();
+    if (k > 0) {
+      EnsureScratch((size_t)k);
+      LaunchCompactIndexValue(d_flags, d_offs, d_vals, n, a_ra_.get(), a_rb_.get(), stream_);
+      out->node.resize(old + k);
+      out->value.resize(old + k);
+      D2H(out->node.data() + old, a_ra_.get(), (size_t)k, stream_);
+      D2H(out->value.data() + old, a_rb_.get(), (size_t)k, stream_);
+      VSG_HIP(hipStreamSynchronize(stream_));
+      for (size_t i = old; i < old + (size_t)k; ++i) out->node[i] += begin;
+    }
+    out->node.push_back(end);     // terminator of the range
+    out->value.push_back(-1);
   };
 
   const double tm0 = NowMs();
-  std::vector<int32_t> nv_nodes, nv_roots, v_nodes, v_roots;
-  for (auto& r : nvranges) collect(r.first, r.second, &nv_nodes, &nv_roots);
-  for (auto& r : vranges) collect(r.first, r.second, &v_nodes, &v_roots);
+  Runs nv, vr;
+  for (auto& r : nvranges) collect(r.first, r.second, &nv);
+  for (auto& r : vranges) collect(r.first, r.second, &vr);
   const double tm1 = NowMs();
 
-  // Distinct representatives and their states.
+  // Distinct representatives of the nodes whose own constraint is >= 0, and their states.
   std::vector<int32_t> ids;
   {
-    // Millions of flagged nodes, a few dozen representatives, long runs of equal values.
     std::unordered_set<int32_t> seen;
-    int32_t last = -1;
-    for (const std::vector<int32_t>* v : {&nv_roots, &v_roots}) {
-      for (int32_t r : *v) {
-        if (r == last) continue;
-        last = r;
-        if (seen.insert(r).second) ids.push_back(r);
+    for (const Runs* v : {&nv, &vr}) {
+      for (int32_t r : v->value) {
+        if (r >= 0 && seen.insert(r).second) ids.push_back(r);
       }
     }
     std::sort(ids.begin(), ids.end());
@@ -799,80 +812,55 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
     merge(my, crep);
     return true;
   };
-
-  // Non-virtual pass.  Visit order = node id order.  A node that is (or was) a representative
-  // is tested with its *current* own constraint field (it changes when the region is
-  // unconstrained or inherits a constraint through a merge); other nodes keep the value they had
-  // before the pass (>= 0 for every listed node).  Representatives whose own field was < 0 before
-  // the pass are not in the flagged list and are visited through `extra`.
-  std::vector<int32_t> extra;
-  {
-    std::vector<std::pair<int, int>> nvr = nvranges;
-    for (int id : ids) {
-      const SimRegion& r = sim.at(id);
-      if (r.cons >= 0) continue;
-      for (auto& rg : nvr) {
-        if (id >= rg.first && id < rg.second) {
-          extra.push_back(id);
-          break;
-        }
-      }
+  auto visit_virtual = [&](int r0) -> bool {   // never reset, always merge
+    const int my = find(r0);
+    SimRegion& me = sim.at(my);
+    auto pos = c2r.find(me.cons);
+    if (pos == c2r.end()) {
+      c2r.emplace(me.cons, my);
+      return true;
     }
-  }   // ids is sorted, so extra is sorted
-  {
-    size_t ia = 0, ib = 0, ip = 0;   // ip: moving pointer into the sorted representative ids
-    int noop_root = -1;   // representative whose plain member visits are currently no-ops
-    while (ia < nv_nodes.size() || ib < extra.size()) {
-      int node, r0;
-      if (ib >= extra.size() || (ia < nv_nodes.size() && nv_nodes[ia] < extra[ib])) {
-        node = nv_nodes[ia];
-        r0 = nv_roots[ia];
-        ++ia;
-      } else {
-        node = extra[ib];
-        r0 = node;
-        ++ib;
-      }
-      while (ip < ids.size() && ids[ip] < node) ++ip;
-      const bool is_rep = ip < ids.size() && ids[ip] == node;
-      if (is_rep) {
-        if (sim.at(node).cons < 0) continue;   // region->constraint_id < 0
-      } else if (r0 == noop_root) {
-        continue;   // same state, same input as the previous no-op visit
-      }
-      const bool changed = visit_nonvirtual(r0);
-      noop_root = changed ? -1 : r0;
+    const int crep = find(pos->second);
+    if (crep == my) return false;
+    merge(my, crep);
+    return true;
+  };
+
+  // Non-virtual pass, visit order = node id order.  A node that is (or was) a representative is
+  // tested with its *current* own constraint field (it changes when the region is unconstrained
+  // or inherits a constraint through a merge); other nodes keep the value they had before the
+  // pass (>= 0 for every node of a plain run).  A run is visited node by node until a visit
+  // changes nothing: the nodes after that repeat the same no-op.
+  for (size_t k = 0; k + 1 < nv.node.size(); ++k) {
+    const int node = nv.node[k], v = nv.value[k];
+    if (v == -1) continue;
+    const bool is_rep = v == -2 || v == node;
+    if (is_rep) {
+      auto it = sim.find(node);
+      if (it == sim.end() || it->second.cons < 0) continue;   // region->constraint_id < 0
+      visit_nonvirtual(node);
+      continue;
+    }
+    const int len = nv.node[k + 1] - node;
+    for (int i = 0; i < len; ++i) {
+      if (!visit_nonvirtual(v)) break;
     }
   }
-  // Virtual pass: never reset, always merge.
-  {
-    int noop_root = -1;
-    for (size_t k = 0; k < v_nodes.size(); ++k) {
-      const int r0 = v_roots[k];
-      if (r0 == noop_root) continue;
-      const int my = find(r0);
-      SimRegion& me = sim.at(my);
-      auto pos = c2r.find(me.cons);
-      bool changed = true;
-      if (pos == c2r.end()) {
-        c2r.emplace(me.cons, my);
-      } else {
-        const int crep = find(pos->second);
-        if (crep == my) {
-          changed = false;
-        } else {
-          merge(my, crep);
-        }
-      }
-      noop_root = changed ? -1 : r0;
+  // Virtual pass.
+  for (size_t k = 0; k + 1 < vr.node.size(); ++k) {
+    const int node = vr.node[k], v = vr.value[k];
+    if (v < 0) continue;   // terminator / a representative whose own field is < 0 is not listed
+    const int len = (v == node) ? 1 : vr.node[k + 1] - node;
+    for (int i = 0; i < len; ++i) {
+      if (!visit_virtual(v)) break;
     }
   }
 
   // Write back.
   const double tm3 = NowMs();
   if (getenv("VSG_DEBUG_STATS")) {
-    std::fprintf(stderr, "[vsg] merge-constrained: collect %.1f ms (%zu + %zu flagged nodes), states %.1f ms "
-                 "(%d representatives), replay %.1f ms\n", tm1 - tm0, nv_nodes.size(), v_nodes.size(),
+    std::fprintf(stderr, "[vsg] merge-constrained: collect %.1f ms (%zu + %zu runs), states %.1f ms "
+                 "(%d representatives), replay %.1f ms\n", tm1 - tm0, nv.node.size(), vr.node.size(),
                  tm2 - tm1, m, tm3 - tm2);
   }
   std::vector<int32_t> u_ids, u_parent, u_cons, u_flags;

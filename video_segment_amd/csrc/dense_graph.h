@@ -147,7 +147,9 @@ class DenseGraphHip {
   DevBuf<int32_t> e_ra_, e_rb_, e_active_, e_apos_, a_ra_, a_rb_, seg_cnt_, seg_off_;
   DevBuf<int32_t> lead_pos_, l_ra_, l_rb_;
   DevBuf<uint32_t> e_gpos_, a_gpos_, a_comp_, a_idx_, s_comp_, s_idx_, seg_key_, l_gpos_;
-  DevBuf<uint8_t> e_ti_, bk_flags_;
+  DevBuf<uint8_t> bk_flags_;
+  DevBuf<unsigned long long> filter_masks_;   // k_filter's verdict: 3 x one bit per edge
+  DevBuf<int32_t> block_cnt_, block_off_;
   DevBuf<float4> bk_ds_;
   DevBuf<int32_t> bk_cons_;
   int64_t optimistic_stages_ = 0, rollbacks_ = 0;

@@ -106,13 +106,23 @@ void UniqueU64(void* temp, size_t temp_bytes, const unsigned long long* in,
                int32_t* num_out, int n, hipStream_t s);
 
 // ---- merge_stage.hip (workers: merge_wave.hip, merge_wave_v1.hip) ----------------------------------------------------------------
+// What k_filter found, three bits per edge of the stage: one 64-bit word per wavefront (64
+// consecutive edges) and class, and the number of active edges per workgroup of 256 edges.
+struct FilterMasks {
+  unsigned long long* active;      // the edge goes to a worker
+  unsigned long long* settled;     // kept by the filter (inert)
+  unsigned long long* tentative;   // settled under an assumption (inert_mode 2)
+  int32_t* block_cnt;
+};
 struct MergeScratch {
   // sized for the largest bucket (n_max edges)
   int32_t* e_ra;         // root of node a at filter time (per bucket edge)
   int32_t* e_rb;
   uint32_t* e_gpos;      // global kept position (list_slot_base[l] + pos)
-  int32_t* e_active;     // 0/1
-  int32_t* e_apos;       // exclusive scan of e_active
+  int32_t* e_active;     // scratch (run-leader flags)
+  int32_t* e_apos;       // scratch (kept positions in component order)
+  FilterMasks masks;     // the filter's verdict per edge
+  int32_t* block_off;    // exclusive scan of masks.block_cnt
   int32_t* a_ra;         // compacted active edges (bucket order)
   int32_t* a_rb;
   uint32_t* a_gpos;
@@ -125,7 +135,6 @@ struct MergeScratch {
   int32_t* seg_off;
   int32_t* num_active;   // device scalars: [0] num_active [1] num_segs [2] num_ti [3] violation [5] num_leaders
   int32_t* num_segs;     // = num_active + 1
-  uint8_t* e_ti;         // per bucket edge: tentatively settled by the filter
   float4* bk_ds;         // undo buffers of an optimistic stage (2 entries per active edge)
   int32_t* bk_cons;
   uint8_t* bk_flags;
@@ -229,6 +238,11 @@ void LaunchScatterStates(NodeArrays nodes, const int32_t* ids, int n, const int3
 // Nodes with own constraint >= 0 in [begin, end): flag array for compaction + their roots.
 void LaunchConstrainedRoots(NodeArrays nodes, int begin, int end, int32_t* flag_out,
                             int32_t* root_out, hipStream_t s);
+// The same walk reduced to runs of equal representatives (see readout_kernels.hip): value_out[j] =
+// representative of node begin + j, -2 for an unconstrained representative, -1 for a node that
+// does not matter; flag_out[j] = the node starts a run (or terminates the one before it).
+void LaunchConstrainedRuns(NodeArrays nodes, int begin, int end, int32_t* value_out,
+                           int32_t* flag_out, hipStream_t s);
 void LaunchCompactI32(const int32_t* flags, const int32_t* offsets, const int32_t* values, int n,
                       int32_t* out, hipStream_t s);
 void LaunchGatherI32(const int32_t* src, const int32_t* idx, int n, int32_t* out, hipStream_t s);

@@ -317,7 +317,17 @@ struct WorkerArgs {
   unsigned long long* stats;
   int wave_min;             // the wave worker takes components of more than wave_min and less than
   int wave_max;             // wave_max edges (k_merge_small: up to kSmallSegment, when wave_min is that)
+  // Work list of the wave worker (null: every workgroup strides over all segments).  k_merge_small
+  // visits every segment anyway and files the ones the wave worker will replay into three size
+  // classes (kWaveClasses: largest first); the wave worker's workgroups then draw tickets, so the
+  // long components start first and nobody strides over a hundred thousand small segments.
+  uint32_t* work_list;      // [kWaveClasses][work_cap] segment indices
+  int work_cap;
+  int32_t* work_ctl;        // [kWaveClasses] counts, [kWaveClasses] ticket -- zeroed before k_merge_small
 };
+constexpr int kWaveClasses = 3;
+constexpr int kWaveClassMin1 = 192;    // class 1: at least this many edges
+constexpr int kWaveClassMin0 = 1536;   // class 0: at least this many edges
 // Edge-by-edge replay by one wavefront (round 1a; debug reference, VSG_WAVE_V1).
 void LaunchMergeWaveV1(int grid, const WorkerArgs& a, hipStream_t s);
 // Round-based replay by one consumer wavefront + one reader wavefront (the default).

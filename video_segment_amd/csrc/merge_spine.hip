@@ -1090,6 +1090,9 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
     w2.s_rb = o_rb;
     w2.s_gpos = o_gpos;
     w2.T.side = 1;
+    w2.work_cap = n_side / (kSmallSegment + 1) + 1;
+    w2.work_list = (size_t)kWaveClasses * w2.work_cap <= ns ? seg_key : nullptr;
+    w2.work_ctl = scalars + 8;
     // A large side cluster is a component like any other: one level down.
     SpineInput nested;
     int32_t* d_list = pool.take(kSpineListInts);
@@ -1118,6 +1121,7 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
         WorkerArgs w3 = w2;   // no room: the wave worker replays them
         w3.wave_min = w2.wave_max - 1;
         w3.wave_max = 0x7fffffff;
+        w3.work_list = nullptr;
         run_workers(w3, n_side, s);
       }
       if (fork) VSG_HIP(hipStreamWaitEvent(s, (*S.ev_pool)[ej], 0));

@@ -90,11 +90,11 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
                                                  int32_t* __restrict__ e_ra,
                                                  int32_t* __restrict__ e_rb,
                                                  uint32_t* __restrict__ e_gpos,
-                                                 int32_t* __restrict__ e_active,
-                                                 uint8_t* __restrict__ e_ti,
+                                                 FilterMasks M,
                                                  int32_t* __restrict__ num_ti) {
+  __shared__ int wave_cnt[4];
   const int j = blockIdx.x * 256 + threadIdx.x;   // index inside the stage's window
-  int ti = 0;
+  int ti = 0, active = 0, settled = 0;
   if (j < n_b) {
     int bk = bucket;
     int jb = j0 + j;                               // index inside the bucket
@@ -117,7 +117,6 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
     const int ra = FindCompress(nodes.parent, a);
     const int rb = FindCompress(nodes.parent, b);
     const uint32_t gpos = list_slot_base[l] + (uint32_t)pos;
-    int active = 0, settled = 0;
     const bool gone = P.spatial_survivors && L.type == 0 && !P.spatial_survivors[gpos];
     if (ra != rb && !gone) {
       bool inert = false;
@@ -161,21 +160,35 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
       e_rb[j] = rb;
       e_gpos[j] = gpos;
     }
-    e_active[j] = active;
-    e_ti[j] = (uint8_t)(ti ? 1 : (settled ? 2 : (active ? 3 : 0)));   // 1 tentatively settled, 2 settled for good, 3 active
   }
-  const unsigned long long m = __ballot(ti != 0);
-  if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(num_ti, (int)__popcll(m));
+  // What the edge turned out to be is three bits per edge, one 64-bit word per wavefront and
+  // class (a dense flag + code array per edge was 5 of the 17 bytes this kernel wrote per edge,
+  // with 2 % of the edges active), plus the number of active edges per workgroup for the ordered
+  // compaction (k_compact_active).
+  const unsigned long long ma = __ballot(active != 0);
+  const unsigned long long ms = __ballot(settled != 0);
+  const unsigned long long mt = __ballot(ti != 0);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    const size_t gw = (size_t)blockIdx.x * 4 + w;
+    M.active[gw] = ma;
+    M.settled[gw] = ms;
+    M.tentative[gw] = mt;
+    wave_cnt[w] = (int)__popcll(ma);
+    if (mt != 0) atomicAdd(num_ti, (int)__popcll(mt));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) M.block_cnt[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
 // Clears the tentative marks of a stage: on the regions marked by the filter and on whatever
 // region they have been merged into since.
-__global__ __launch_bounds__(256) void k_clear_tentative(int n_b, const uint8_t* __restrict__ e_ti,
+__global__ __launch_bounds__(256) void k_clear_tentative(int n_b, const unsigned long long* __restrict__ m_ti,
                                                           const int32_t* __restrict__ e_ra,
                                                           const int32_t* __restrict__ e_rb,
                                                           NodeArrays nodes) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_b || e_ti[j] != 1) return;
+  if (j >= n_b || !((m_ti[j >> 6] >> (j & 63)) & 1ull)) return;
   int r[2] = {e_ra[j], e_rb[j]};
   for (int k = 0; k < 2; ++k) {
     int x = r[k];
@@ -225,15 +238,20 @@ __global__ __launch_bounds__(256) void k_restore_roots(int n, const int32_t* __r
   nodes.flags[rb] = bk_flags[2 * i + 1];
 }
 
-__global__ __launch_bounds__(256) void k_clear_kept(int n_b, const uint8_t* __restrict__ e_ti,
+__global__ __launch_bounds__(256) void k_clear_kept(int n_b, const unsigned long long* __restrict__ m_active,
+                                                     const unsigned long long* __restrict__ m_settled,
                                                      const uint32_t* __restrict__ e_gpos,
                                                      uint8_t* __restrict__ kept_all) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j < n_b && e_ti[j]) kept_all[e_gpos[j]] = 0;   // every edge whose kept mark the stage may have set
+  if (j >= n_b) return;
+  // every edge whose kept mark the stage may have set
+  if (((m_active[j >> 6] | m_settled[j >> 6]) >> (j & 63)) & 1ull) kept_all[e_gpos[j]] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_compact_active(int n_b, const int32_t* __restrict__ e_active,
-                                                         const int32_t* __restrict__ e_apos,
+// Ordered compaction of the active edges: block_off = exclusive scan of the per-workgroup counts
+// the filter left; inside a workgroup the position follows from the wavefronts' masks.
+__global__ __launch_bounds__(256) void k_compact_active(int n_b, FilterMasks M,
+                                                         const int32_t* __restrict__ block_off,
                                                          const int32_t* __restrict__ e_ra,
                                                          const int32_t* __restrict__ e_rb,
                                                          const uint32_t* __restrict__ e_gpos,
@@ -242,14 +260,18 @@ __global__ __launch_bounds__(256) void k_compact_active(int n_b, const int32_t* 
                                                          uint32_t* __restrict__ a_gpos,
                                                          int32_t* __restrict__ num_active) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_b) return;
-  if (e_active[j]) {
-    const int p = e_apos[j];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t gw0 = (size_t)blockIdx.x * 4;
+  const unsigned long long m = M.active[gw0 + w];
+  int base = block_off[blockIdx.x];
+  for (int k = 0; k < w; ++k) base += (int)__popcll(M.active[gw0 + k]);
+  if ((m >> lane) & 1ull) {
+    const int p = base + (int)__popcll(m & ((1ull << lane) - 1ull));
     a_ra[p] = e_ra[j];
     a_rb[p] = e_rb[j];
     a_gpos[p] = e_gpos[j];
   }
-  if (j == n_b - 1) *num_active = e_apos[j] + e_active[j];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *num_active = base + (int)__popcll(m);
 }
 
 __global__ __launch_bounds__(256) void k_component_ids(int n, const int32_t* __restrict__ a_ra,
@@ -301,11 +323,20 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
                                                       NodeArrays nodes, uint8_t* __restrict__ kept_all,
                                                       StageThr T, int optimistic,
                                                       int32_t* __restrict__ violation,
-                                                      unsigned long long* __restrict__ stats) {
+                                                      unsigned long long* __restrict__ stats,
+                                                      int wave_max, uint32_t* __restrict__ work_list,
+                                                      int work_cap, int32_t* __restrict__ work_ctl) {
   const int seg = blockIdx.x * 256 + threadIdx.x;
   unsigned n_forced = 0, n_regular = 0, n_small = 0;
   if (seg < *num_segs) {
     const int cnt = seg_cnt[seg];
+    if (cnt > kSmallSegment && cnt < wave_max && work_list) {
+      // the wave worker's: filed under its size class (the order inside a class is arbitrary --
+      // components are independent)
+      const int cls = cnt >= kWaveClassMin0 ? 0 : (cnt >= kWaveClassMin1 ? 1 : 2);
+      const int at = atomicAdd(&work_ctl[cls], 1);
+      work_list[(size_t)cls * work_cap + at] = (uint32_t)seg;
+    }
     if (cnt <= kSmallSegment) {
       const int beg = seg_off[seg];
       for (int p = beg; p < beg + cnt; ++p) {
@@ -442,15 +473,15 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   if (ef0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ef0], s));
   hipLaunchKernelGGL(k_filter, dim3(Blocks(n_b)), dim3(256), 0, s, bucket, bucket_hi, j0, n_b, lists,
                      bucket_base, S.bucket_prefix, list_slot_base, kept_all, nodes, P, inert_mode, S.cc, S.e_ra, S.e_rb, S.e_gpos,
-                     S.e_active, S.e_ti, d_num_ti);
+                     S.masks, d_num_ti);
   const int ef1 = NextEvent(S);
   if (ef1 >= 0) {
     VSG_HIP(hipEventRecord((*S.ev_pool)[ef1], s));
     S.ev_filter->emplace_back(ef0, ef1);
   }
-  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, S.e_active, S.e_apos, n_b, s);
-  hipLaunchKernelGGL(k_compact_active, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_active,
-                     S.e_apos, S.e_ra, S.e_rb, S.e_gpos, S.a_ra, S.a_rb, S.a_gpos, S.num_active);
+  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, S.masks.block_cnt, S.block_off, (int)Blocks(n_b), s);
+  hipLaunchKernelGGL(k_compact_active, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks, S.block_off,
+                     S.e_ra, S.e_rb, S.e_gpos, S.a_ra, S.a_rb, S.a_gpos, S.num_active);
   VSG_HIP(hipGetLastError());
   int h[4] = {0, 0, 0, 0};   // num_active, num_segs (unused), num_ti, violation
   VSG_HIP(hipMemcpyAsync(h, S.num_active, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -459,8 +490,8 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   const int n_ti = h[2];
   auto clear_marks = [&]() {
     if (n_ti > 0) {
-      hipLaunchKernelGGL(k_clear_tentative, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_ti, S.e_ra,
-                         S.e_rb, nodes);
+      hipLaunchKernelGGL(k_clear_tentative, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks.tentative,
+                         S.e_ra, S.e_rb, nodes);
     }
   };
   if (n_active == 0) {
@@ -551,11 +582,19 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   wa.stats = S.stats;
   wa.wave_min = kSmallSegment;
   wa.wave_max = spine_thr;
+  // work list of the wave worker: the RLE keys are not read again, the control words follow the
+  // stage's scalars
+  wa.work_cap = n_work / (kSmallSegment + 1) + 1;
+  wa.work_list = (size_t)kWaveClasses * wa.work_cap <= (size_t)n_work && !S.wave_v1 ? S.seg_key : nullptr;
+  wa.work_ctl = S.num_active + 8;
   auto general_workers = [&](const WorkerArgs& w, int small_threads, int grid, hipStream_t s) {
-    if (w.wave_min == kSmallSegment)
-    hipLaunchKernelGGL(k_merge_small, dim3(Blocks(small_threads)), dim3(256), 0, s, w.num_segs,
-                       w.seg_off, w.seg_cnt, w.s_ra, w.s_rb, w.s_gpos, w.nodes, w.kept_all, w.T,
-                       w.optimistic, w.violation, w.stats);
+    if (w.wave_min == kSmallSegment) {
+      if (w.work_list) VSG_HIP(hipMemsetAsync(w.work_ctl, 0, 2 * kWaveClasses * sizeof(int32_t), s));
+      hipLaunchKernelGGL(k_merge_small, dim3(Blocks(small_threads)), dim3(256), 0, s, w.num_segs,
+                         w.seg_off, w.seg_cnt, w.s_ra, w.s_rb, w.s_gpos, w.nodes, w.kept_all, w.T,
+                         w.optimistic, w.violation, w.stats, w.wave_max, w.work_list, w.work_cap,
+                         w.work_ctl);
+    }
     // the wave worker is timed on the stream it runs on
     const int ew0 = NextEvent(S);
     if (ew0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ew0], s));
@@ -587,6 +626,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       WorkerArgs w3 = wa;
       w3.wave_min = spine_thr - 1;
       w3.wave_max = 0x7fffffff;
+      w3.work_list = nullptr;   // (the list belongs to the launch on the second stream)
       general_workers(w3, n_work, wave_grid, s);
     }
     VSG_HIP(hipStreamWaitEvent(s, S.aux_join, 0));
@@ -605,7 +645,8 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
                          nodes, S.bk_ds, S.bk_cons, S.bk_flags);
       VSG_HIP(hipMemcpyAsync(S.stats, S.stats + 8, 8 * sizeof(unsigned long long),
                              hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.e_ti, S.e_gpos, kept_all);
+      hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks.active,
+                         S.masks.settled, S.e_gpos, kept_all);
       clear_marks();
       VSG_HIP(hipGetLastError());
       if (spine && violated == 2 && !S.force_rollback) {

@@ -524,7 +524,9 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
                                                     StageThr T, int optimistic,
                                                     int32_t* __restrict__ violation,
                                                     unsigned long long* __restrict__ stats,
-                                                    int dbg_flags, int wave_min, int wave_max) {
+                                                    int dbg_flags, int wave_min, int wave_max,
+                                                    const uint32_t* __restrict__ work_list, int work_cap,
+                                                    int32_t* __restrict__ work_ctl) {
   __shared__ WaveTable tab;
   auto Clock = []() -> unsigned long long { return kDbg ? __builtin_readcyclecounter() : 0ull; };
   __shared__ WaveQueue queue;
@@ -542,7 +544,36 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
   unsigned dbg_batches = 0;
   unsigned long long dbg_taken = 0, dbg_live = 0;
   unsigned long long cyc_load = 0, cyc_loop = 0, cyc_wait = 0;
-  for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+  __shared__ int next_seg;
+  // With a work list (filed by k_merge_small, three size classes, largest first) the workgroups
+  // draw tickets; without one they stride over all segments.
+  int total = 0, c0 = 0, c1 = 0;
+  if (work_list) {
+    c0 = work_ctl[0];
+    c1 = work_ctl[1];
+    total = c0 + c1 + work_ctl[2];
+  }
+  for (int it = blockIdx.x;; it += gridDim.x) {
+    int seg;
+    if (work_list) {
+      if (threadIdx.x == 0) {
+        const int ticket = atomicAdd(&work_ctl[kWaveClasses], 1);
+        int s_ = -1;
+        if (ticket < total) {
+          const int cls = ticket < c0 ? 0 : (ticket < c0 + c1 ? 1 : 2);
+          const int at = ticket - (cls == 0 ? 0 : (cls == 1 ? c0 : c0 + c1));
+          s_ = (int)work_list[(size_t)cls * work_cap + at];
+        }
+        next_seg = s_;
+      }
+      __syncthreads();
+      seg = next_seg;
+      __syncthreads();   // everybody has read next_seg before the next ticket overwrites it
+      if (seg < 0) break;
+    } else {
+      seg = it;
+      if (seg >= nseg) break;
+    }
     const int cnt = seg_cnt[seg];
     if (cnt <= wave_min || cnt >= wave_max) continue;
     const int beg = seg_off[seg];
@@ -834,11 +865,13 @@ void LaunchMergeWave(int grid, const WorkerArgs& a, bool instrumented, int dbg_f
   if (instrumented) {
     hipLaunchKernelGGL(k_merge_wave<true>, dim3(grid), dim3(128), 0, s, a.num_segs, a.seg_off,
                        a.seg_cnt, a.s_ra, a.s_rb, a.s_gpos, a.nodes, a.kept_all, a.T, a.optimistic,
-                       a.violation, a.stats, dbg_flags, a.wave_min, a.wave_max);
+                       a.violation, a.stats, dbg_flags, a.wave_min, a.wave_max, a.work_list, a.work_cap,
+                       a.work_ctl);
   } else {
     hipLaunchKernelGGL(k_merge_wave<false>, dim3(grid), dim3(128), 0, s, a.num_segs, a.seg_off,
                        a.seg_cnt, a.s_ra, a.s_rb, a.s_gpos, a.nodes, a.kept_all, a.T, a.optimistic,
-                       a.violation, a.stats, 0, a.wave_min, a.wave_max);
+                       a.violation, a.stats, 0, a.wave_min, a.wave_max, a.work_list, a.work_cap,
+                       a.work_ctl);
   }
   VSG_HIP(hipGetLastError());
 }

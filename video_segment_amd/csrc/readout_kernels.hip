@@ -208,27 +208,47 @@ __global__ __launch_bounds__(256) void k_neighbor_pairs(const ListDesc* __restri
   const ListDesc L = lists[l];
   if (!L.offsets) return;
   const int n_valid = L.offsets[kNumBuckets + 1];
-  for (int p = blockIdx.x * 256 + threadIdx.x; p < n_valid; p += gridDim.x * 256) {
-    if (!L.kept[p]) continue;
-    const uint32_t slot = L.slots[p];
-    int a, b;
-    if (L.type == 0) {
-      const uint32_t pix = slot >> 2;
-      const int k = (int)(slot & 3u);
-      a = L.base_a + (int)pix;
-      b = a + ((k == 0) ? 1 : (k == 1) ? W : (k == 2) ? (W - 1) : (W + 1));
-    } else {
-      const uint32_t pix = slot / 9u;
-      const int k = (int)(slot - pix * 9u);
-      const int dy = k / 3 - 1, dx = k - (k / 3) * 3 - 1;
-      a = L.base_a + (int)pix;
-      b = L.base_b + L.prev_idx[pix] + dy * W + dx;
+  const int lane = threadIdx.x & 63;
+  // (whole wavefronts iterate together: the ballots below need every lane)
+  for (int p0 = blockIdx.x * 256 + (threadIdx.x & ~63); p0 < n_valid; p0 += gridDim.x * 256) {
+    const int p = p0 + lane;
+    unsigned long long pair = 0;
+    bool emit = false;
+    if (p < n_valid && L.kept[p]) {
+      const uint32_t slot = L.slots[p];
+      int a, b;
+      if (L.type == 0) {
+        const uint32_t pix = slot >> 2;
+        const int k = (int)(slot & 3u);
+        a = L.base_a + (int)pix;
+        b = a + ((k == 0) ? 1 : (k == 1) ? W : (k == 2) ? (W - 1) : (W + 1));
+      } else {
+        const uint32_t pix = slot / 9u;
+        const int k = (int)(slot - pix * 9u);
+        const int dy = k / 3 - 1, dx = k - (k / 3) * 3 - 1;
+        a = L.base_a + (int)pix;
+        b = L.base_b + L.prev_idx[pix] + dy * W + dx;
+      }
+      const int ka = label_uf[a], kb = label_uf[b];
+      emit = ka != kb;
+      pair = ((unsigned long long)(uint32_t)ka << 32) | (unsigned long long)(uint32_t)kb;
     }
-    const int ka = label_uf[a], kb = label_uf[b];
-    if (ka == kb) continue;
-    const int idx = atomicAdd(count, 1);
+    // The kept edges along the common boundary of two regions repeat the same pair: a lane whose
+    // predecessor emits the same ordered pair stays silent (the earlier position carries the
+    // smaller order key, which is the one that counts), and the wavefront takes its output slots
+    // with one atomic.  Sort + unique on the rest do the exact job.
+    const unsigned long long prev_pair = __shfl_up(pair, 1);
+    const int prev_emit = __shfl_up((int)emit, 1);
+    if (lane > 0 && emit && prev_emit && prev_pair == pair) emit = false;
+    const unsigned long long m = __ballot(emit);
+    if (m == 0) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, (int)__popcll(m));
+    base = __shfl(base, 0);
+    if (!emit) continue;
+    const int idx = base + (int)__popcll(m & ((1ull << lane) - 1ull));
     if (idx < capacity) {
-      pairs[idx] = ((unsigned long long)(uint32_t)ka << 32) | (unsigned long long)(uint32_t)kb;
+      pairs[idx] = pair;
       // bucket of position p: binary search in the offsets
       int lo = 0, hi = kNumBuckets + 1;   // largest bkt with offsets[bkt] <= p
       while (hi - lo > 1) {
@@ -311,6 +331,64 @@ void LaunchConstrainedRoots(NodeArrays nodes, int begin, int end, int32_t* flag_
   if (n <= 0) return;
   hipLaunchKernelGGL(k_constrained_roots, dim3((n + 255) / 256), dim3(256), 0, s, nodes, begin, end,
                      flag_out, root_out);
+  VSG_HIP(hipGetLastError());
+}
+
+// The node walk of MergeConstrainedRegions reduced to *runs*.  A node matters to the walk if its own
+// constraint field is >= 0 or if it is a representative (whose field may become >= 0 during the
+// walk).  Consecutive nodes with the same representative repeat the same step until it becomes a
+// no-op, so only the first node of such a run (and the run's length, from the next entry) reaches
+// the host.  value_out: the representative; kRunRepUnconstrained for a representative whose own
+// field is < 0; kRunNone for a node that does not matter (it only terminates the run before it).
+constexpr int kRunNone = -1;
+constexpr int kRunRepUnconstrained = -2;
+__global__ __launch_bounds__(256) void k_constrained_run_values(NodeArrays nodes, int begin, int end,
+                                                                 int32_t* __restrict__ value_out) {
+  const int i = begin + blockIdx.x * 256 + threadIdx.x;
+  if (i >= end) return;
+  const int c = nodes.cons[i];
+  const int p = nodes.parent[i];
+  int v = kRunNone;
+  if (p == i) {
+    v = c >= 0 ? i : kRunRepUnconstrained;
+  } else if (c >= 0) {
+    v = FindRO(nodes.parent, p);
+  }
+  value_out[i - begin] = v;
+}
+
+__global__ __launch_bounds__(256) void k_constrained_run_heads(int begin, int n,
+                                                                const int32_t* __restrict__ value,
+                                                                int32_t* __restrict__ flag_out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int v = value[j];
+  const int i = begin + j;
+  int head;
+  if (j == 0) {
+    head = 1;
+  } else {
+    const int pv = value[j - 1];
+    const bool prev_plain = pv >= 0 && pv != i - 1;   // matters, is not a representative
+    if (v == kRunNone) {
+      head = pv != kRunNone;                           // terminates the run before it
+    } else if (v == kRunRepUnconstrained || v == i) {
+      head = 1;                                        // a representative is a run of its own
+    } else {
+      head = !(prev_plain && pv == v);
+    }
+  }
+  flag_out[j] = head;
+}
+
+void LaunchConstrainedRuns(NodeArrays nodes, int begin, int end, int32_t* value_out,
+                           int32_t* flag_out, hipStream_t s) {
+  const int n = end - begin;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_constrained_run_values, dim3((n + 255) / 256), dim3(256), 0, s, nodes, begin,
+                     end, value_out);
+  hipLaunchKernelGGL(k_constrained_run_heads, dim3((n + 255) / 256), dim3(256), 0, s, begin, n,
+                     value_out, flag_out);
   VSG_HIP(hipGetLastError());
 }
 

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 namespace vsg {
@@ -115,6 +116,7 @@ DenseSegmentationHip::DenseSegmentationHip(const vsg_options& o, int W, int H)
   VSG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   graph_.reset(new DenseGraphHip(W, H, options_.chunk_size + 1, options_.color_distance == 0, stream_));
   pre_.reset(new Preprocessor(W, H, stream_));
+  planes_ = std::make_shared<PlanePool>();
   std::memset(&last_timings_, 0, sizeof(last_timings_));
   std::memset(&accum_, 0, sizeof(accum_));
 }
@@ -124,6 +126,9 @@ DenseSegmentationHip::~DenseSegmentationHip() {
     (void)hipStreamSynchronize(stream_);
     graph_.reset();
     pre_.reset();
+    feature_buffer_.clear();
+    flow_dev_buffer_.clear();
+    planes_.reset();
     (void)hipStreamDestroy(stream_);
   }
 }
@@ -152,7 +157,7 @@ int DenseSegmentationHip::ProcessFrame(bool flush, const uint8_t* bgr, size_t st
                              hipMemcpyHostToDevice, stream_));
       bgr_dev = staging_bgr_.get();
     }
-    DevPlane feat(new DevBuf<float>(3 * wh_));
+    DevPlane feat = planes_->Take(3 * wh_);
     pre_->Run(bgr_dev, stride, options_.presmoothing, feat->get());
     accum_.preprocess_ms += pre_->last_ms();
     accum_.preprocess_launches += 1;
@@ -170,7 +175,7 @@ int DenseSegmentationHip::ProcessFrame(bool flush, const uint8_t* bgr, size_t st
         VSG_REQUIRE(flow != nullptr, -1, "Flow always has to be passed or be absent.");
         // Deep copy (the caller's buffer is only valid during the call); the field stays on the
         // device: the edge kernels read it, the tube analysis samples it there.
-        DevPlane fd(new DevBuf<float>(2 * wh_));
+        DevPlane fd = planes_->Take(2 * wh_);
         VSG_HIP(hipMemcpyAsync(fd->get(), flow, 2 * wh_ * sizeof(float),
                                mem == VSG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
                                stream_));
@@ -236,7 +241,9 @@ void DenseSegmentationHip::StartConstrainedGraph(const int32_t* virt_ids_dev,
 }
 
 void DenseSegmentationHip::ChunkBoundaryOutput(bool flush) {
+  const double tb0 = NowMs();
   SegmentAndOutputChunk(flush);
+  const double tb1 = NowMs();
   if (flush) {
     graph_open_ = false;
     return;
@@ -253,8 +260,14 @@ void DenseSegmentationHip::ChunkBoundaryOutput(bool flush) {
     VSG_HIP(hipStreamSynchronize(stream_));
   }
   halo_valid_ = true;
+  const double tb2 = NowMs();
   StartConstrainedGraph(halo_ids_dev_[0].get(), halo_ids_dev_[1].get(), max_region_id_);
   overlap_segmentations_.clear();
+  if (getenv("VSG_DEBUG_STATS")) {
+    VSG_HIP(hipStreamSynchronize(stream_));
+    std::fprintf(stderr, "[vsg] boundary: segment+output %.1f ms, halo planes %.1f ms, next graph start %.1f ms\n",
+                 tb1 - tb0, tb2 - tb1, NowMs() - tb2);
+  }
 }
 
 void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
@@ -270,6 +283,7 @@ void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
   graph_->ObtainResults(have_flows ? &flows : nullptr, options_.enforce_n4_connectivity != 0,
                         options_.enforce_spatial_connectedness != 0);
   const double t_host0 = NowMs();
+  double t_h[6] = {0};
   const GraphTimings& gt = graph_->timings();
   last_merge_stats_[0] = gt.merges[0];
   last_merge_stats_[1] = gt.merges[1];
@@ -310,6 +324,7 @@ void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
   }
   max_region_id_ = std::max(max_region_id_, max_id + 1);
 
+  t_h[0] = NowMs();
   const int chunk_size = last_output_frame - curr_chunk_start_ + 1;
   overlap_segmentations_.clear();
   const int hierarchy_frame_idx = num_output_frames_;
@@ -340,6 +355,7 @@ void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
     work();
     for (std::thread& t : pool) t.join();
   }
+  t_h[1] = NowMs();
   for (int i = 0; i < num_result_frames; ++i) {
     const int frame_idx = curr_chunk_start_ + i;
     std::unique_ptr<SegDesc>& desc = descs[(size_t)i];
@@ -357,6 +373,7 @@ void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
     overlap_segmentations_.push_back(std::move(desc));
   }
 
+  t_h[2] = NowMs();
   feature_buffer_.erase(feature_buffer_.begin(), feature_buffer_.begin() + last_output_frame);
   if (!flow_dev_buffer_.empty()) {
     flow_dev_buffer_.erase(flow_dev_buffer_.begin(), flow_dev_buffer_.begin() + last_output_frame);
@@ -370,6 +387,11 @@ void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
     }
   }
   ++chunk_id_;
+  t_h[3] = NowMs();
+  if (getenv("VSG_DEBUG_STATS")) {
+    std::fprintf(stderr, "[vsg] output: region table %.1f ms, retrieve+encode %.1f ms, collect %.1f ms, buffers %.1f ms\n",
+                 t_h[0] - t_host0, t_h[1] - t_h[0], t_h[2] - t_h[1], t_h[3] - t_h[2]);
+  }
 
   std::memset(&last_timings_, 0, sizeof(last_timings_));
   last_timings_.preprocess_ms = accum_.preprocess_ms;
