@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use device 0")
     ap.add_argument("--cpu-frames", type=int, default=20)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the information-only legs after the timed region (other configs, other "
+                         "inputs, several streams per GPU)")
     return ap.parse_args()
 
 
@@ -126,6 +129,224 @@ def cpu_baseline(W, H, chunk, n_frames, device):
     }, threaded, parity
 
 
+ACC_KEYS = ["wave_ms", "wave_launches", "wave_edges", "spine_ms", "spine_launches", "spine_edges",
+            "merge_ms", "pre_ms", "edges_ms", "readout_ms", "host_ms", "filter_ms", "filter_launches",
+            "edges_total", "merges"]
+
+
+def add_timings(a, t):
+    a["wave_ms"] += t.wave_kernel_ms
+    a["wave_launches"] += t.wave_kernel_launches
+    a["wave_edges"] += t.wave_kernel_edges
+    a["spine_ms"] += t.spine_kernel_ms
+    a["spine_launches"] += t.spine_kernel_launches
+    a["spine_edges"] += t.spine_kernel_edges
+    a["filter_ms"] += t.filter_kernel_ms
+    a["filter_launches"] += t.filter_kernel_launches
+    a["merge_ms"] += t.merge_ms
+    a["pre_ms"] += t.preprocess_ms
+    a["edges_ms"] += t.edges_ms
+    a["readout_ms"] += t.readout_ms
+    a["host_ms"] += t.host_post_ms
+    a["edges_total"] += t.edges_total
+    a["merges"] += t.merges
+
+
+def make_frames(kind, W, H, n, dev, seed_shift=0, host=False):
+    """n frames of a synthetic input, generated on the device (tests/synth.py: bit-identical to the
+    numpy generators the parity tests use)."""
+    import synth
+    frames = [synth.frame_torch(kind, W, H, k + seed_shift, dev) for k in range(n)]
+    if host:
+        return [f.cpu().numpy() for f in frames]
+    return frames
+
+
+def time_streams(vsg, frames, flow, W, H, chunk, S, warm, steps, device_index, barrier=None):
+    """S independent streams (one host thread each) over the same resident frames: `warm` untimed
+    chunk boundaries per stream, then exactly `steps` timed ones between two synchronisations.
+    Every SegmentationDesc of a boundary is fetched inside the timed region."""
+    import threading
+    streams = [vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=device_index),
+                                     has_flow=True) for _ in range(S)]
+    torch.cuda.synchronize()
+    accs = [dict((k_, 0) for k_ in ACC_KEYS) for _ in range(S)]
+    outs = [0] * S
+    pos = [0] * S
+    errors = []
+
+    def run_stream(si, n_steps, record):
+        stream = streams[si]
+        done = 0
+        while done < n_steps:
+            k = pos[si]
+            n = stream.process_frame(frames[k], flow if k > 0 else None)
+            pos[si] = k + 1
+            if n:
+                # the consumer side of the boundary: every SegmentationDesc is fetched
+                # (serialized message copied out) inside the timed region
+                fetched = sum(len(stream.result_bytes(i)) for i in range(n))
+                assert fetched > 0
+                done += 1
+                if record:
+                    outs[si] += n
+                    add_timings(accs[si], stream.last_timings())
+
+    def run(si, n_steps, record):
+        try:
+            run_stream(si, n_steps, record)
+        except BaseException as e:  # noqa: BLE001 -- re-raised on the main thread
+            errors.append(e)
+
+    def run_all(n_steps, record):
+        if S == 1:
+            run_stream(0, n_steps, record)
+            return
+        th = [threading.Thread(target=run, args=(si, n_steps, record)) for si in range(S)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        if errors:
+            raise errors[0]
+
+    def sync():
+        torch.cuda.synchronize()
+        if barrier is not None:
+            barrier()
+
+    run_all(warm, False)          # warm-up: includes the first (unconstrained) chunk
+    sync()
+    t0 = time.perf_counter()
+    run_all(steps, True)          # exactly `steps` timed boundaries per stream
+    sync()
+    dt = time.perf_counter() - t0
+    for st_ in streams:
+        st_.close()
+    acc = dict((k_, sum(a[k_] for a in accs) / S) for k_ in ACC_KEYS)
+    return {"dt": dt, "frames": sum(outs), "acc": acc}
+
+
+def stage_ms(acc, steps):
+    return {"preprocess": acc["pre_ms"] / steps, "edges_sort": acc["edges_ms"] / steps,
+            "merge": acc["merge_ms"] / steps, "merge_wave_kernel": acc["wave_ms"] / steps,
+            "merge_spine_kernel": acc["spine_ms"] / steps, "merge_filter_kernel": acc["filter_ms"] / steps,
+            "readout": acc["readout_ms"] / steps, "host_post": acc["host_ms"] / steps}
+
+
+def extra_measurements(vsg, args, dev, device_index, headline_fps):
+    """What the headline number depends on (rank 0, N = 1, after the timed region; information
+    only): the other single-GPU configs of BASELINE.json, the same 1080p shape on inputs with many
+    small regions, and S concurrent streams on the one GPU."""
+    import oracle_lib as ol
+    import synth
+    W, H, chunk = args.width, args.height, args.chunk
+    px_bytes = BYTES_PER_PX_FRAME
+    out = {}
+
+    # ---- BASELINE configs[1]: 640x480, 32-slice window, spatial-only graph through seam 3 ----
+    cw, chh, cf = 640, 480, 32
+    frames = [synth.frame_torch("bench", cw, chh, k, dev) for k in range(cf)]
+
+    def run_graph():
+        g = vsg.DenseSegGraph(cw, chh, cf, device=device_index)
+        for f in frames:
+            g.add_frame_bgr(f)
+        g.finish_building()
+        g.segment(983, False)
+        g.obtain_results(use_flows=False)
+        n = g.num_regions()
+        g.close()
+        return n
+
+    run_graph()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        nreg = run_graph()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    c1 = {"workload": "640x480 bench generator, 32-slice window, spatial-only dense graph "
+                      "(DenseSegGraphInterface seam: add frames, SegmentFullGraph(983), ObtainResults + "
+                      "DetermineNeighborIds), frames resident in HBM",
+          "value": cf / dt, "unit": "frames/s", "ms_per_window": dt * 1e3, "regions": nreg,
+          "roofline_note": "55 B/px/frame (SURVEY 8(d), spatial-only) -> %.2f GB/s" %
+                           (cf / dt * cw * chh * 55.0 / 1e9)}
+    if not args.no_cpu_baseline:
+        hf = [f.cpu().numpy() for f in frames]
+        ol.set_threads(1)
+        t0 = time.perf_counter()
+        og = ol.OracleGraph(cw, chh, cf)
+        for f in hf:
+            og.add_frame(ol.preprocess(f))
+        og.segment(983, False)
+        og.obtain_results(None, True, True)
+        dt_o = time.perf_counter() - t0
+        c1["cpu_baseline"] = {"value": cf / dt_o, "unit": "frames/s", "cores": 1, "kind": "port",
+                              "sample": "the same 32-slice window, oracle/libvs_oracle.so, %.1f s" % dt_o}
+        c1["parity_checked"] = bool(og.num_regions() == nreg)
+        og.close()
+    out["configs"] = {"configs[1]": c1}
+
+    # ---- 3840x2160 + flow (the over-segmentation half of configs[4]) --------------------------
+    w4, h4 = 3840, 2160
+    n4 = chunk + (chunk - 1) * 2
+    f4 = make_frames("bench", w4, h4, n4, dev)
+    fl4 = torch.from_numpy(synth.const_flow(w4, h4)).to(dev)
+    r4 = time_streams(vsg, f4, fl4, w4, h4, chunk, 1, 1, 2, device_index)
+    fps4 = r4["frames"] / r4["dt"]
+    c4 = {"workload": "3840x2160 bench generator + constant flow, chunk %d, one stream, 2 timed "
+                      "steady-state chunks, inputs resident in HBM" % chunk,
+          "value": fps4, "unit": "frames/s", "ms_per_step": r4["dt"] / 2 * 1e3,
+          "stage_ms_per_step": stage_ms(r4["acc"], 2),
+          "roofline_note": "%.0f B/px/frame -> %.2f GB/s" % (px_bytes, fps4 * w4 * h4 * px_bytes / 1e9)}
+    if not args.no_cpu_baseline:
+        ns = 8
+        hf = [f.cpu().numpy() for f in f4[:ns]]
+        flh = synth.const_flow(w4, h4)
+        ol.set_threads(1)
+        st = ol.OracleStream(w4, h4, ol.default_options(chunk_size=chunk), has_flow=True)
+        t0 = time.perf_counter()
+        n_ = 0
+        for k in range(ns):
+            n_ += st.process_frame(hf[k], flh if k > 0 else None, flush=(k == ns - 1))
+        dt_o = time.perf_counter() - t0
+        st.close()
+        c4["cpu_baseline"] = {"value": ns / dt_o, "unit": "frames/s", "cores": 1, "kind": "port",
+                              "sample": "first %d frames of the same 3840x2160 workload as one flushed "
+                                        "chunk, oracle/libvs_oracle.so, %.1f s" % (ns, dt_o)}
+    del f4, fl4
+    torch.cuda.empty_cache()
+    out["configs"]["3840x2160"] = c4
+
+    # ---- the 1080p shape on inputs with many small regions ---------------------------------------
+    flow = torch.from_numpy(synth.const_flow(W, H)).to(dev)
+    nfr = chunk + (chunk - 1) * 2
+    wl = {"checker (headline input)": {"value": headline_fps, "unit": "frames/s"}}
+    for kind, label in (("blobs", "value noise: 48 px cells of random colour moving with the flow, +-3 noise"),
+                        ("noise", "gradient + independent +-40 noise per pixel and channel")):
+        fr = make_frames(kind, W, H, nfr, dev)
+        r = time_streams(vsg, fr, flow, W, H, chunk, 1, 1, 2, device_index)
+        fps = r["frames"] / r["dt"]
+        wl[kind] = {"input": label, "value": fps, "unit": "frames/s", "ms_per_step": r["dt"] / 2 * 1e3,
+                    "merges_per_step": r["acc"]["merges"] / 2, "stage_ms_per_step": stage_ms(r["acc"], 2)}
+        del fr
+    out["workloads"] = wl
+
+    # ---- S concurrent streams on the one GPU -------------------------------------------------------
+    fr = make_frames("bench", W, H, nfr, dev)
+    sweep = []
+    for S in (1, 2, 4, 8):
+        r = time_streams(vsg, fr, flow, W, H, chunk, S, 1, 2, device_index)
+        fps = r["frames"] / r["dt"]
+        sweep.append({"streams": S, "value": fps, "unit": "frames/s/GPU",
+                      "end_to_end_gbps": fps * W * H * px_bytes / 1e9,
+                      "ms_per_step_per_stream": r["dt"] / 2 * 1e3})
+    out["streams_sweep"] = sweep
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -173,109 +394,32 @@ def main():
         seed_shift = 1000 * rank
         flow_host = synth.const_flow(W, H)
         flow = flow_host if args.host_inputs else torch.from_numpy(flow_host).to(dev)
-        frames, frames_host = [], []
-        for k in range(n_frames):
-            f = synth.bench_frame(W, H, k + seed_shift) if rank else synth.bench_frame(W, H, k)
-            frames_host.append(f)
-            frames.append(f if args.host_inputs else torch.from_numpy(f).to(dev))
-        import threading
+        frames = make_frames("bench", W, H, n_frames, dev, seed_shift, host=args.host_inputs)
         S = max(1, args.streams)
-        streams = [vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=local_rank),
-                                         has_flow=True) for _ in range(S)]
-        torch.cuda.synchronize()
 
         def barrier():
-            torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
 
-        keys = ["wave_ms", "wave_launches", "wave_edges", "spine_ms", "spine_launches", "spine_edges",
-                "merge_ms", "pre_ms", "edges_ms",
-                "readout_ms", "host_ms", "filter_ms", "filter_launches", "edges_total", "merges"]
-        accs = [dict((k_, 0) for k_ in keys) for _ in range(S)]
-        outs = [0] * S
-        pos = [0] * S
-
-        errors = []
-
-        def run(si, steps, record):
-            try:
-                run_stream(si, steps, record)
-            except BaseException as e:  # noqa: BLE001 -- re-raised on the main thread
-                errors.append(e)
-
-        def run_stream(si, steps, record):
-            stream = streams[si]
-            done = 0
-            while done < steps:
-                k = pos[si]
-                n = stream.process_frame(frames[k], flow if k > 0 else None)
-                pos[si] = k + 1
-                if n:
-                    # the consumer side of the boundary: every SegmentationDesc is fetched
-                    # (serialized message copied out) inside the timed region
-                    fetched = sum(len(stream.result_bytes(i)) for i in range(n))
-                    assert fetched > 0
-                    done += 1
-                    if record:
-                        outs[si] += n
-                        t = stream.last_timings()
-                        a = accs[si]
-                        a["wave_ms"] += t.wave_kernel_ms
-                        a["wave_launches"] += t.wave_kernel_launches
-                        a["wave_edges"] += t.wave_kernel_edges
-                        a["spine_ms"] += t.spine_kernel_ms
-                        a["spine_launches"] += t.spine_kernel_launches
-                        a["spine_edges"] += t.spine_kernel_edges
-                        a["filter_ms"] += t.filter_kernel_ms
-                        a["filter_launches"] += t.filter_kernel_launches
-                        a["merge_ms"] += t.merge_ms
-                        a["pre_ms"] += t.preprocess_ms
-                        a["edges_ms"] += t.edges_ms
-                        a["readout_ms"] += t.readout_ms
-                        a["host_ms"] += t.host_post_ms
-                        a["edges_total"] += t.edges_total
-                        a["merges"] += t.merges
-
-        def run_all(steps, record):
-            if S == 1:
-                run_stream(0, steps, record)
-                return
-            th = [threading.Thread(target=run, args=(si, steps, record)) for si in range(S)]
-            for t_ in th:
-                t_.start()
-            for t_ in th:
-                t_.join()
-            if errors:
-                raise errors[0]
-
-        run_all(Wm, False)          # warm-up: includes the first (unconstrained) chunk
-        barrier()
-        t0 = time.perf_counter()
-        run_all(K, True)            # K timed steps per stream
-        barrier()
-        dt = time.perf_counter() - t0
-        frames_out = sum(outs)
-        acc = dict((k_, sum(a[k_] for a in accs) / S) for k_ in keys)
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        fo = torch.tensor([frames_out], dtype=torch.float64, device=dev)
+        r = time_streams(vsg, frames, flow, W, H, chunk, S, Wm, K, local_rank, barrier)
+        tt = torch.tensor([r["dt"]], dtype=torch.float64, device=dev)
+        fo = torch.tensor([r["frames"]], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.all_reduce(fo, op=dist.ReduceOp.SUM)
-        result = {"dt": float(tt.item()), "frames": float(fo.item()), "acc": acc,
+        result = {"dt": float(tt.item()), "frames": float(fo.item()), "acc": r["acc"],
                   "parallelism": "%d independent 1080p stream(s) per GPU x %d GPU(s)" % (S, world)}
-        for st_ in streams:
-            st_.close()
         # PCIe-inclusive leg (rank 0, one stream, not `value`): the same steady-state chunks with
         # frames and flow handed over as host buffers, so that the H2D copies are timed as well.
         result["pcie"] = None
         if rank == 0 and not args.host_inputs and not args.no_pcie_leg and S == 1:
             st_ = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=local_rank),
                                         has_flow=True)
-            need = chunk + (chunk - 1) * 2
+            need = min(chunk + (chunk - 1) * 2, n_frames)
+            frames_host = [frames[k].cpu().numpy() for k in range(need)]
             k = 0
             t_start, got, steps_done = None, 0, 0
-            while k < min(need, n_frames):
+            while k < need:
                 n_ = st_.process_frame(frames_host[k], flow_host if k > 0 else None)
                 k += 1
                 if n_:
@@ -291,6 +435,7 @@ def main():
                                   "note": "frames (6.2 MB) and flow (16.6 MB) per frame copied from "
                                           "pageable host memory inside the timed region"}
             st_.close()
+        del frames
 
     if rank == 0:
         dt, frames_total, acc = result["dt"], result["frames"], result["acc"]
@@ -312,7 +457,9 @@ def main():
         # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes cannot run inside the
         # timed process, so the committed summary of the same workload is quoted (null if absent).
         traffic, traffic_note = None, "no PMC summary under profiles/"
-        pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_%s.json" % dom[0])
+        pmc_path = os.path.join(ROOT, "profiles", "r3_pmc_%s.json" % dom[0])
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_%s.json" % dom[0])
         if os.path.exists(pmc_path) and (W, H, chunk) == (1920, 1080, 20):
             pmc = json.load(open(pmc_path))
             traffic = pmc["fetch_bytes_per_launch_raw"] + pmc["write_bytes_per_launch_raw"]
@@ -359,13 +506,7 @@ def main():
                         % (dom[2], dom[3], BYTES_PER_PX_FRAME,
                            fps / world * px * BYTES_PER_PX_FRAME / 1e9),
             },
-            "stage_ms_per_step": {
-                "preprocess": acc["pre_ms"] / K, "edges_sort": acc["edges_ms"] / K,
-                "merge": acc["merge_ms"] / K, "merge_wave_kernel": acc["wave_ms"] / K,
-                "merge_spine_kernel": acc["spine_ms"] / K,
-                "merge_filter_kernel": acc["filter_ms"] / K, "readout": acc["readout_ms"] / K,
-                "host_post": acc["host_ms"] / K,
-            },
+            "stage_ms_per_step": stage_ms(acc, K),
             "edges_per_step": acc["edges_total"] / K,
             "merges_per_step": acc["merges"] / K,
         }
@@ -379,6 +520,10 @@ def main():
             if threaded is not None:
                 out["cpu_baseline_threaded"] = threaded
             assert out["parity_checked"], "HIP output differs from the oracle on the bench workload"
+        if world == 1 and args.mode == "streams" and not args.no_extras and not args.host_inputs \
+                and args.streams == 1 and (W, H) == (1920, 1080):
+            torch.cuda.empty_cache()
+            out.update(extra_measurements(vsg, args, dev, local_rank, fps))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

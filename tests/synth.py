@@ -56,6 +56,89 @@ def bench_frame(W, H, t, noise=True):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
+def noise_frame(W, H, t, amp=40):
+    """The bench shape on an input with MANY SMALL regions: the gradient of bench_frame (no checker)
+    plus independent noise of +-amp per pixel and channel (pcg32(4321 + t))."""
+    x = np.arange(W, dtype=np.int64)[None, :]
+    y = np.arange(H, dtype=np.int64)[:, None]
+    img = np.empty((H, W, 3), np.int64)
+    img[..., 0] = (x * 255) // W
+    img[..., 1] = (y * 255) // H
+    img[..., 2] = 128
+    r = _pcg32_stream(4321 + t, W * H * 3).astype(np.int64).reshape(H, W, 3)
+    img += (r % (2 * amp + 1)) - amp
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def blobs_frame(W, H, t, cell=48):
+    """Value noise: a coarse grid of random colours (one per cell x cell block, pcg32(777)), moved
+    2 px per frame like the checker so that the constant flow matches, plus the +-3 noise of
+    bench_frame -- thousands of medium-sized regions per frame instead of a dozen giant ones."""
+    x = (np.arange(W, dtype=np.int64)[None, :] + 2 * t) // cell
+    y = np.arange(H, dtype=np.int64)[:, None] // cell
+    gw = (W + 2 * 4096) // cell + 2
+    key = (y * gw + x).astype(np.uint32)
+    img = np.empty((H, W, 3), np.int64)
+    for c in range(3):
+        img[..., c] = _pcg_hash(key * np.uint32(3) + np.uint32(c) + _pcg_hash(np.array([777], np.uint32))[0]) % 224 + 16
+    r = _pcg32_stream(1234 + t, W * H * 3).astype(np.int64).reshape(H, W, 3)
+    img += (r % 7) - 3
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _pcg_hash_t(v):
+    """_pcg_hash on a torch int64 tensor holding uint32 values."""
+    m = 0xFFFFFFFF
+    state = (v * 747796405 + 2891336453) & m
+    word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & m
+    return ((word >> 22) ^ word) & m
+
+
+def frame_torch(kind, W, H, t, device):
+    """bench_frame / noise_frame / blobs_frame generated on `device` with torch (bit-identical to
+    the numpy versions, tests/test_synth.py): the numpy generators need 0.15 s per 1080p frame."""
+    import torch
+    x = torch.arange(W, dtype=torch.int64, device=device)[None, :]
+    y = torch.arange(H, dtype=torch.int64, device=device)[:, None]
+    img = torch.empty((H, W, 3), dtype=torch.int64, device=device)
+
+    def stream(seed):
+        base = int(_pcg_hash(np.array([seed], np.uint32))[0])
+        idx = (torch.arange(W * H * 3, dtype=torch.int64, device=device) + base) & 0xFFFFFFFF
+        return _pcg_hash_t(idx).reshape(H, W, 3)
+
+    if kind == "bench":
+        cw = max(1, (16 * W) // 64)
+        ch = max(1, (12 * W) // 64)
+        img[..., 0] = ((x * 255) // W).expand(H, W)
+        img[..., 1] = ((y * 255) // H).expand(H, W)
+        chk = (((x + 2 * t) // cw) % 2) ^ ((y // ch) % 2)
+        img[..., 2] = chk * 160 + 40
+        img += (stream(1234 + t) % 7) - 3
+    elif kind == "noise":
+        amp = 40
+        img[..., 0] = ((x * 255) // W).expand(H, W)
+        img[..., 1] = ((y * 255) // H).expand(H, W)
+        img[..., 2] = 128
+        img += (stream(4321 + t) % (2 * amp + 1)) - amp
+    elif kind == "blobs":
+        cell = 48
+        gx = (x + 2 * t) // cell
+        gy = y // cell
+        gw = (W + 2 * 4096) // cell + 2
+        key = (gy * gw + gx) & 0xFFFFFFFF
+        salt = int(_pcg_hash(np.array([777], np.uint32))[0])
+        for c in range(3):
+            img[..., c] = _pcg_hash_t((key * 3 + c + salt) & 0xFFFFFFFF) % 224 + 16
+        img += (stream(1234 + t) % 7) - 3
+    else:
+        raise ValueError(kind)
+    return img.clamp_(0, 255).to(torch.uint8)
+
+
+FRAME_FNS = {"bench": bench_frame, "noise": noise_frame, "blobs": blobs_frame}
+
+
 def const_flow(W, H, fx=-2.0, fy=0.0):
     f = np.empty((H, W, 2), np.float32)
     f[..., 0] = fx

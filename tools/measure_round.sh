@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
-CMD="python $ROOT/bench.py --no-cpu-baseline --no-pcie-leg"
+CMD="python $ROOT/bench.py --no-cpu-baseline --no-pcie-leg --no-extras"
 rm -rf /tmp/prof_ks && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o ks -- $CMD > "$OUT/ks.log" 2>&1
 cp /tmp/prof_ks/ks_kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null
 for C in FETCH_SIZE WRITE_SIZE; do

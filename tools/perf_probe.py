@@ -11,8 +11,8 @@ W, H, N, chunk = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.a
 kind = sys.argv[5] if len(sys.argv) > 5 else "bench"
 s = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=True)
 fl = torch.from_numpy(synth.const_flow(W, H)).cuda()
-frames = [torch.from_numpy(synth.bench_frame(W, H, k) if kind == "bench" else synth.probe_frame(W, H, k)).cuda()
-          for k in range(N)]
+frames = [synth.frame_torch(kind, W, H, k, torch.device("cuda")) if kind in synth.FRAME_FNS
+          else torch.from_numpy(synth.probe_frame(W, H, k)).cuda() for k in range(N)]
 torch.cuda.synchronize()
 t0 = time.time(); tl = t0
 for k in range(N):

@@ -376,8 +376,17 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.bk_flags = bk_flags_.get();
   S.force_rollback = getenv("VSG_FORCE_ROLLBACK") ? 1 : 0;
   S.wave_v1 = getenv("VSG_WAVE_V1") ? 1 : 0;
+  // Sizes that follow the graph rather than the 1080p bench: the tree replay's scratch pool holds
+  // the large components of one stage, which together are at most about one bucket of the chunk
+  // graph (1.15 N edges: 48 M at 1080p x 21 slices; the stamped ranks of the spanning forest allow
+  // 2^27); a component is worth the tree replay from a fixed number of edges on (what one
+  // wavefront replays in about a millisecond), whatever the frame size.
   S.spine_min = getenv("VSG_SPINE_MIN") ? atoi(getenv("VSG_SPINE_MIN")) : 4096;
-  S.spine_max_edges = getenv("VSG_SPINE_MAX_EDGES") ? atoi(getenv("VSG_SPINE_MAX_EDGES")) : (48 << 20);
+  {
+    const double want = 1.15 * (double)wh_ * (double)capacity_frames_;   // (the handle's capacity, not this chunk's N)
+    const int by_graph = (int)std::min<double>(std::max<double>(want, 1 << 20), 120 << 20);
+    S.spine_max_edges = getenv("VSG_SPINE_MAX_EDGES") ? atoi(getenv("VSG_SPINE_MAX_EDGES")) : by_graph;
+  }
   S.spine_off = 0;
   if (spine_limit_bucket_ != 0x7fffffff && ++spine_limit_age_ > 8) {   // probe again
     spine_limit_bucket_ = 0x7fffffff;
@@ -467,9 +476,14 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   const bool debug_stages = getenv("VSG_DEBUG_STAGES") != nullptr;
   const int num_windows = getenv("VSG_WINDOWS") ? std::max(1, atoi(getenv("VSG_WINDOWS"))) : 6;
   const int window_bushy = getenv("VSG_WINDOW_BUSHY") ? atoi(getenv("VSG_WINDOW_BUSHY")) : 64;
-  const int window_min_edges = getenv("VSG_WINDOW_MIN") ? atoi(getenv("VSG_WINDOW_MIN")) : (4 << 20);
+  // (in units of the frame: a bucket is split into rank windows from two frames' worth of edges
+  // on -- 4 M at 1080p --, a probe window that replays less than half a frame's worth -- 1 M --
+  // ends the splitting)
+  const int window_min_edges =
+      getenv("VSG_WINDOW_MIN") ? atoi(getenv("VSG_WINDOW_MIN")) : (int)std::min<size_t>(2 * wh_, 1u << 30);
   const int window_min_replayed =
-      getenv("VSG_WINDOW_MIN_REPLAYED") ? atoi(getenv("VSG_WINDOW_MIN_REPLAYED")) : (getenv("VSG_WINDOW_MIN") ? 0 : (1 << 20));
+      getenv("VSG_WINDOW_MIN_REPLAYED") ? atoi(getenv("VSG_WINDOW_MIN_REPLAYED"))
+                                        : (getenv("VSG_WINDOW_MIN") ? 0 : (int)std::min<size_t>(wh_ / 2, 1u << 30));
   // A bucket is replayed as consecutive *rank windows* (each a full stage: filter -> components ->
   // workers; exact for any split, see RunBucketStage).  While the regions of a bucket are still
   // many small clusters growing side by side, the edges of one window fall into many small
