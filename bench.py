@@ -335,14 +335,53 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps):
     out["workloads"] = wl
 
     # ---- S concurrent streams on the one GPU -------------------------------------------------------
-    fr = make_frames("bench", W, H, nfr, dev)
+    # One PROCESS per stream (the control flow of --gpus S with every rank on this GPU: gloo barrier
+    # and reductions, no data-path collective).  Threads of one process are measured as well
+    # (--streams S): they scale worse, the HIP runtime serialises the host calls of a process and
+    # one stream issues about 4000 launches and 250 synchronisations per chunk.
+    import socket
+    import subprocess
+    del flow
+    torch.cuda.empty_cache()
+
+    def sub_bench(extra):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k_, None)
+        cmd = [sys.executable] + extra(port) + ["--steps", "2", "--warmup", "1", "--no-extras",
+                                               "--no-cpu-baseline", "--no-pcie-leg", "--width", str(W),
+                                               "--height", str(H), "--chunk", str(chunk)]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        if p.returncode != 0:
+            return None
+        for line in reversed(p.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return None
+
     sweep = []
     for S in (1, 2, 4, 8):
-        r = time_streams(vsg, fr, flow, W, H, chunk, S, 1, 2, device_index)
-        fps = r["frames"] / r["dt"]
-        sweep.append({"streams": S, "value": fps, "unit": "frames/s/GPU",
-                      "end_to_end_gbps": fps * W * H * px_bytes / 1e9,
-                      "ms_per_step_per_stream": r["dt"] / 2 * 1e3})
+        entry = {"streams": S}
+        if S == 1:
+            d = sub_bench(lambda port: [os.path.abspath(__file__)])
+        else:
+            d = sub_bench(lambda port: ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(S),
+                                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                        os.path.abspath(__file__), "--gpus", str(S), "--share-gpu",
+                                        "--dist-backend", "gloo"])
+        if d is not None:
+            entry.update({"processes": {"value": d["value"], "unit": "frames/s/GPU",
+                                        "end_to_end_gbps": d["value"] * W * H * px_bytes / 1e9,
+                                        "ms_per_step_per_stream": d["ms_per_step"]}})
+        if S > 1:
+            d = sub_bench(lambda port: [os.path.abspath(__file__), "--streams", str(S)])
+            if d is not None:
+                entry["threads_of_one_process"] = {"value": d["value"], "unit": "frames/s/GPU",
+                                                   "ms_per_step_per_stream": d["ms_per_step"]}
+        sweep.append(entry)
     out["streams_sweep"] = sweep
     return out
 

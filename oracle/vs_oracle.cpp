@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -53,10 +54,16 @@ struct ShapeMoments {
   float size = 0, mean_x = 0, mean_y = 0, moment_xx = 0, moment_xy = 0, moment_yy = 0;
 };
 
+struct Polygon {   // SegmentationDesc.Polygon
+  std::vector<int> coord_idx;
+  bool hole = false;
+};
+
 struct Region2D {
   int id = 0;
   Rasterization raster;
   ShapeMoments shape_moments;
+  std::vector<Polygon> vectorization;   // Vectorization.polygon (empty: field absent)
 };
 
 struct CompoundRegion {
@@ -80,6 +87,8 @@ struct SegmentationDesc {
   int frame_width = 0, frame_height = 0;
   int chunk_size = 0, overlap_start = 0, chunk_id = -1, hierarchy_frame_idx = 0;
   int connectedness = 1;  // N4_CONNECT = 1, N8_CONNECT = 2
+  bool has_vector_mesh = false;
+  std::vector<float> vector_mesh;   // VectorMesh.coord: x, y pairs
 };
 
 // proto2 wire encoding of SegmentationDesc (field numbers from segmentation.proto:55-172;
@@ -130,6 +139,18 @@ static std::string Encode(const SegmentationDesc& d) {
     Float(&sm, 5, r.shape_moments.moment_xy);
     Float(&sm, 6, r.shape_moments.moment_yy);
     Bytes(&rs, 5, sm);
+    if (!r.vectorization.empty()) {   // Region2D.vectorization = 6
+      std::string vec;
+      for (const Polygon& pg : r.vectorization) {
+        std::string ps, packed;
+        for (int idx : pg.coord_idx) Varint(&packed, (uint64_t)(int64_t)idx);
+        if (!packed.empty()) Bytes(&ps, 1, packed);   // coord_idx = 1 [packed = true]
+        Tag(&ps, 2, 0);                               // hole = 2: set_hole() is always called
+        Varint(&ps, pg.hole ? 1 : 0);
+        Bytes(&vec, 1, ps);
+      }
+      Bytes(&rs, 6, vec);
+    }
     Bytes(&out, 2, rs);
   }
   for (const HierarchyLevel& h : d.hierarchy) {
@@ -153,6 +174,19 @@ static std::string Encode(const SegmentationDesc& d) {
   Int32(&out, 7, d.overlap_start);
   Int32(&out, 8, d.chunk_id);
   Int32(&out, 9, d.hierarchy_frame_idx);
+  if (d.has_vector_mesh) {   // SegmentationDesc.vector_mesh = 11
+    std::string mesh;
+    if (!d.vector_mesh.empty()) {   // coord = 1 [packed = true]
+      std::string packed;
+      for (float f : d.vector_mesh) {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        for (int i = 0; i < 4; ++i) packed.push_back(static_cast<char>((u >> (8 * i)) & 0xff));
+      }
+      Bytes(&mesh, 1, packed);
+    }
+    Bytes(&out, 11, mesh);
+  }
   Int32(&out, 12, d.connectedness);
   return out;
 }
@@ -1513,11 +1547,14 @@ static void SegmentationDescToIdImage(const SegmentationDesc& seg, int W, int32_
   }
 }
 
+#include "vs_oracle_boundary.inc"
+
 // ------------------------------------------------------------------------------------------
 // Segmentation (over-segmentation half), segmentation/segmentation.cpp.
 // ------------------------------------------------------------------------------------------
 struct SegOptions {
   int min_region_size = 200;
+  bool compute_vectorization = false;    // segmentation.h: compute_vectorization (seg_tree --over_segment)
   bool two_stage_segmentation = false;   // segmentation.h:53-55
   bool enforce_n4_connectivity = true;
   bool enforce_spatial_connectedness = true;
@@ -1630,6 +1667,7 @@ class Segmentation {
                   [](const CompoundRegion& a, const CompoundRegion& b) { return a.id < b.id; });
       }
     }
+    if (options_.compute_vectorization) ComputeFrameVectorization(desc);   // segmentation.cpp:527-532
   }
 
   const int64_t* merge_stats() const { return merge_stats_; }
@@ -1754,6 +1792,7 @@ class DenseSegmentation {
     so.enforce_n4_connectivity = options_.enforce_n4_connectivity != 0;
     so.enforce_spatial_connectedness = options_.enforce_spatial_connectedness != 0;
     so.two_stage_segmentation = options_.two_stage_oversegment != 0;   // dense_segmentation.cpp:274
+    so.compute_vectorization = options_.compute_vectorization != 0;
     seg_.reset(new Segmentation(so, W_, H_, chunk_id_, max_frames, options_.color_distance == 0));
   }
 
@@ -1886,6 +1925,37 @@ extern "C" {
 
 void vso_set_threads(int n) { vso::g_threads = n < 1 ? 1 : n; }
 
+int vso_vectorize_id_image(const int32_t* ids, int width, int height, const uint8_t** data, size_t* len) {
+  // Region2D list as RetrieveSegmentation3D emits it after SortRegions2DById: one region per id,
+  // scan intervals in scan order.
+  thread_local std::string wire;
+  std::map<int, vso::Region2D> by_id;
+  for (int y = 0; y < height; ++y) {
+    const int32_t* row = ids + (size_t)y * width;
+    for (int x = 0; x < width;) {
+      int x2 = x;
+      while (x2 + 1 < width && row[x2 + 1] == row[x]) ++x2;
+      if (row[x] < 0) return -1;
+      vso::Region2D& r = by_id[row[x]];
+      r.id = row[x];
+      r.raster.push_back(vso::ScanInterval{y, x, x2});
+      x = x2 + 1;
+    }
+  }
+  vso::SegmentationDesc d;
+  d.frame_width = width;
+  d.frame_height = height;
+  for (auto& kv : by_id) {
+    vso::ShapeMomentsFromRasterization(kv.second.raster, &kv.second.shape_moments);
+    d.region.push_back(std::move(kv.second));
+  }
+  vso::ComputeFrameVectorization(&d);
+  wire = vso::wire::Encode(d);
+  *data = reinterpret_cast<const uint8_t*>(wire.data());
+  *len = wire.size();
+  return 0;
+}
+
 void vso_default_options(vso_options* o) {
   o->presmoothing = 2;
   o->frac_min_region_size = 0.01f;
@@ -1896,6 +1966,7 @@ void vso_default_options(vso_options* o) {
   o->enforce_spatial_connectedness = 1;
   o->color_distance = 1;
   o->two_stage_oversegment = 0;
+  o->compute_vectorization = 0;
 }
 
 vso_stream* vso_stream_create(const vso_options* o, int width, int height) {

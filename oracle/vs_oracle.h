@@ -40,6 +40,8 @@ typedef struct vso_options {
   int enforce_spatial_connectedness; /* 1 */
   int color_distance;           /* 0 = L1, 1 = L2 */
   int two_stage_oversegment;    /* 0; 1 = SegmentGraphSpatially before SegmentFullGraph */
+  int compute_vectorization;    /* 0; 1 = BoundaryComputation + vector mesh in every result
+                                   (segmentation.cpp:527-532; seg_tree --over_segment) */
 } vso_options;
 
 void vso_default_options(vso_options* o);
@@ -47,6 +49,11 @@ void vso_default_options(vso_options* o);
  * n > 1 = the reference's defaults, i.e. one thread per Add*Edges call of the graph construction
  * (dense_segmentation_graph.cpp:31) and an n-way row-parallel bilateral filter. */
 void vso_set_threads(int n);
+
+/* Mirror of vsg_vectorize_id_image: the SegmentationDesc (Region2D list sorted by id, boundaries
+ * vectorised) of a frame given as a W*H region-id image.  *data is valid until the thread's next
+ * call. */
+int vso_vectorize_id_image(const int32_t* ids, int width, int height, const uint8_t** data, size_t* len);
 
 /* ---- streaming level: DenseSegmentation::ProcessFrame ------------------------------- */
 vso_stream* vso_stream_create(const vso_options* o, int width, int height);

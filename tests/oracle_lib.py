@@ -25,6 +25,7 @@ class VsoOptions(C.Structure):
         ("enforce_spatial_connectedness", C.c_int),
         ("color_distance", C.c_int),
         ("two_stage_oversegment", C.c_int),
+        ("compute_vectorization", C.c_int),
     ]
 
 
@@ -75,6 +76,8 @@ def lib():
     L.vso_bilateral_tables.argtypes = [C.c_float, C.c_float, vp, vp]
     L.vso_spatial_buckets.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     L.vso_temporal_buckets.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.vso_vectorize_id_image.restype = C.c_int
+    L.vso_vectorize_id_image.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.vso_graph_create.restype = vp
     L.vso_graph_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.vso_graph_destroy.argtypes = [vp]
@@ -220,6 +223,16 @@ class OracleStream:
         for (bgr, flow, flush) in held or []:
             n = self._process_frame(bgr, flow, flush)
             assert n == 0, "the frame that completes the chunk has to follow the halo"
+
+
+def vectorize_id_image(ids):
+    """Serialized SegmentationDesc (Region2D list sorted by id + vectorization + vector mesh) of a
+    frame given as an H x W region-id image (mirror of vsg_vectorize_id_image)."""
+    ids = np.ascontiguousarray(ids, np.int32)
+    p, n = C.c_void_p(), C.c_size_t()
+    rc = lib().vso_vectorize_id_image(_ptr(ids), ids.shape[1], ids.shape[0], C.byref(p), C.byref(n))
+    assert rc == 0
+    return C.string_at(p, n.value)
 
 
 def preprocess(bgr, presmoothing=2):

@@ -1,9 +1,17 @@
 """Boundary vectorisation (`seg_tree_sample --over_segment` sets
-compute_vectorization): the host C++ implementation in the product library against the
-plain-Python oracle (tests/boundary_oracle.py), as geometry.  The CPU tests go through the
-host-only C entry point vsg_vectorize_id_image; the GPU test runs the dense unit with
-compute_vectorization and checks every frame's vector data against the oracle on that frame's own
-region-id image, and that everything else in the message is unchanged by the option."""
+compute_vectorization): the host C++ implementation in the product library against
+
+* the C++ oracle (oracle/vs_oracle_boundary.inc, an independent restatement that follows the
+  reference's BoundaryComputation member by member, with cv::approxPolyDP restated in its other
+  published form): the serialized SegmentationDesc BYTE FOR BYTE -- polygon start points, hole
+  order (the iteration order of the reference's hash map), vector mesh order included;
+* the plain-Python oracle (tests/boundary_oracle.py), as geometry up to polygon rotation.
+
+Parity stays unpinned for this row (approxPolyDP and the hash-map order come from outside the
+reference tree); what these tests pin is that two independent restatements agree.
+The CPU tests go through the host-only C entry points vsg_vectorize_id_image /
+vso_vectorize_id_image; the GPU test runs the dense unit with compute_vectorization against the
+oracle stream with the same option."""
 import ctypes as C
 
 import numpy as np
@@ -81,6 +89,62 @@ CASES = {
 }
 
 
+def product_bytes(ids):
+    from video_segment_amd import _lib
+    ids = np.ascontiguousarray(ids, np.int32)
+    p, n = C.c_void_p(), C.c_size_t()
+    _lib.check(_lib.lib().vsg_vectorize_id_image(ids.ctypes.data_as(C.c_void_p), ids.shape[1],
+                                                 ids.shape[0], C.byref(p), C.byref(n)))
+    return C.string_at(p, n.value)
+
+
+def _holes_case(rng, W, H, k):
+    """A partition with islands: rectangles of new ids dropped into a Voronoi partition, some of
+    them nested, some touching -- regions with several holes, holes with several neighbours."""
+    ids = _voronoi(rng, W, H, k)
+    nxt = int(ids.max()) + 1
+    for _ in range(int(rng.integers(3, 9))):
+        w, h = int(rng.integers(2, 9)), int(rng.integers(2, 8))
+        x, y = int(rng.integers(1, W - w - 1)), int(rng.integers(1, H - h - 1))
+        ids[y:y + h, x:x + w] = nxt
+        nxt += 1
+    # components of equal id must be N4-connected regions of their own: relabel
+    from scipy import ndimage
+    out = np.zeros_like(ids)
+    n = 0
+    for v in np.unique(ids):
+        comp, c = ndimage.label(ids == v)
+        for q in range(1, c + 1):
+            out[comp == q] = n
+            n += 1
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_vectorization_bytes_match_cpp_oracle_small(name):
+    import oracle_lib as ol
+    ids = CASES[name]
+    assert product_bytes(ids) == ol.vectorize_id_image(ids)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_vectorization_bytes_match_cpp_oracle_random(seed):
+    """Byte equality, not rotation-canonicalised geometry: which vertex a hole polygon starts at and
+    the order of the holes follow the iteration order of the segment hash map, and the vector mesh
+    lists the points in order of first use."""
+    import oracle_lib as ol
+    rng = np.random.default_rng(100 + seed)
+    W, H = int(rng.integers(24, 90)), int(rng.integers(20, 70))
+    ids = _holes_case(rng, W, H, int(rng.integers(4, 20))) if seed % 2 else _voronoi(rng, W, H, int(rng.integers(3, 30)))
+    got, want = product_bytes(ids), ol.vectorize_id_image(ids)
+    assert got == want
+    m = build_schema()()
+    m.ParseFromString(got)
+    if seed in (1, 3, 9):   # (these partitions are known to contain holes: the hole path is covered)
+        assert any(p.hole for r in m.region for p in r.vectorization.polygon)
+    assert decoded_geometry(m) == oracle_geometry(ids)
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_vectorization_small_cases(name):
     ids = CASES[name]
@@ -140,6 +204,7 @@ def test_dense_unit_with_compute_vectorization():
     g = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, compute_vectorization=1),
                               has_flow=True)
     o = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
+    ov = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk, compute_vectorization=1), has_flow=True)
     fl = synth.const_flow(W, H)
     Msg = build_schema()
     frames = 0
@@ -148,8 +213,10 @@ def test_dense_unit_with_compute_vectorization():
         frame = synth.bench_frame(W, H, k)
         ng = g.process_frame(frame, f, flush=(k == N - 1))
         no = o.process_frame(frame, f, flush=(k == N - 1))
-        assert ng == no
+        assert ng == no and ov.process_frame(frame, f, flush=(k == N - 1)) == no
         for i in range(ng):
+            # the whole message, vector data included, against the oracle with the same option
+            assert g.result_bytes(i) == ov.result_bytes(i)
             m = Msg()
             m.ParseFromString(g.result_bytes(i))
             assert m.HasField("vector_mesh") and len(m.vector_mesh.coord) > 0

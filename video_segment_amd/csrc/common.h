@@ -65,8 +65,10 @@ class DevBuf {
     VSG_HIP(hipMalloc(reinterpret_cast<void**>(&p_), n * sizeof(T)));
     n_ = n;
   }
+  // Grows with slack: sizes that drift from chunk to chunk (intervals, pairs, runs) must not cost
+  // a hipFree + hipMalloc -- both synchronise the whole device -- every time they tick up.
   void ensure(size_t n) {
-    if (n > n_) alloc(n);
+    if (n > n_) alloc(n + n / 8 + 256);
   }
   void release() {
     if (p_) (void)hipFree(p_);

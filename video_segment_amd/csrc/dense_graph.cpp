@@ -19,6 +19,12 @@
 namespace vsg {
 
 namespace {
+// Persistent scratch that only ever grows (with slack): no hipMalloc / hipFree in the steady state.
+template <class T>
+DevBuf<T>& Grow(DevBuf<T>& b, size_t n) {
+  if (b.size() < n) b.alloc(n + n / 2 + 1024);
+  return b;
+}
 double NowMs() {
   using clk = std::chrono::steady_clock;
   return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
@@ -891,8 +897,11 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
   }
   const int u = (int)u_ids.size();
   if (u == 0) return;
-  DevBuf<int32_t> d_ids(u), d_par(u), d_cons(u), d_fl(u);
-  DevBuf<float4> d_ds(u);
+  // (persistent scratch: a hipFree per call would synchronise the whole device, i.e. every other
+  // stream of the GPU as well)
+  DevBuf<int32_t>&d_ids = Grow(mc_ids_, u), &d_par = Grow(mc_par_, u), &d_cons = Grow(mc_cons_, u),
+                 &d_fl = Grow(mc_fl_, u);
+  DevBuf<float4>& d_ds = Grow(mc_ds_, u);
   H2D(d_ids.get(), u_ids.data(), (size_t)u, stream_);
   H2D(d_par.get(), u_parent.data(), (size_t)u, stream_);
   H2D(d_cons.get(), u_cons.data(), (size_t)u, stream_);
@@ -1234,8 +1243,8 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
   // 8. DetermineNeighborIds: relabel split tubes on the device, then collect region pairs.
   const int n_rl = (int)rl_ty.size();
   if (n_rl > 0) {
-    DevBuf<uint32_t> d_ty((size_t)n_rl);
-    DevBuf<int32_t> d_lx((size_t)n_rl), d_rx((size_t)n_rl), d_nl((size_t)n_rl);
+    DevBuf<uint32_t>& d_ty = Grow(rl_ty_, n_rl);
+    DevBuf<int32_t>&d_lx = Grow(rl_lx_, n_rl), &d_rx = Grow(rl_rx_, n_rl), &d_nl = Grow(rl_nl_, n_rl);
     H2D(d_ty.get(), rl_ty.data(), (size_t)n_rl, stream_);
     H2D(d_lx.get(), rl_lx.data(), (size_t)n_rl, stream_);
     H2D(d_rx.get(), rl_rx.data(), (size_t)n_rl, stream_);
@@ -1288,8 +1297,8 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
   unseen.erase(std::unique(unseen.begin(), unseen.end()), unseen.end());
   if (!unseen.empty()) {
     const int U = (int)unseen.size();
-    DevBuf<int32_t> d_keys((size_t)U);
-    DevBuf<unsigned long long> d_min((size_t)U);
+    DevBuf<int32_t>& d_keys = Grow(un_keys_, U);
+    DevBuf<unsigned long long>& d_min = Grow(un_min_, U);
     H2D(d_keys.get(), unseen.data(), (size_t)U, stream_);
     VSG_HIP(hipMemsetAsync(d_min.get(), 0xFF, (size_t)U * sizeof(unsigned long long), stream_));
     LaunchFirstOrderOfKeys(pairs_.get(), order_keys_.get(), count, d_keys.get(), U, d_min.get(),

@@ -176,6 +176,11 @@ class DenseGraphHip {
   DevBuf<unsigned long long> pairs_, order_keys_, pairs_sorted_, pairs_unique_;
   DevBuf<int32_t> small_i32_a_, small_i32_b_, small_i32_c_;
   DevBuf<float4> small_f4_;
+  // persistent small scratch (MergeConstrainedRegions write-back, tube relabelling, unseen keys)
+  DevBuf<int32_t> mc_ids_, mc_par_, mc_cons_, mc_fl_, rl_lx_, rl_rx_, rl_nl_, un_keys_;
+  DevBuf<float4> mc_ds_;
+  DevBuf<uint32_t> rl_ty_;
+  DevBuf<unsigned long long> un_min_;
   std::vector<hipEvent_t> ev_pool_;
   std::vector<std::pair<int, int>> ev_wave_, ev_filter_, ev_spine_;
   int ev_used_ = 0;
