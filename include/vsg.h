@@ -181,6 +181,50 @@ int vsg_chain_send_halo(vsg_chain* c, vsg_stream* from, int dst);
 int vsg_chain_recv_halo(vsg_chain* c, vsg_stream* into, int src);
 int vsg_chain_exchange_halo(vsg_chain* c, vsg_stream* from, int dst, vsg_stream* into, int src);
 
+/* ---- hierarchical stage: RegionSegmentation (BASELINE configs[4]) ------ */
+/* segmentation::RegionSegmentation (segmentation/region_segmentation.h:131-216), called by
+ * RegionSegmentationUnit::ProcessFrame / PostProcess (segmentation_unit.cpp:236-279): consumes the
+ * dense unit's SegmentationDesc per frame together with the frame (and its backward flow) and
+ * emits SegmentationDesc messages that carry the whole region hierarchy.  Host code, host memory:
+ * the clustering works on a few thousand regions per chunk set (see region_segmentation.h); no HIP
+ * device is needed for these entry points. */
+typedef struct vsg_regionseg vsg_regionseg;
+/* Mirrors segmentation::RegionSegmentationOptions (region_segmentation.h:41-83; save_descriptors
+ * is not supported). */
+typedef struct vsg_regionseg_options {
+  int min_region_num;             /* 10    */
+  int max_region_num;             /* 10000 */
+  float level_cutoff_fraction;    /* 0.8f  */
+  float small_region_penalizer;   /* 0.25f */
+  int luminance_bins;             /* 10 */
+  int color_bins;                 /* 20 */
+  int flow_bins;                  /* 16 */
+  int chunk_set_size;             /* 6: over-segmentation chunks per chunk set        */
+  int chunk_set_overlap;          /* 2 */
+  int constraint_chunks;          /* 1 */
+  int use_appearance;             /* 1 */
+  int use_flow;                   /* 1: RegionSegmentationUnit sets it to "a flow stream exists" */
+  int use_size_penalizer;         /* 1 */
+  int compute_vectorization;      /* 1 */
+} vsg_regionseg_options;
+void vsg_regionseg_default_options(vsg_regionseg_options* o);
+int vsg_regionseg_create(const vsg_regionseg_options* o, int width, int height, vsg_regionseg** out);
+void vsg_regionseg_destroy(vsg_regionseg* r);
+/* int RegionSegmentation::ProcessFrame(flush, segmentation, features, results), cpp:97-205.
+ *   seg_desc : this frame's serialized over-segmentation (what vsg_stream_result_bytes returns),
+ *              NULL together with bgr for a pure flush;
+ *   bgr      : H rows of W BGR24 pixels `stride` bytes apart, host memory;
+ *   flow     : W*H interleaved (x, y) f32 backward flow of the frame, or NULL (the first frame has
+ *              none: segmentation_unit.cpp:314-323; always NULL with use_flow == 0).
+ * VSG_ERR_INVALID where the reference aborts (glog CHECK), including the one plain input can reach:
+ * two neighbouring regions at distance exactly 1.0 (region_segmentation_graph.cpp:165, see
+ * region_segmentation.cpp). */
+int vsg_regionseg_process_frame(vsg_regionseg* r, int flush, const uint8_t* seg_desc, size_t seg_len,
+                             const uint8_t* bgr, size_t stride, const float* flow, int* num_results);
+int vsg_regionseg_result_bytes(vsg_regionseg* r, int i, const uint8_t** data, size_t* len);
+/* Parity hook: cv::cvtColor(BGR -> Lab, 8 bit) as the stage computes it; lab: W*H*3, rows packed. */
+int vsg_bgr_to_lab(const uint8_t* bgr, size_t stride, int width, int height, uint8_t* lab);
+
 /* ---- seam 3: DenseSegGraphInterface ------------------------------------------------------- */
 /* CreateDenseSegGraph(frame_width, frame_height, max_frames) + InitializeGraph(),
  * dense_seg_graph_interface.h:46-48,112; l1 selects DistanceColorL1 (dense_segmentation.cpp:247-251). */

@@ -20,10 +20,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <list>
 #include <map>
 #include <memory>
 #include <numeric>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -1548,6 +1551,7 @@ static void SegmentationDescToIdImage(const SegmentationDesc& seg, int W, int32_
 }
 
 #include "vs_oracle_boundary.inc"
+#include "vs_oracle_region.inc"
 
 // ------------------------------------------------------------------------------------------
 // Segmentation (over-segmentation half), segmentation/segmentation.cpp.
@@ -1914,6 +1918,12 @@ struct vso_stream {
   std::vector<std::string> encoded;
 };
 
+struct vso_region {
+  std::unique_ptr<vso::RegionSegmentation> rs;
+  std::vector<std::unique_ptr<vso::SegmentationDesc>> results;
+  std::vector<std::string> encoded;
+};
+
 struct vso_graph {
   std::unique_ptr<vso::DenseGraph> g;
   vso::RegionInfoList regions;
@@ -1924,6 +1934,78 @@ struct vso_graph {
 extern "C" {
 
 void vso_set_threads(int n) { vso::g_threads = n < 1 ? 1 : n; }
+
+void vso_region_default_options(vso_region_options* o) {
+  vso::RegionSegOptions d;
+  o->min_region_num = d.min_region_num;
+  o->max_region_num = d.max_region_num;
+  o->level_cutoff_fraction = d.level_cutoff_fraction;
+  o->small_region_penalizer = d.small_region_penalizer;
+  o->luminance_bins = d.luminance_bins;
+  o->color_bins = d.color_bins;
+  o->flow_bins = d.flow_bins;
+  o->chunk_set_size = d.chunk_set_size;
+  o->chunk_set_overlap = d.chunk_set_overlap;
+  o->constraint_chunks = d.constraint_chunks;
+  o->use_appearance = d.use_appearance;
+  o->use_flow = d.use_flow;
+  o->use_size_penalizer = d.use_size_penalizer;
+  o->compute_vectorization = d.compute_vectorization;
+}
+
+vso_region* vso_region_create(const vso_region_options* o, int width, int height) {
+  vso::RegionSegOptions d;
+  d.min_region_num = o->min_region_num;
+  d.max_region_num = o->max_region_num;
+  d.level_cutoff_fraction = o->level_cutoff_fraction;
+  d.small_region_penalizer = o->small_region_penalizer;
+  d.luminance_bins = o->luminance_bins;
+  d.color_bins = o->color_bins;
+  d.flow_bins = o->flow_bins;
+  d.chunk_set_size = o->chunk_set_size;
+  d.chunk_set_overlap = o->chunk_set_overlap;
+  d.constraint_chunks = o->constraint_chunks;
+  d.use_appearance = o->use_appearance != 0;
+  d.use_flow = o->use_flow != 0;
+  d.use_size_penalizer = o->use_size_penalizer != 0;
+  d.compute_vectorization = o->compute_vectorization != 0;
+  vso_region* r = new vso_region;
+  r->rs.reset(new vso::RegionSegmentation(d, width, height));
+  return r;
+}
+
+void vso_region_destroy(vso_region* r) { delete r; }
+
+int vso_region_process_frame(vso_region* r, int flush, const uint8_t* seg_desc, size_t seg_len,
+                             const uint8_t* bgr, size_t stride, const float* flow) {
+  r->results.clear();
+  r->encoded.clear();
+  try {
+    if (seg_desc) {
+      vso::SegmentationDesc d;
+      if (!vso::wire::Decode(seg_desc, seg_len, &d)) return -1;
+      r->rs->ProcessFrame(flush != 0, &d, bgr, stride, flow, &r->results);
+    } else {
+      r->rs->ProcessFrame(flush != 0, nullptr, nullptr, 0, nullptr, &r->results);
+    }
+  } catch (const vso::ReferenceCheckFailed& e) {
+    std::fprintf(stderr, "vs_oracle: the reference aborts here: %s\n", e.what());
+    return -2;
+  }
+  for (const auto& d : r->results) r->encoded.push_back(vso::wire::Encode(*d));
+  return (int)r->results.size();
+}
+
+int vso_region_result_bytes(const vso_region* r, int i, const uint8_t** data, size_t* len) {
+  if (i < 0 || i >= (int)r->encoded.size()) return -1;
+  *data = reinterpret_cast<const uint8_t*>(r->encoded[(size_t)i].data());
+  *len = r->encoded[(size_t)i].size();
+  return 0;
+}
+
+void vso_bgr_to_lab(const uint8_t* bgr, size_t stride, int width, int height, uint8_t* lab) {
+  vso::cvlab::BgrToLab8(bgr, stride, width, height, lab);
+}
 
 int vso_vectorize_id_image(const int32_t* ids, int width, int height, const uint8_t** data, size_t* len) {
   // Region2D list as RetrieveSegmentation3D emits it after SortRegions2DById: one region per id,

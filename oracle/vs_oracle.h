@@ -50,6 +50,35 @@ void vso_default_options(vso_options* o);
  * (dense_segmentation_graph.cpp:31) and an n-way row-parallel bilateral filter. */
 void vso_set_threads(int n);
 
+/* ---- hierarchical stage: RegionSegmentation::ProcessFrame (segmentation/region_segmentation.h) -- */
+typedef struct vso_region vso_region;
+/* Mirrors RegionSegmentationOptions (region_segmentation.h:41-83; save_descriptors not supported). */
+typedef struct vso_region_options {
+  int min_region_num;            /* 10 */
+  int max_region_num;            /* 10000 */
+  float level_cutoff_fraction;   /* 0.8f */
+  float small_region_penalizer;  /* 0.25f */
+  int luminance_bins, color_bins, flow_bins;                      /* 10, 20, 16 */
+  int chunk_set_size, chunk_set_overlap, constraint_chunks;       /* 6, 2, 1 */
+  int use_appearance, use_flow, use_size_penalizer;               /* 1, 1, 1 */
+  int compute_vectorization;                                      /* 1 */
+} vso_region_options;
+void vso_region_default_options(vso_region_options* o);
+vso_region* vso_region_create(const vso_region_options* o, int width, int height);
+void vso_region_destroy(vso_region* r);
+/* seg_desc: the serialized SegmentationDesc of this frame's over-segmentation (NULL together with
+ * bgr for a pure flush); bgr: the frame (H rows, `stride` bytes apart); flow: W*H*2 f32 or NULL
+ * (first frame / no flow stream; use_flow says whether a flow descriptor exists at all).
+ * Returns the number of hierarchical SegmentationDesc now available, -1 on a malformed message,
+ * -2 where the reference itself aborts on this input (a glog CHECK in
+ * RegionAgglomerationGraph::SegmentGraph, region_segmentation_graph.cpp:165, reachable when two
+ * adjacent regions have distance exactly 1.0 -- see vs_oracle_region.inc). */
+int vso_region_process_frame(vso_region* r, int flush, const uint8_t* seg_desc, size_t seg_len,
+                             const uint8_t* bgr, size_t stride, const float* flow);
+int vso_region_result_bytes(const vso_region* r, int i, const uint8_t** data, size_t* len);
+/* cv::cvtColor(BGR -> Lab) for 8-bit frames as restated by the oracle (parity unpinned). */
+void vso_bgr_to_lab(const uint8_t* bgr, size_t stride, int width, int height, uint8_t* lab);
+
 /* Mirror of vsg_vectorize_id_image: the SegmentationDesc (Region2D list sorted by id, boundaries
  * vectorised) of a frame given as a W*H region-id image.  *data is valid until the thread's next
  * call. */

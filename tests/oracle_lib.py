@@ -29,6 +29,17 @@ class VsoOptions(C.Structure):
     ]
 
 
+class VsoRegionOptions(C.Structure):
+    _fields_ = [
+        ("min_region_num", C.c_int), ("max_region_num", C.c_int),
+        ("level_cutoff_fraction", C.c_float), ("small_region_penalizer", C.c_float),
+        ("luminance_bins", C.c_int), ("color_bins", C.c_int), ("flow_bins", C.c_int),
+        ("chunk_set_size", C.c_int), ("chunk_set_overlap", C.c_int), ("constraint_chunks", C.c_int),
+        ("use_appearance", C.c_int), ("use_flow", C.c_int), ("use_size_penalizer", C.c_int),
+        ("compute_vectorization", C.c_int),
+    ]
+
+
 def build_oracle(force=False):
     src = os.path.join(ORACLE_DIR, "vs_oracle.cpp")
     if (force or not os.path.exists(_LIB_PATH)
@@ -78,6 +89,15 @@ def lib():
     L.vso_temporal_buckets.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.vso_vectorize_id_image.restype = C.c_int
     L.vso_vectorize_id_image.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.vso_region_default_options.argtypes = [C.POINTER(VsoRegionOptions)]
+    L.vso_region_create.restype = vp
+    L.vso_region_create.argtypes = [C.POINTER(VsoRegionOptions), C.c_int, C.c_int]
+    L.vso_region_destroy.argtypes = [vp]
+    L.vso_region_process_frame.restype = C.c_int
+    L.vso_region_process_frame.argtypes = [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t, vp]
+    L.vso_region_result_bytes.restype = C.c_int
+    L.vso_region_result_bytes.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.vso_bgr_to_lab.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp]
     L.vso_graph_create.restype = vp
     L.vso_graph_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.vso_graph_destroy.argtypes = [vp]
@@ -223,6 +243,56 @@ class OracleStream:
         for (bgr, flow, flush) in held or []:
             n = self._process_frame(bgr, flow, flush)
             assert n == 0, "the frame that completes the chunk has to follow the halo"
+
+
+def region_options(**kw):
+    o = VsoRegionOptions()
+    lib().vso_region_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def bgr_to_lab(bgr):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    out = np.empty_like(bgr)
+    lib().vso_bgr_to_lab(_ptr(bgr), bgr.strides[0], bgr.shape[1], bgr.shape[0], _ptr(out))
+    return out
+
+
+class OracleRegionSegmentation:
+    """RegionSegmentation restatement (hierarchical stage on top of the over-segmentation)."""
+
+    def __init__(self, width, height, options=None):
+        self.W, self.H = width, height
+        self.opts = options if options is not None else region_options()
+        self.h = lib().vso_region_create(C.byref(self.opts), width, height)
+
+    def close(self):
+        if self.h:
+            lib().vso_region_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def process_frame(self, seg_bytes, bgr, flow=None, flush=False):
+        """seg_bytes: serialized SegmentationDesc of the frame (None with bgr None: pure flush)."""
+        if seg_bytes is None:
+            return lib().vso_region_process_frame(self.h, int(flush), None, 0, None, 0, None)
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        if flow is not None:
+            flow = np.ascontiguousarray(flow, np.float32)
+        buf = C.create_string_buffer(seg_bytes, len(seg_bytes))
+        n = lib().vso_region_process_frame(self.h, int(flush), C.cast(buf, C.c_void_p), len(seg_bytes),
+                                           _ptr(bgr), bgr.strides[0], _ptr(flow))
+        assert n != -1, "malformed SegmentationDesc"
+        return n   # -2: the reference aborts on this input (see vs_oracle.h)
+
+    def result_bytes(self, i):
+        p, n = C.c_void_p(), C.c_size_t()
+        assert lib().vso_region_result_bytes(self.h, i, C.byref(p), C.byref(n)) == 0
+        return C.string_at(p, n.value)
 
 
 def vectorize_id_image(ids):

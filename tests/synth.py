@@ -86,6 +86,26 @@ def blobs_frame(W, H, t, cell=48):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
+def soft_frame(W, H, t):
+    """Input for the hierarchical stage: the bench generator with a LOW-contrast checker (R 110 /
+    140 instead of 40 / 200).  Neighbouring regions then always share colour-histogram bins; on
+    the bench input itself neighbouring checker cells have disjoint Lab histograms, their region
+    distance is exactly 1.0 and the reference's RegionAgglomerationGraph aborts (a glog CHECK,
+    region_segmentation_graph.cpp:165; see oracle/vs_oracle_region.inc)."""
+    x = np.arange(W, dtype=np.int64)[None, :]
+    y = np.arange(H, dtype=np.int64)[:, None]
+    cw = max(1, (16 * W) // 64)
+    ch = max(1, (12 * W) // 64)
+    img = np.empty((H, W, 3), np.int64)
+    img[..., 0] = 96 + (x * 64) // W
+    img[..., 1] = 96 + (y * 64) // H
+    chk = (((x + 2 * t) // cw) % 2) ^ ((y // ch) % 2)
+    img[..., 2] = chk * 30 + 110
+    r = _pcg32_stream(1234 + t, W * H * 3).astype(np.int64).reshape(H, W, 3)
+    img += (r % 7) - 3
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
 def _pcg_hash_t(v):
     """_pcg_hash on a torch int64 tensor holding uint32 values."""
     m = 0xFFFFFFFF
@@ -121,6 +141,14 @@ def frame_torch(kind, W, H, t, device):
         img[..., 1] = ((y * 255) // H).expand(H, W)
         img[..., 2] = 128
         img += (stream(4321 + t) % (2 * amp + 1)) - amp
+    elif kind == "soft":
+        cw = max(1, (16 * W) // 64)
+        ch = max(1, (12 * W) // 64)
+        img[..., 0] = (96 + (x * 64) // W).expand(H, W)
+        img[..., 1] = (96 + (y * 64) // H).expand(H, W)
+        chk = (((x + 2 * t) // cw) % 2) ^ ((y // ch) % 2)
+        img[..., 2] = chk * 30 + 110
+        img += (stream(1234 + t) % 7) - 3
     elif kind == "blobs":
         cell = 48
         gx = (x + 2 * t) // cell
@@ -136,7 +164,7 @@ def frame_torch(kind, W, H, t, device):
     return img.clamp_(0, 255).to(torch.uint8)
 
 
-FRAME_FNS = {"bench": bench_frame, "noise": noise_frame, "blobs": blobs_frame}
+FRAME_FNS = {"bench": bench_frame, "noise": noise_frame, "blobs": blobs_frame, "soft": soft_frame}
 
 
 def const_flow(W, H, fx=-2.0, fy=0.0):

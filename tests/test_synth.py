@@ -6,7 +6,7 @@ import pytest
 import synth
 
 
-@pytest.mark.parametrize("kind", ["bench", "noise", "blobs"])
+@pytest.mark.parametrize("kind", ["bench", "noise", "blobs", "soft"])
 @pytest.mark.parametrize("W,H,t", [(64, 48, 0), (161, 97, 5), (320, 240, 37)])
 def test_torch_generators_match_numpy(kind, W, H, t):
     import torch

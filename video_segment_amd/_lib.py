@@ -57,6 +57,17 @@ class VsgTimings(C.Structure):
     ]
 
 
+class VsgRegionOptions(C.Structure):
+    _fields_ = [
+        ("min_region_num", C.c_int), ("max_region_num", C.c_int),
+        ("level_cutoff_fraction", C.c_float), ("small_region_penalizer", C.c_float),
+        ("luminance_bins", C.c_int), ("color_bins", C.c_int), ("flow_bins", C.c_int),
+        ("chunk_set_size", C.c_int), ("chunk_set_overlap", C.c_int), ("constraint_chunks", C.c_int),
+        ("use_appearance", C.c_int), ("use_flow", C.c_int), ("use_size_penalizer", C.c_int),
+        ("compute_vectorization", C.c_int),
+    ]
+
+
 # Every symbol include/vsg.h declares (checked by tests/test_capi_symbols.py).
 EXPORTED_SYMBOLS = [
     "vsg_last_error", "vsg_version", "vsg_default_options", "vsg_device_count",
@@ -67,6 +78,8 @@ EXPORTED_SYMBOLS = [
     "vsg_stream_import_halo", "vsg_stream_expect_halo", "vsg_stream_restart",
     "vsg_chain_create", "vsg_chain_destroy", "vsg_chain_info", "vsg_chain_send_halo",
     "vsg_chain_recv_halo", "vsg_chain_exchange_halo",
+    "vsg_regionseg_default_options", "vsg_regionseg_create", "vsg_regionseg_destroy", "vsg_regionseg_process_frame",
+    "vsg_regionseg_result_bytes", "vsg_bgr_to_lab",
     "vsg_graph_create", "vsg_graph_destroy", "vsg_graph_add_frame_bgr",
     "vsg_graph_add_frame_features", "vsg_graph_add_virtual_frame", "vsg_graph_add_temporal",
     "vsg_graph_finish_building", "vsg_graph_segment_spatially", "vsg_graph_segment", "vsg_graph_obtain_results",
@@ -133,6 +146,12 @@ def lib():
     L.vsg_chain_destroy.argtypes = [vp]
     L.vsg_chain_send_halo.argtypes = [vp, vp, C.c_int]
     L.vsg_chain_recv_halo.argtypes = [vp, vp, C.c_int]
+    L.vsg_regionseg_default_options.argtypes = [C.POINTER(VsgRegionOptions)]
+    L.vsg_regionseg_create.argtypes = [C.POINTER(VsgRegionOptions), C.c_int, C.c_int, C.POINTER(vp)]
+    L.vsg_regionseg_destroy.argtypes = [vp]
+    L.vsg_regionseg_process_frame.argtypes = [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t, vp, C.POINTER(C.c_int)]
+    L.vsg_regionseg_result_bytes.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.vsg_bgr_to_lab.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp]
     L.vsg_graph_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.vsg_graph_destroy.argtypes = [vp]
     L.vsg_graph_add_frame_bgr.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_int]

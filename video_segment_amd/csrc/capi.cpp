@@ -13,6 +13,7 @@
 #include <thread>
 
 #include "../../include/vsg.h"
+#include "region_segmentation.h"
 #include "stream.h"
 
 namespace {
@@ -83,6 +84,10 @@ struct vsg_stream {
   int device = 0;
   std::unique_ptr<vsg::DenseSegmentationHip> impl;
   std::vector<int32_t> id_image;
+};
+
+struct vsg_regionseg {
+  std::unique_ptr<vsg::RegionSegmentationHost> impl;
 };
 
 struct vsg_graph {
@@ -468,6 +473,83 @@ int vsg_chain_recv_halo(vsg_chain* c, vsg_stream* into, int src) {
     return VSG_ERR_INVALID;
   }
   return vsg_chain_exchange_halo(c, nullptr, -1, into, src);
+}
+
+// ---- hierarchical region segmentation (host) -------------------------------------------------
+void vsg_regionseg_default_options(vsg_regionseg_options* o) {
+  const vsg::RegionSegOptions d;
+  o->min_region_num = d.min_region_num;
+  o->max_region_num = d.max_region_num;
+  o->level_cutoff_fraction = d.level_cutoff_fraction;
+  o->small_region_penalizer = d.small_region_penalizer;
+  o->luminance_bins = d.luminance_bins;
+  o->color_bins = d.color_bins;
+  o->flow_bins = d.flow_bins;
+  o->chunk_set_size = d.chunk_set_size;
+  o->chunk_set_overlap = d.chunk_set_overlap;
+  o->constraint_chunks = d.constraint_chunks;
+  o->use_appearance = d.use_appearance;
+  o->use_flow = d.use_flow;
+  o->use_size_penalizer = d.use_size_penalizer;
+  o->compute_vectorization = d.compute_vectorization;
+}
+
+int vsg_regionseg_create(const vsg_regionseg_options* o, int width, int height, vsg_regionseg** out) {
+  return Guard([&] {
+    VSG_REQUIRE(o && out, VSG_ERR_INVALID, "null argument");
+    vsg::RegionSegOptions d;
+    d.min_region_num = o->min_region_num;
+    d.max_region_num = o->max_region_num;
+    d.level_cutoff_fraction = o->level_cutoff_fraction;
+    d.small_region_penalizer = o->small_region_penalizer;
+    d.luminance_bins = o->luminance_bins;
+    d.color_bins = o->color_bins;
+    d.flow_bins = o->flow_bins;
+    d.chunk_set_size = o->chunk_set_size;
+    d.chunk_set_overlap = o->chunk_set_overlap;
+    d.constraint_chunks = o->constraint_chunks;
+    d.use_appearance = o->use_appearance != 0;
+    d.use_flow = o->use_flow != 0;
+    d.use_size_penalizer = o->use_size_penalizer != 0;
+    d.compute_vectorization = o->compute_vectorization != 0;
+    std::unique_ptr<vsg_regionseg> r(new vsg_regionseg);
+    r->impl.reset(new vsg::RegionSegmentationHost(d, width, height));
+    *out = r.release();
+  });
+}
+
+void vsg_regionseg_destroy(vsg_regionseg* r) { delete r; }
+
+int vsg_regionseg_process_frame(vsg_regionseg* r, int flush, const uint8_t* seg_desc, size_t seg_len,
+                             const uint8_t* bgr, size_t stride, const float* flow, int* num_results) {
+  return Guard([&] {
+    VSG_REQUIRE(r && num_results, VSG_ERR_INVALID, "null argument");
+    if (seg_desc) {
+      vsg::SegDesc d;
+      VSG_REQUIRE(vsg::DecodeSegDesc(seg_desc, seg_len, &d), VSG_ERR_INVALID, "malformed SegmentationDesc");
+      *num_results = r->impl->ProcessFrame(flush != 0, &d, bgr, stride, flow);
+    } else {
+      *num_results = r->impl->ProcessFrame(flush != 0, nullptr, bgr, stride, flow);
+    }
+  });
+}
+
+int vsg_regionseg_result_bytes(vsg_regionseg* r, int i, const uint8_t** data, size_t* len) {
+  return Guard([&] {
+    VSG_REQUIRE(r && data && len, VSG_ERR_INVALID, "null argument");
+    VSG_REQUIRE(i >= 0 && i < r->impl->num_results(), VSG_ERR_INVALID, "result index");
+    const std::string& b = r->impl->result_bytes(i);
+    *data = reinterpret_cast<const uint8_t*>(b.data());
+    *len = b.size();
+  });
+}
+
+int vsg_bgr_to_lab(const uint8_t* bgr, size_t stride, int width, int height, uint8_t* lab) {
+  return Guard([&] {
+    VSG_REQUIRE(bgr && lab && width >= 1 && height >= 1 && stride >= (size_t)width * 3, VSG_ERR_INVALID,
+                "bad argument");
+    vsg::BgrToLab8(bgr, stride, width, height, lab);
+  });
 }
 
 // ---- graph -------------------------------------------------------------------------------

@@ -57,6 +57,9 @@ struct Region2DOut {
 struct CompoundOut {
   int id = 0, size = 0;
   std::vector<int> neighbor_ids;
+  bool has_parent = false;        // CompoundRegion.parent_id is set (every level but the top one)
+  int parent_id = -1;
+  std::vector<int> child_ids;     // CompoundRegion.child_id (levels above the over-segmentation)
   int start_frame = 0, end_frame = 0;
 };
 
@@ -64,6 +67,9 @@ struct SegDesc {
   std::vector<Region2DOut> regions;
   bool has_hierarchy = false;
   std::vector<CompoundOut> hierarchy0;
+  // SegmentationDesc.hierarchy beyond level 0 (hierarchical RegionSegmentation; empty for the
+  // dense unit): upper_levels[l - 1] = HierarchyLevel l.
+  std::vector<std::vector<CompoundOut>> upper_levels;
   int frame_width = 0, frame_height = 0;
   int chunk_size = 0, overlap_start = 0, chunk_id = -1, hierarchy_frame_idx = 0;
   int connectedness = 1;   // N4_CONNECT = 1, N8_CONNECT = 2
@@ -116,6 +122,10 @@ void SplitRegionIntoTubes(const Raster3D& raster, int W, int H,
 
 // proto2 wire encoding of SegmentationDesc (field order = field number order).
 std::string EncodeSegDesc(const SegDesc& d);
+// ... and decoding of what a consumer of the dense unit's output needs: Region2D ids and
+// rasterizations, the hierarchy levels, the frame / chunk fields (shape moments and vector data are
+// recomputed by whoever needs them).  Returns false on a malformed message.
+bool DecodeSegDesc(const uint8_t* data, size_t len, SegDesc* d);
 // Renders the Region2D ids into a W*H image (SegmentationDescToIdImage, level 0).
 void RenderIdImage(const SegDesc& d, int W, int32_t* out);
 

@@ -631,16 +631,23 @@ std::string EncodeSegDesc(const SegDesc& d) {
   }
   if (d.has_hierarchy) {
     std::string level, c;
-    for (const CompoundOut& cr : d.hierarchy0) {
-      c.clear();
-      PutInt(&c, 1, cr.id);
-      PutInt(&c, 2, cr.size);
-      for (int n : cr.neighbor_ids) PutInt(&c, 3, n);
-      PutInt(&c, 6, cr.start_frame);
-      PutInt(&c, 7, cr.end_frame);
-      PutMsg(&level, 2, c);                         // HierarchyLevel.region = 2
-    }
-    PutMsg(&out, 3, level);                         // SegmentationDesc.hierarchy = 3
+    auto put_level = [&](const std::vector<CompoundOut>& regions) {
+      level.clear();
+      for (const CompoundOut& cr : regions) {
+        c.clear();
+        PutInt(&c, 1, cr.id);
+        PutInt(&c, 2, cr.size);
+        for (int n : cr.neighbor_ids) PutInt(&c, 3, n);
+        if (cr.has_parent) PutInt(&c, 4, cr.parent_id);
+        for (int n : cr.child_ids) PutInt(&c, 5, n);
+        PutInt(&c, 6, cr.start_frame);
+        PutInt(&c, 7, cr.end_frame);
+        PutMsg(&level, 2, c);                       // HierarchyLevel.region = 2
+      }
+      PutMsg(&out, 3, level);                       // SegmentationDesc.hierarchy = 3
+    };
+    put_level(d.hierarchy0);
+    for (const auto& lv : d.upper_levels) put_level(lv);
   }
   PutInt(&out, 4, d.frame_width);
   PutInt(&out, 5, d.frame_height);
@@ -659,6 +666,147 @@ std::string EncodeSegDesc(const SegDesc& d) {
   PutInt(&out, 12, d.connectedness);
   (void)VarintLen;
   return out;
+}
+
+namespace {
+// Cursor over a proto2 message.
+struct WireIn {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool bad = false;
+  bool more() const { return !bad && p < end; }
+  uint64_t varint() {
+    uint64_t v = 0;
+    for (int shift = 0; p < end && shift < 64; shift += 7) {
+      const uint8_t b = *p++;
+      v |= (uint64_t)(b & 0x7f) << shift;
+      if (!(b & 0x80)) return v;
+    }
+    bad = true;
+    return 0;
+  }
+  WireIn sub() {
+    const uint64_t n = varint();
+    if (bad || n > (uint64_t)(end - p)) {
+      bad = true;
+      return WireIn{p, p, true};
+    }
+    WireIn s{p, p + n, false};
+    p += n;
+    return s;
+  }
+  void skip(int wire_type) {
+    switch (wire_type) {
+      case 0: (void)varint(); break;
+      case 1: if (end - p < 8) bad = true; else p += 8; break;
+      case 2: (void)sub(); break;
+      case 5: if (end - p < 4) bad = true; else p += 4; break;
+      default: bad = true;
+    }
+  }
+};
+}  // namespace
+
+bool DecodeSegDesc(const uint8_t* data, size_t len, SegDesc* d) {
+  WireIn in{data, data + len};
+  bool first_level = true;
+  while (in.more()) {
+    const uint64_t tag = in.varint();
+    const int field = (int)(tag >> 3), wt = (int)(tag & 7);
+    if (field == 2 && wt == 2) {                      // Region2D
+      WireIn r = in.sub();
+      d->regions.emplace_back();
+      Region2DOut& reg = d->regions.back();
+      while (r.more()) {
+        const uint64_t t = r.varint();
+        if ((t >> 3) == 1 && (t & 7) == 0) {
+          reg.id = (int)(int64_t)r.varint();
+        } else if ((t >> 3) == 3 && (t & 7) == 2) {   // Rasterization
+          WireIn ra = r.sub();
+          while (ra.more()) {
+            const uint64_t t2 = ra.varint();
+            if ((t2 >> 3) != 1 || (t2 & 7) != 2) {
+              ra.skip((int)(t2 & 7));
+              continue;
+            }
+            WireIn si = ra.sub();
+            Interval iv{0, 0, 0};
+            while (si.more()) {
+              const uint64_t t3 = si.varint();
+              if ((t3 & 7) != 0) {
+                si.skip((int)(t3 & 7));
+                continue;
+              }
+              const int v = (int)(int64_t)si.varint();
+              if ((t3 >> 3) == 1) iv.y = v; else if ((t3 >> 3) == 2) iv.lx = v; else if ((t3 >> 3) == 3) iv.rx = v;
+            }
+            ra.bad = ra.bad || si.bad;
+            reg.raster.push_back(iv);
+          }
+          r.bad = r.bad || ra.bad;
+        } else {
+          r.skip((int)(t & 7));
+        }
+      }
+      in.bad = in.bad || r.bad;
+    } else if (field == 3 && wt == 2) {               // HierarchyLevel
+      WireIn h = in.sub();
+      std::vector<CompoundOut>* level;
+      if (first_level) {
+        d->has_hierarchy = true;
+        level = &d->hierarchy0;
+        first_level = false;
+      } else {
+        d->upper_levels.emplace_back();
+        level = &d->upper_levels.back();
+      }
+      while (h.more()) {
+        const uint64_t t = h.varint();
+        if ((t >> 3) != 2 || (t & 7) != 2) {
+          h.skip((int)(t & 7));
+          continue;
+        }
+        WireIn c = h.sub();
+        level->emplace_back();
+        CompoundOut& cr = level->back();
+        while (c.more()) {
+          const uint64_t t2 = c.varint();
+          if ((t2 & 7) != 0) {
+            c.skip((int)(t2 & 7));
+            continue;
+          }
+          const int v = (int)(int64_t)c.varint();
+          switch ((int)(t2 >> 3)) {
+            case 1: cr.id = v; break;
+            case 2: cr.size = v; break;
+            case 3: cr.neighbor_ids.push_back(v); break;
+            case 4: cr.has_parent = true; cr.parent_id = v; break;
+            case 5: cr.child_ids.push_back(v); break;
+            case 6: cr.start_frame = v; break;
+            case 7: cr.end_frame = v; break;
+            default: break;
+          }
+        }
+        h.bad = h.bad || c.bad;
+      }
+      in.bad = in.bad || h.bad;
+    } else if (wt == 0) {
+      const int v = (int)(int64_t)in.varint();
+      switch (field) {
+        case 4: d->frame_width = v; break;
+        case 5: d->frame_height = v; break;
+        case 6: d->chunk_size = v; break;
+        case 7: d->overlap_start = v; break;
+        case 8: d->chunk_id = v; break;
+        case 9: d->hierarchy_frame_idx = v; break;
+        case 12: d->connectedness = v; break;
+        default: break;
+      }
+    } else {
+      in.skip(wt);
+    }
+  }
+  return !in.bad;
 }
 
 void RenderIdImage(const SegDesc& d, int W, int32_t* out) {

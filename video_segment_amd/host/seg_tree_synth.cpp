@@ -33,9 +33,10 @@ uint32_t PcgHash(uint32_t v) {
 // Same generators as tests/synth.py (probe_frame / bench_frame / const_flow).
 class SyntheticVideoUnit : public VideoUnit {
  public:
-  SyntheticVideoUnit(int width, int height, int frames, bool flow, bool bench,
+  // kind: 0 probe, 1 bench, 2 soft (tests/synth.py: soft_frame, the input of the hierarchical stage)
+  SyntheticVideoUnit(int width, int height, int frames, bool flow, int kind,
                      const std::string& save_flow = std::string())
-      : width_(width), height_(height), frames_(frames), flow_(flow), bench_(bench),
+      : width_(width), height_(height), frames_(frames), flow_(flow), bench_(kind != 0), soft_(kind == 2),
         save_flow_(save_flow) {}
 
   bool OpenStreams(StreamSet* set) override {
@@ -67,9 +68,10 @@ class SyntheticVideoUnit : public VideoUnit {
     for (int y = 0; y < height_; ++y) {
       uint8_t* row = d + (size_t)y * width_step_;
       for (int x = 0; x < width_; ++x) {
-        int b = x * 255 / width_, g = y * 255 / height_;
+        int b = soft_ ? 96 + x * 64 / width_ : x * 255 / width_;
+        int g = soft_ ? 96 + y * 64 / height_ : y * 255 / height_;
         const int chk = (((x + 2 * k_) / cw) % 2) ^ ((y / ch) % 2);
-        int r = bench_ ? chk * 160 + 40 : (chk ? 200 : 40);
+        int r = soft_ ? chk * 30 + 110 : (bench_ ? chk * 160 + 40 : (chk ? 200 : 40));
         if (bench_) {
           const uint32_t i = (uint32_t)((y * width_ + x) * 3);
           b += (int)(PcgHash(i + base) % 7u) - 3;
@@ -99,7 +101,7 @@ class SyntheticVideoUnit : public VideoUnit {
 
  private:
   int width_, height_, frames_;
-  bool flow_, bench_;
+  bool flow_, bench_, soft_;
   std::string save_flow_;
   std::unique_ptr<DenseFlowWriter> flow_writer_;
   int width_step_ = 0;
@@ -128,7 +130,10 @@ class HashSinkUnit : public VideoUnit {
         hash_ *= 16777619u;
       }
     }
-    if (frames_ == 0) first_regions_ = desc.NumRegions();
+    if (frames_ == 0) {
+      first_regions_ = desc.NumRegions();
+      first_levels_ = desc.NumHierarchyLevels();
+    }
     total_regions_ += desc.NumRegions();
     bytes_ += desc.wire.size();
     ++frames_;
@@ -137,11 +142,12 @@ class HashSinkUnit : public VideoUnit {
   uint32_t hash() const { return hash_; }
   int frames() const { return frames_; }
   int first_regions() const { return first_regions_; }
+  int first_levels() const { return first_levels_; }
   long total_regions() const { return total_regions_; }
   size_t bytes() const { return bytes_; }
 
  private:
-  int seg_idx_ = -1, width_ = 0, height_ = 0, frames_ = 0, first_regions_ = 0;
+  int seg_idx_ = -1, width_ = 0, height_ = 0, frames_ = 0, first_regions_ = 0, first_levels_ = 0;
   long total_regions_ = 0;
   size_t bytes_ = 0;
   uint32_t hash_ = 2166136261u;
@@ -199,7 +205,11 @@ struct Flags {
   double dense_min_region_size = 0.01;         // frac_min_region_size
   // this driver only
   int width = 64, height = 48, frames = 45, chunk_size = 20, device = -1;
-  std::string input = "probe";     // synthetic generator: probe | bench
+  std::string input = "probe";     // synthetic generator: probe | bench | soft
+  // seg_tree.cpp:219-241 runs the RegionSegmentationUnit unless --over_segment is given; here it is
+  // opt-in, so that the over-segmentation hashes of the default run stay what the pins say
+  bool region_segmentation = false;
+  int chunk_set_size = 6, chunk_set_overlap = 2, min_region_num = 10;
   std::string output_file, flow_file, read_pb;
   std::string flow_output_file;    // DenseFlowOptions::flow_output_file: explicit path for --save_flow
   double pipeline_max_rate = 0;    // seg_tree.cpp:349 uses 20 frames/s for its root
@@ -224,7 +234,7 @@ bool ParseFlags(int argc, char** argv, Flags* f) {
       has_v = true;
     }
     static const char* kBools[] = {"flow", "use_pipeline", "over_segment", "write_to_file", "save_flow",
-                                   "two_stage_oversegment"};
+                                   "two_stage_oversegment", "region_segmentation"};
     bool is_bool = false, negated = false;
     for (const char* b : kBools) {
       if (a == b) is_bool = true;
@@ -249,6 +259,10 @@ bool ParseFlags(int argc, char** argv, Flags* f) {
     else if (a == "write_to_file") f->write_to_file = bv;
     else if (a == "save_flow") f->save_flow = bv;
     else if (a == "two_stage_oversegment") f->two_stage_oversegment = bv;
+    else if (a == "region_segmentation") f->region_segmentation = bv;
+    else if (a == "chunk_set_size") f->chunk_set_size = atoi(v.c_str());
+    else if (a == "chunk_set_overlap") f->chunk_set_overlap = atoi(v.c_str());
+    else if (a == "min_region_num") f->min_region_num = atoi(v.c_str());
     else if (a == "input_file") f->input_file = v;
     else if (a == "dense_smoothing") f->dense_smoothing = v;
     else if (a == "dense_color_dist") f->dense_color_dist = v;
@@ -300,7 +314,7 @@ int main(int argc, char** argv) {
       : FLAGS.save_flow ? (FLAGS.input_file.empty() ? std::string("synth.flow") : input_base + ".flow")
                         : std::string();
   SyntheticVideoUnit source(FLAGS.width, FLAGS.height, frames, use_flow && !flow_from_file,
-                            FLAGS.input == "bench", save_flow);
+                            FLAGS.input == "bench" ? 1 : (FLAGS.input == "soft" ? 2 : 0), save_flow);
   VideoUnit* root = raw_reader ? static_cast<VideoUnit*>(raw_reader.get()) : &source;
   VideoUnit* input = root;
 
@@ -350,6 +364,20 @@ int main(int argc, char** argv) {
   input = &dense_unit;
   if (FLAGS.use_pipeline) cut();
 
+  std::unique_ptr<RegionSegmentationUnit> region_unit;   // seg_tree.cpp:219-241
+  if (FLAGS.region_segmentation && !FLAGS.over_segment) {
+    RegionSegmentationUnitOptions ro;
+    if (!use_flow) ro.flow_stream_name.clear();
+    RegionSegmentationOptions rso;
+    rso.chunk_set_size = FLAGS.chunk_set_size;
+    rso.chunk_set_overlap = FLAGS.chunk_set_overlap;
+    rso.min_region_num = FLAGS.min_region_num;
+    region_unit.reset(new RegionSegmentationUnit(ro, &rso));
+    region_unit->AttachTo(input);
+    input = region_unit.get();
+    if (FLAGS.use_pipeline) cut();
+  }
+
   HashSinkUnit sink;
   sink.AttachTo(input);
   input = &sink;
@@ -382,9 +410,9 @@ int main(int argc, char** argv) {
   if (raw_reader) frames = raw_reader->num_frames();
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::printf("frames=%d first_frame_regions=%d total_regions=%ld label_fnv1a32=%08x bytes=%zu "
-              "seconds=%.3f fps=%.2f pipeline=%d\n",
+              "seconds=%.3f fps=%.2f pipeline=%d hierarchy_levels=%d\n",
               sink.frames(), sink.first_regions(), sink.total_regions(), sink.hash(), sink.bytes(),
-              dt, sink.frames() / dt, FLAGS.use_pipeline ? 1 : 0);
+              dt, sink.frames() / dt, FLAGS.use_pipeline ? 1 : 0, sink.first_levels());
   std::fprintf(stderr, "__SEGMENTATION_FINISHED__\n");
   return sink.frames() == frames ? 0 : 3;
 }

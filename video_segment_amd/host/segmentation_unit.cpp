@@ -107,6 +107,16 @@ int SegmentationDesc::NumRegions() const {
   return top.ok ? n : -1;
 }
 
+int SegmentationDesc::NumHierarchyLevels() const {
+  Cursor top{reinterpret_cast<const uint8_t*>(wire.data()),
+             reinterpret_cast<const uint8_t*>(wire.data()) + wire.size()};
+  int f, wt, n = 0;
+  uint64_t v;
+  Cursor sub{nullptr, nullptr};
+  while (top.Next(&f, &wt, &sub, &v)) n += (f == 3 && wt == 2);   // SegmentationDesc.hierarchy = 3
+  return top.ok ? n : -1;
+}
+
 bool SegmentationDesc::FrameSize(int* width, int* height) const {
   Cursor top{reinterpret_cast<const uint8_t*>(wire.data()),
              reinterpret_cast<const uint8_t*>(wire.data()) + wire.size()};
@@ -297,6 +307,180 @@ void DenseSegmentationUnit::OutputSegmentation(
   }
   // Progress marker parsed by the reference's web front end (segmentation_unit.cpp:177).
   std::fprintf(stderr, "__STREAMING_SIZE__: %d\n", output_frames_);
+}
+
+// ---- RegionSegmentation / RegionSegmentationUnit ---------------------------------------------
+RegionSegmentation::RegionSegmentation(const RegionSegmentationOptions& options, int frame_width, int frame_height)
+    : options_(options) {
+  vsg_regionseg_options o;
+  vsg_regionseg_default_options(&o);
+  o.min_region_num = options.min_region_num;
+  o.max_region_num = options.max_region_num;
+  o.level_cutoff_fraction = options.level_cutoff_fraction;
+  o.small_region_penalizer = options.small_region_penalizer;
+  o.luminance_bins = options.luminance_bins;
+  o.color_bins = options.color_bins;
+  o.flow_bins = options.flow_bins;
+  o.chunk_set_size = options.chunk_set_size;
+  o.chunk_set_overlap = options.chunk_set_overlap;
+  o.constraint_chunks = options.constraint_chunks;
+  o.use_appearance = options.use_appearance;
+  o.use_flow = options.use_flow;
+  o.use_size_penalizer = options.use_size_penalizer;
+  o.compute_vectorization = options.compute_vectorization;
+  if (vsg_regionseg_create(&o, frame_width, frame_height, &handle_) != VSG_OK) handle_ = nullptr;
+}
+
+RegionSegmentation::~RegionSegmentation() { vsg_regionseg_destroy(handle_); }
+
+int RegionSegmentation::ProcessFrame(bool flush, const SegmentationDesc* segmentation,
+                                     const std::vector<MatView>* features,
+                                     std::vector<std::unique_ptr<SegmentationDesc>>* results) {
+  VF_CHECK(handle_ != nullptr, "region segmentation was not created");
+  VF_CHECK((segmentation == nullptr) == (features == nullptr),
+           "Requring both segmentation and features to be either set or null.");
+  int num_results = 0;
+  if (segmentation) {
+    VF_CHECK(!features->empty() && (*features)[0].type == MatView::TYPE_8UC3, "first feature has to be the BGR24 frame");
+    const MatView& image = (*features)[0];
+    const float* flow = nullptr;
+    if (options_.use_flow && features->size() > 1 && !(*features)[1].empty()) {
+      const MatView& fv = (*features)[1];
+      VF_CHECK(fv.type == MatView::TYPE_32FC2 && fv.step == (size_t)fv.cols * 2 * sizeof(float), "flow has to be packed 32FC2");
+      flow = static_cast<const float*>(fv.data);
+    }
+    VF_CHECK(vsg_regionseg_process_frame(handle_, flush ? 1 : 0,
+                                         reinterpret_cast<const uint8_t*>(segmentation->wire.data()),
+                                         segmentation->wire.size(), static_cast<const uint8_t*>(image.data),
+                                         image.step, flow, &num_results) == VSG_OK,
+             vsg_last_error());
+  } else {
+    VF_CHECK(vsg_regionseg_process_frame(handle_, flush ? 1 : 0, nullptr, 0, nullptr, 0, nullptr, &num_results) == VSG_OK,
+             vsg_last_error());
+  }
+  for (int k = 0; k < num_results; ++k) {
+    const uint8_t* data = nullptr;
+    size_t len = 0;
+    VF_CHECK(vsg_regionseg_result_bytes(handle_, k, &data, &len) == VSG_OK, vsg_last_error());
+    std::unique_ptr<SegmentationDesc> desc(new SegmentationDesc);
+    desc->wire.assign(reinterpret_cast<const char*>(data), len);
+    results->push_back(std::move(desc));
+  }
+  return (int)results->size();
+}
+
+RegionSegmentationUnit::RegionSegmentationUnit(const RegionSegmentationUnitOptions& options,
+                                               const RegionSegmentationOptions* region_options)
+    : options_(options) {
+  if (region_options) region_options_ = *region_options;
+  SetRateBufferSize(300);
+}
+
+RegionSegmentationUnit::~RegionSegmentationUnit() {}
+
+bool RegionSegmentationUnit::OpenStreams(StreamSet* set) {
+  video_stream_idx_ = FindStreamIdx(options_.video_stream_name, set);
+  if (video_stream_idx_ < 0) {
+    std::fprintf(stderr, "ERROR: Could not find video stream!\n");
+    return false;
+  }
+  const VideoStream& vid_stream = set->at(video_stream_idx_)->As<VideoStream>();
+  frame_width_ = vid_stream.frame_width();
+  frame_height_ = vid_stream.frame_height();
+  if (vid_stream.pixel_format() != PIXEL_FORMAT_BGR24) {
+    std::fprintf(stderr, "ERROR: Expecting video format to be BGR24.\n");
+    return false;
+  }
+  if (!options_.flow_stream_name.empty()) {
+    flow_stream_idx_ = FindStreamIdx(options_.flow_stream_name, set);
+    if (flow_stream_idx_ < 0) {
+      std::fprintf(stderr, "ERROR: Flow stream specified but not present\n");
+      return false;
+    }
+  } else {
+    flow_stream_idx_ = -1;
+  }
+  seg_stream_idx_ = FindStreamIdx(options_.segment_stream_name, set);
+  if (seg_stream_idx_ < 0) {
+    std::fprintf(stderr, "ERROR: Could not find Segmentation stream!\n");
+    return false;
+  }
+  if (!OpenFeatureStreams(set)) {
+    std::fprintf(stderr, "ERROR: Error opening feature streams!\n");
+    return false;
+  }
+  region_seg_ = CreateRegionSegmentation();
+  if (!region_seg_ || !region_seg_->ok()) {
+    std::fprintf(stderr, "ERROR: could not create the region segmentation: %s\n", vsg_last_error());
+    return false;
+  }
+  return true;
+}
+
+bool RegionSegmentationUnit::OpenFeatureStreams(StreamSet*) { return true; }
+
+std::unique_ptr<RegionSegmentation> RegionSegmentationUnit::CreateRegionSegmentation() {
+  region_options_.use_flow = flow_stream_idx_ >= 0;   // segmentation_unit.cpp:297
+  return std::unique_ptr<RegionSegmentation>(new RegionSegmentation(region_options_, frame_width_, frame_height_));
+}
+
+void RegionSegmentationUnit::ExtractFrameSetFeatures(FrameSetPtr input, std::vector<MatView>* features) {
+  VF_CHECK(features != nullptr, "features");
+  const VideoFrame& frame = input->at(video_stream_idx_)->As<VideoFrame>();
+  MatView image;
+  image.data = frame.data();
+  image.rows = frame.height();
+  image.cols = frame.width();
+  image.step = (size_t)frame.width_step();
+  image.type = MatView::TYPE_8UC3;
+  features->push_back(image);
+  if (flow_stream_idx_ >= 0) {
+    MatView flow;
+    flow.type = MatView::TYPE_32FC2;
+    if (num_input_frames_ > 0) {
+      const DenseFlowFrame& flow_frame = input->at(flow_stream_idx_)->As<DenseFlowFrame>();
+      flow.data = flow_frame.flow();
+      flow.rows = flow_frame.height();
+      flow.cols = flow_frame.width();
+      flow.step = (size_t)flow_frame.width() * 2 * sizeof(float);
+    }
+    features->push_back(flow);   // an empty view for the first frame
+  }
+}
+
+void RegionSegmentationUnit::ProcessFrame(FrameSetPtr input, std::list<FrameSetPtr>* output) {
+  const PointerFrame<SegmentationDesc>& seg_frame = input->at(seg_stream_idx_)->As<PointerFrame<SegmentationDesc>>();
+  const SegmentationDesc* desc = seg_frame.Ptr();
+  std::vector<MatView> features;
+  ExtractFrameSetFeatures(input, &features);
+  frame_set_buffer_.push_back(input);
+  std::vector<std::unique_ptr<SegmentationDesc>> results;
+  region_seg_->ProcessFrame(false, desc, &features, &results);
+  // The over-segmentation is replaced by the hierarchical result (OutputSegmentation); the frames
+  // the next units do not need can go (segmentation_unit.cpp:255-262).
+  if (options_.free_video_frames) input->at(video_stream_idx_).reset();
+  if (flow_stream_idx_ >= 0 && options_.free_flow_frames) input->at(flow_stream_idx_).reset();
+  if (!results.empty()) OutputSegmentation(&results, output);
+  ++num_input_frames_;
+}
+
+bool RegionSegmentationUnit::PostProcess(std::list<FrameSetPtr>* append) {
+  if (!region_seg_ || num_input_frames_ == 0) return false;
+  std::vector<std::unique_ptr<SegmentationDesc>> results;
+  if (region_seg_->ProcessFrame(true, nullptr, nullptr, &results) > 0) OutputSegmentation(&results, append);
+  return false;
+}
+
+void RegionSegmentationUnit::OutputSegmentation(std::vector<std::unique_ptr<SegmentationDesc>>* results,
+                                                std::list<FrameSetPtr>* output) {
+  for (size_t k = 0; k < results->size(); ++k) {
+    VF_CHECK(!frame_set_buffer_.empty(), "more results than buffered frame sets");
+    FrameSetPtr frame_set = frame_set_buffer_.front();
+    frame_set_buffer_.pop_front();
+    const int64_t pts = frame_set->at(seg_stream_idx_)->pts();
+    frame_set->at(seg_stream_idx_).reset(new PointerFrame<SegmentationDesc>(std::move((*results)[k]), pts));
+    output->push_back(frame_set);
+  }
 }
 
 }  // namespace segmentation

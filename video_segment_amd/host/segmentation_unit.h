@@ -29,6 +29,7 @@ struct SegmentationDesc {
   // segment_util/segmentation_util.cpp:741-770).  Returns false on malformed input.
   bool ToIdImage(int width, int height, std::vector<int32_t>* out) const;
   int NumRegions() const;
+  int NumHierarchyLevels() const;
   // frame_width (field 4) / frame_height (field 5); false if absent or malformed.
   bool FrameSize(int* width, int* height) const;
 };
@@ -143,6 +144,90 @@ class DenseSegmentationUnit : public VideoUnit {
   int frame_width_ = 0, frame_height_ = 0;
   int input_frames_ = 0, output_frames_ = 0;
   std::unique_ptr<DenseSegmentation> dense_seg_;
+  std::list<FrameSetPtr> frame_set_buffer_;
+};
+
+// ---- hierarchical stage -----------------------------------------------------------------------
+// Same fields and defaults as the reference (region_segmentation.h:41-83; save_descriptors is not
+// supported by the library).
+struct RegionSegmentationOptions {
+  int min_region_num = 10;
+  int max_region_num = 10000;
+  float level_cutoff_fraction = 0.8f;
+  float small_region_penalizer = 0.25f;
+  int luminance_bins = 10;
+  int color_bins = 20;
+  int flow_bins = 16;
+  int chunk_set_size = 6;
+  int chunk_set_overlap = 2;
+  int constraint_chunks = 1;
+  bool use_appearance = true;
+  bool use_flow = true;
+  bool use_size_penalizer = true;
+  bool compute_vectorization = true;
+};
+
+// Host-side drop-in for segmentation::RegionSegmentation (region_segmentation.h:131-216) behind
+// the C ABI (vsg_regionseg_*, include/vsg.h).
+class RegionSegmentation {
+ public:
+  RegionSegmentation(const RegionSegmentationOptions& options, int frame_width, int frame_height);
+  virtual ~RegionSegmentation();
+  RegionSegmentation(const RegionSegmentation&) = delete;
+  RegionSegmentation& operator=(const RegionSegmentation&) = delete;
+
+  // segmentation + features ({BGR24 frame[, flow: empty view for the first frame]}) are either
+  // both set or both null (flush only).  Returns the number of results.
+  int ProcessFrame(bool flush, const SegmentationDesc* segmentation, const std::vector<MatView>* features,
+                   std::vector<std::unique_ptr<SegmentationDesc>>* results);
+  bool ok() const { return handle_ != nullptr; }
+
+ private:
+  RegionSegmentationOptions options_;
+  vsg_regionseg* handle_ = nullptr;
+};
+
+struct RegionSegmentationUnitOptions {   // segmentation_unit.h:126-137
+  std::string video_stream_name = "VideoStream";
+  std::string flow_stream_name = "BackwardFlowStream";
+  std::string segment_stream_name = "SegmentationStream";
+  bool free_video_frames = false;
+  bool free_flow_frames = true;
+};
+
+// Drop-in for the reference's RegionSegmentationUnit (segmentation_unit.h:139-199,
+// segmentation_unit.cpp:180-331): replaces the over-segmentation in "SegmentationStream" by the
+// hierarchical segmentation, chunk set by chunk set.
+class RegionSegmentationUnit : public VideoUnit {
+ public:
+  RegionSegmentationUnit(const RegionSegmentationUnitOptions& options,
+                         const RegionSegmentationOptions* region_options);
+  virtual ~RegionSegmentationUnit();
+
+  virtual bool OpenStreams(StreamSet* set);
+  virtual void ProcessFrame(FrameSetPtr input, std::list<FrameSetPtr>* output);
+  virtual bool PostProcess(std::list<FrameSetPtr>* append);
+
+ protected:
+  virtual bool OpenFeatureStreams(StreamSet* set);
+  virtual std::unique_ptr<RegionSegmentation> CreateRegionSegmentation();
+  virtual void ExtractFrameSetFeatures(FrameSetPtr input, std::vector<MatView>* features);
+
+  int video_stream_idx() const { return video_stream_idx_; }
+  int flow_stream_idx() const { return flow_stream_idx_; }
+  int frame_width() const { return frame_width_; }
+  int frame_height() const { return frame_height_; }
+  const RegionSegmentationUnitOptions& options() const { return options_; }
+
+ private:
+  void OutputSegmentation(std::vector<std::unique_ptr<SegmentationDesc>>* results,
+                          std::list<FrameSetPtr>* output);
+
+  int video_stream_idx_ = -1, flow_stream_idx_ = -1, seg_stream_idx_ = -1;
+  RegionSegmentationUnitOptions options_;
+  RegionSegmentationOptions region_options_;
+  std::unique_ptr<RegionSegmentation> region_seg_;
+  int frame_width_ = 0, frame_height_ = 0, num_input_frames_ = 0;
   std::list<FrameSetPtr> frame_set_buffer_;
 };
 
