@@ -316,9 +316,47 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps):
         c4["cpu_baseline"] = {"value": ns / dt_o, "unit": "frames/s", "cores": 1, "kind": "port",
                               "sample": "first %d frames of the same 3840x2160 workload as one flushed "
                                         "chunk, oracle/libvs_oracle.so, %.1f s" % (ns, dt_o)}
-    del f4, fl4
-    torch.cuda.empty_cache()
+    del f4
     out["configs"]["3840x2160"] = c4
+
+    # ---- BASELINE configs[4] on one GPU: 4K over-segmentation on the device + the hierarchical
+    # RegionSegmentation (host) on top of it.  Input: the low-contrast variant of the generator --
+    # on the bench input itself the reference's RegionAgglomerationGraph aborts (neighbouring
+    # checker cells are at distance exactly 1.0, region_segmentation_graph.cpp:165).
+    nh = chunk + (chunk - 1)
+    fh = make_frames("soft", w4, h4, nh, dev)
+    fh_host = [f.cpu().numpy() for f in fh]
+    flh = synth.const_flow(w4, h4)
+    dseg = vsg.DenseSegmentation(w4, h4, vsg.default_options(chunk_size=chunk, device=device_index), has_flow=True)
+    rseg = vsg.RegionSegmentation(w4, h4, vsg.default_region_options())
+    torch.cuda.synchronize()
+    t_dense = t_region = 0.0
+    n_out, fed = 0, 0
+    t0 = time.perf_counter()
+    for k in range(nh):
+        ta = time.perf_counter()
+        n = dseg.process_frame(fh[k], fl4 if k > 0 else None, flush=(k == nh - 1))
+        segs = [dseg.result_bytes(i) for i in range(n)]
+        tb = time.perf_counter()
+        t_dense += tb - ta
+        for j, seg in enumerate(segs):
+            last = k == nh - 1 and j == len(segs) - 1
+            m = rseg.process_frame(seg, fh_host[fed], flh if fed > 0 else None, flush=last)
+            fed += 1
+            n_out += sum(1 for i in range(m) if len(rseg.result_bytes(i)) > 0)
+        t_region += time.perf_counter() - tb
+    dt = time.perf_counter() - t0
+    dseg.close()
+    rseg.close()
+    out["configs"]["configs[4]"] = {
+        "workload": "3840x2160 low-contrast bench generator + constant flow, chunk %d, %d frames: dense "
+                    "over-segmentation on the GPU, hierarchical RegionSegmentation (default options: Lab "
+                    "+ flow histograms, size penalizer, vectorization) on the host; one GPU" % (chunk, nh),
+        "value": n_out / dt, "unit": "frames/s", "frames": n_out,
+        "dense_ms_per_frame": t_dense / nh * 1e3, "region_ms_per_frame": t_region / nh * 1e3,
+        "note": "first (unconstrained) chunk included; the hierarchy is host work by design (SURVEY 8(f) row 3)"}
+    del fh, fl4
+    torch.cuda.empty_cache()
 
     # ---- the 1080p shape on inputs with many small regions ---------------------------------------
     flow = torch.from_numpy(synth.const_flow(W, H)).to(dev)

@@ -391,7 +391,8 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   {
     const double want = 1.15 * (double)wh_ * (double)capacity_frames_;   // (the handle's capacity, not this chunk's N)
     const int by_graph = (int)std::min<double>(std::max<double>(want, 1 << 20), 120 << 20);
-    S.spine_max_edges = getenv("VSG_SPINE_MAX_EDGES") ? atoi(getenv("VSG_SPINE_MAX_EDGES")) : by_graph;
+    S.spine_max_edges = getenv("VSG_SPINE_MAX_EDGES") ? atoi(getenv("VSG_SPINE_MAX_EDGES"))
+                                                      : std::max(by_graph, spine_max_edges_grown_);
   }
   S.spine_off = 0;
   if (spine_limit_bucket_ != 0x7fffffff && ++spine_limit_age_ > 8) {   // probe again
@@ -420,6 +421,30 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   }
   S.spine_pool = spine_pool_.get();
   S.spine_pool_ints = spine_pool_.size();
+  S.grow_spine_pool = [this, &S](long long edges) {
+    // up to what the rank stamps of the spanning forest address (2^27 edges, merge_spine.hip)
+    if (getenv("VSG_SPINE_MAX_EDGES") || edges >= (120ll << 20)) return false;
+    const long long want = std::min<long long>(edges + edges / 8, 120ll << 20);
+    // SpinePoolInts prices a stage whose components are dense (a fifth to two thirds of the edges
+    // are tree edges, the rest of the 16 ints per edge is room for nested levels); a stage this
+    // large is the opposite -- most of the volume in a few components, nearly every node a tree
+    // edge -- and rooting the trees takes 29 ints per tree edge on top of the 7 per edge.
+    const long long nodes = (long long)wh_ * (long long)std::max(capacity_frames_, 1);
+    const size_t ints = SpinePoolInts((size_t)want) + (size_t)(29 * std::min(want, nodes));
+    if (ints <= spine_pool_.size()) return false;
+    size_t free_b = 0, total_b = 0;
+    VSG_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (free_b + spine_pool_.size() * sizeof(int32_t) < 2 * ints * sizeof(int32_t)) return false;
+    VSG_HIP(hipStreamSynchronize(stream_));
+    VSG_HIP(hipStreamSynchronize(aux_stream_));
+    VSG_HIP(hipStreamSynchronize(aux2_stream_));
+    spine_pool_.alloc(ints);
+    S.spine_pool = spine_pool_.get();
+    S.spine_pool_ints = spine_pool_.size();
+    S.spine_max_edges = (int)want;
+    spine_max_edges_grown_ = S.spine_max_edges;
+    return true;
+  };
   S.nmap[0] = label_uf_.get();
   S.nmap[1] = label_img_.get();
   S.nmap[2] = adjust_.get();

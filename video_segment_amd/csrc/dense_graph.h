@@ -160,6 +160,7 @@ class DenseGraphHip {
                                           // chunk must not switch the tree replay off for good)
   int spine_low_fails_[2] = {0, 0}, spine_low_cooldown_[2] = {0, 0};   // the same for buckets 0 and 1
   DevBuf<int32_t> spine_pool_;   // scratch of the Kruskal-tree replay (merge_spine.hip)
+  int spine_max_edges_grown_ = 0;   // what the pool was enlarged to for this video's largest stage
   DevBuf<unsigned long long> stats_;
   DevBuf<uint8_t> cub_temp_;
   size_t scratch_edges_ = 0;

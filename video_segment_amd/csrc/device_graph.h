@@ -16,6 +16,8 @@
 #ifndef VSG_DEVICE_GRAPH_H_
 #define VSG_DEVICE_GRAPH_H_
 
+#include <functional>
+
 #include "common.h"
 
 namespace vsg {
@@ -160,6 +162,10 @@ struct MergeScratch {
   int spine_debug, spine_check;
   int32_t* spine_pool;   // scratch, SpinePoolInts(spine_max_edges) ints
   size_t spine_pool_ints;
+  // Enlarges the pool so that it holds `edges` edges (all streams of the graph are idle when it is
+  // called); updates spine_pool / spine_pool_ints / spine_max_edges and returns true, or false if
+  // the request is beyond what the tree replay can address.
+  std::function<bool(long long edges)> grow_spine_pool;
   int32_t* nmap[3];      // three more [N] scratch maps (free during the bucket stages)
   hipStream_t aux_stream;   // the ordinary workers run here while the trees are built on the main stream
   hipStream_t aux2_stream;  // the ordinary side clusters of a tree level, beside the level below

@@ -361,8 +361,11 @@ constexpr size_t kSpineListInts = 8192;
 // Chooses the components (segments) of at least min_cnt edges for the Kruskal-tree replay, raising
 // the threshold until all of them fit max_edges; returns the threshold (the ordinary workers leave
 // segments of at least that many edges alone), 0x7fffffff when there is none.  Synchronises.
+// wanted_edges (optional): edges of all components of at least min_cnt edges (what the pool would
+// have to hold for none of them to be left to the wave worker).
 int SelectLargeSegments(int max_segs, const int32_t* num_segs, const int32_t* seg_off, const int32_t* seg_cnt,
-                        int min_cnt, long long max_edges, int32_t* d_list, hipStream_t s, SpineInput* out);
+                        int min_cnt, long long max_edges, int32_t* d_list, hipStream_t s, SpineInput* out,
+                        long long* wanted_edges);
 // pool_used: ints of S.spine_pool already taken (by the caller's lists and outer levels).
 bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch& S, hipStream_t s,
                         const SpineWorkers& run_workers, size_t pool_used, int depth);

@@ -821,8 +821,10 @@ struct Pool {   // stack allocator over the spine scratch
 size_t SpinePoolInts(size_t max_edges) { return 16 * max_edges + 64 * 1024; }
 
 int SelectLargeSegments(int max_segs, const int32_t* num_segs, const int32_t* seg_off, const int32_t* seg_cnt,
-                        int min_cnt, long long max_edges, int32_t* d_list, hipStream_t s, SpineInput* out) {
+                        int min_cnt, long long max_edges, int32_t* d_list, hipStream_t s, SpineInput* out,
+                        long long* wanted_edges) {
   out->segs.clear();
+  if (wanted_edges) *wanted_edges = 0;
   std::vector<int32_t> large(1 + 2 * kSpineListCap);
   int found = 0;
   for (;; min_cnt *= 4) {   // too many for the list: only the larger ones
@@ -845,20 +847,31 @@ int SelectLargeSegments(int max_segs, const int32_t* num_segs, const int32_t* se
                  max_segs, min_cnt, found, sum, mx, max_edges);
   }
   if (found == 0) return 0x7fffffff;
-  int thr = min_cnt;
-  for (;;) {   // every component above the threshold has to fit
-    long long sum = 0;
-    int cnt = 0;
-    for (int i = 0; i < found; ++i) {
-      if (large[2 + 2 * i] >= thr) {
-        sum += large[2 + 2 * i];
-        ++cnt;
-      }
-    }
-    if (cnt == 0) return 0x7fffffff;
-    if (sum <= max_edges && cnt <= 256) break;
-    thr *= 2;
+  // The largest components first, as many as the scratch pool holds (at most 256): the threshold is
+  // the size of the smallest one taken -- everything of at least that size has to be taken, so ties
+  // at the boundary go together.  (Doubling the threshold until everything fits drops fifteen
+  // components of similar size all at once.)
+  std::vector<int> sizes((size_t)found);
+  long long all = 0;
+  for (int i = 0; i < found; ++i) {
+    sizes[(size_t)i] = large[2 + 2 * i];
+    all += sizes[(size_t)i];
   }
+  if (wanted_edges) *wanted_edges = all;
+  std::sort(sizes.begin(), sizes.end(), std::greater<int>());
+  long long sum = 0;
+  int taken = 0, thr = 0x7fffffff;
+  for (int i = 0; i < found && i < 256;) {
+    int j = i;
+    long long group = 0;
+    while (j < found && sizes[(size_t)j] == sizes[(size_t)i]) group += sizes[(size_t)j++];
+    if (sum + group > max_edges || j > 256) break;
+    sum += group;
+    taken = j;
+    thr = sizes[(size_t)i];
+    i = j;
+  }
+  if (taken == 0) return 0x7fffffff;
   for (int i = 0; i < found; ++i) {
     if (large[2 + 2 * i] >= thr) out->segs.push_back(SpineSeg{large[1 + 2 * i], large[2 + 2 * i]});
   }
@@ -1101,7 +1114,8 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
       const long long room = (long long)((S.spine_pool_ints - pool_used - pool.used) / 16);
       // (a level costs about a millisecond of launches: only for what the wave worker needs longer for)
       w2.wave_max = SelectLargeSegments(n_side, d_nseg, seg_off, seg_cnt, S.spine_min * S.spine_nested_factor,
-                                        room < S.spine_max_edges ? room : S.spine_max_edges, d_list, s, &nested);
+                                        room < S.spine_max_edges ? room : S.spine_max_edges, d_list, s, &nested,
+                                        nullptr);
     }
     if (nested.segs.empty()) {
       run_workers(w2, n_side, s);

@@ -92,9 +92,11 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
                                                  uint32_t* __restrict__ e_gpos,
                                                  FilterMasks M,
                                                  int32_t* __restrict__ num_ti) {
-  __shared__ int wave_cnt[4];
+  __shared__ int wave_cnt[4], wave_kept[4];
   const int j = blockIdx.x * 256 + threadIdx.x;   // index inside the stage's window
   int ti = 0, active = 0, settled = 0;
+  int ra = 0, rb = 0;
+  uint32_t gpos = 0;
   if (j < n_b) {
     int bk = bucket;
     int jb = j0 + j;                               // index inside the bucket
@@ -114,9 +116,9 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
     const int pos = L.offsets[bk] + (jb - base_row[l]);
     int a, b;
     DecodeEdge(L, L.slots[pos], P.W, a, b);
-    const int ra = FindCompress(nodes.parent, a);
-    const int rb = FindCompress(nodes.parent, b);
-    const uint32_t gpos = list_slot_base[l] + (uint32_t)pos;
+    ra = FindCompress(nodes.parent, a);
+    rb = FindCompress(nodes.parent, b);
+    gpos = list_slot_base[l] + (uint32_t)pos;
     const bool gone = P.spatial_survivors && L.type == 0 && !P.spatial_survivors[gpos];
     if (ra != rb && !gone) {
       bool inert = false;
@@ -152,14 +154,6 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
         CcUnion(cc, ra, rb);
       }
     }
-    // Roots and position only where something reads them back (the compaction: active; the
-    // clearing of the marks: tentative; the rollback: every kept mark the filter set) -- most
-    // edges of a stage are internal.
-    if (active | settled) {
-      e_ra[j] = ra;
-      e_rb[j] = rb;
-      e_gpos[j] = gpos;
-    }
   }
   // What the edge turned out to be is three bits per edge, one 64-bit word per wavefront and
   // class (a dense flag + code array per edge was 5 of the 17 bytes this kernel wrote per edge,
@@ -168,28 +162,53 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
   const unsigned long long ma = __ballot(active != 0);
   const unsigned long long ms = __ballot(settled != 0);
   const unsigned long long mt = __ballot(ti != 0);
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
     const size_t gw = (size_t)blockIdx.x * 4 + w;
     M.active[gw] = ma;
     M.settled[gw] = ms;
     M.tentative[gw] = mt;
     wave_cnt[w] = (int)__popcll(ma);
+    wave_kept[w] = (int)__popcll(ma | ms);
     if (mt != 0) atomicAdd(num_ti, (int)__popcll(mt));
   }
   __syncthreads();
+  // Roots and position only where something reads them back (the compaction: active; the
+  // clearing of the marks: tentative; the rollback: every kept mark the filter set) -- most
+  // edges of a stage are internal, so the records of a workgroup's active / settled edges are
+  // packed at the head of the workgroup's 256 slots (FilterSlot: the readers recompute the rank
+  // from the masks); scattered 4-byte stores cost a 64-byte sector each.
+  if (active | settled) {
+    int rank = (int)__popcll((ma | ms) & ((1ull << lane) - 1ull));
+    for (int k = 0; k < w; ++k) rank += wave_kept[k];
+    const int slot = blockIdx.x * 256 + rank;
+    e_ra[slot] = ra;
+    e_rb[slot] = rb;
+    e_gpos[slot] = gpos;
+  }
   if (threadIdx.x == 0) M.block_cnt[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// Where k_filter left the record (roots, kept position) of edge j of the stage: the rank of the
+// edge among the active / settled edges of its workgroup.  Only valid for such an edge.
+__device__ __forceinline__ int FilterSlot(const FilterMasks& M, int j) {
+  const int block = j >> 8, w = (j >> 6) & 3, lane = j & 63;
+  const size_t gw0 = (size_t)block * 4;
+  int rank = (int)__popcll((M.active[gw0 + w] | M.settled[gw0 + w]) & ((1ull << lane) - 1ull));
+  for (int k = 0; k < w; ++k) rank += (int)__popcll(M.active[gw0 + k] | M.settled[gw0 + k]);
+  return block * 256 + rank;
 }
 
 // Clears the tentative marks of a stage: on the regions marked by the filter and on whatever
 // region they have been merged into since.
-__global__ __launch_bounds__(256) void k_clear_tentative(int n_b, const unsigned long long* __restrict__ m_ti,
+__global__ __launch_bounds__(256) void k_clear_tentative(int n_b, FilterMasks M,
                                                           const int32_t* __restrict__ e_ra,
                                                           const int32_t* __restrict__ e_rb,
                                                           NodeArrays nodes) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_b || !((m_ti[j >> 6] >> (j & 63)) & 1ull)) return;
-  int r[2] = {e_ra[j], e_rb[j]};
+  if (j >= n_b || !((M.tentative[j >> 6] >> (j & 63)) & 1ull)) return;
+  const int slot = FilterSlot(M, j);
+  int r[2] = {e_ra[slot], e_rb[slot]};
   for (int k = 0; k < 2; ++k) {
     int x = r[k];
     for (;;) {
@@ -238,14 +257,13 @@ __global__ __launch_bounds__(256) void k_restore_roots(int n, const int32_t* __r
   nodes.flags[rb] = bk_flags[2 * i + 1];
 }
 
-__global__ __launch_bounds__(256) void k_clear_kept(int n_b, const unsigned long long* __restrict__ m_active,
-                                                     const unsigned long long* __restrict__ m_settled,
+__global__ __launch_bounds__(256) void k_clear_kept(int n_b, FilterMasks M,
                                                      const uint32_t* __restrict__ e_gpos,
                                                      uint8_t* __restrict__ kept_all) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n_b) return;
   // every edge whose kept mark the stage may have set
-  if (((m_active[j >> 6] | m_settled[j >> 6]) >> (j & 63)) & 1ull) kept_all[e_gpos[j]] = 0;
+  if (((M.active[j >> 6] | M.settled[j >> 6]) >> (j & 63)) & 1ull) kept_all[e_gpos[FilterSlot(M, j)]] = 0;
 }
 
 // Ordered compaction of the active edges: block_off = exclusive scan of the per-workgroup counts
@@ -267,9 +285,10 @@ __global__ __launch_bounds__(256) void k_compact_active(int n_b, FilterMasks M,
   for (int k = 0; k < w; ++k) base += (int)__popcll(M.active[gw0 + k]);
   if ((m >> lane) & 1ull) {
     const int p = base + (int)__popcll(m & ((1ull << lane) - 1ull));
-    a_ra[p] = e_ra[j];
-    a_rb[p] = e_rb[j];
-    a_gpos[p] = e_gpos[j];
+    const int slot = FilterSlot(M, j);
+    a_ra[p] = e_ra[slot];
+    a_rb[p] = e_rb[slot];
+    a_gpos[p] = e_gpos[slot];
   }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *num_active = base + (int)__popcll(m);
 }
@@ -490,8 +509,8 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   const int n_ti = h[2];
   auto clear_marks = [&]() {
     if (n_ti > 0) {
-      hipLaunchKernelGGL(k_clear_tentative, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks.tentative,
-                         S.e_ra, S.e_rb, nodes);
+      hipLaunchKernelGGL(k_clear_tentative, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks, S.e_ra,
+                         S.e_rb, nodes);
     }
   };
   if (n_active == 0) {
@@ -536,8 +555,15 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   int spine_thr = 0x7fffffff;
   if (S.spine_min > 0 && !S.spine_off && bucket < *S.spine_limit_bucket &&
       !(bucket < 2 && S.spine_low_skip[bucket]) && inert_mode != 0 && !S.wave_v1 && n_work >= S.spine_min) {
+    long long wanted = 0;
     spine_thr = SelectLargeSegments(n_work, S.num_segs, S.seg_off, S.seg_cnt, S.spine_min,
-                                    S.spine_max_edges, S.spine_pool, s, &spine_in);
+                                    S.spine_max_edges, S.spine_pool, s, &spine_in, &wanted);
+    if (wanted > S.spine_max_edges && S.grow_spine_pool && S.grow_spine_pool(wanted)) {
+      // the pool was too small for this input (it is sized for a typical bucket, not for the
+      // largest one a video can produce): it has grown, choose again
+      spine_thr = SelectLargeSegments(n_work, S.num_segs, S.seg_off, S.seg_cnt, S.spine_min,
+                                      S.spine_max_edges, S.spine_pool, s, &spine_in, nullptr);
+    }
   }
   const bool spine = !spine_in.segs.empty();
   // A stage that settles edges tentatively, replays run leaders only or relies on the spine
@@ -645,8 +671,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
                          nodes, S.bk_ds, S.bk_cons, S.bk_flags);
       VSG_HIP(hipMemcpyAsync(S.stats, S.stats + 8, 8 * sizeof(unsigned long long),
                              hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks.active,
-                         S.masks.settled, S.e_gpos, kept_all);
+      hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks, S.e_gpos, kept_all);
       clear_marks();
       VSG_HIP(hipGetLastError());
       if (spine && violated == 2 && !S.force_rollback) {
