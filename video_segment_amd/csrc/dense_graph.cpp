@@ -65,8 +65,8 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   keys_tmp_.alloc(9 * wh_ + 8);
   hist_tmp_.alloc(EdgeSortHistInts(wh_));
   hist_sums_.alloc(EdgeSortSumInts(wh_) + 1);
-  scalars_.alloc(16);
-  stats_.alloc(64);
+  scalars_.alloc(32);
+  stats_.alloc(96);
   VSG_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
   VSG_HIP(hipStreamCreateWithFlags(&aux2_stream_, hipStreamNonBlocking));
   VSG_HIP(hipEventCreateWithFlags(&aux_fork_, hipEventDisableTiming));
@@ -107,6 +107,10 @@ void DenseGraphHip::ForgetLearned() {
   spine_limit_bucket_ = 0x7fffffff;
   spine_limit_age_ = 0;
   for (int b = 0; b < 2; ++b) spine_low_fails_[b] = spine_low_cooldown_[b] = 0;
+  wave_target_active_ = kNoWindowTarget;
+  window_target_.clear();
+  window_target_age_ = 0;
+  last_density_ = 1.0;
 }
 
 void DenseGraphHip::SortList(ListBuf& lb, int per_px) {
@@ -230,21 +234,22 @@ void DenseGraphHip::EnsureScratch(size_t n) {
 // One stage, with the per-stage counters of VSG_DEBUG_STAGES printed around it.
 void DenseGraphHip::RunStageDebug(int b, int w, int windows, int j0, int n, const MergeParams& P,
                                   int inert_mode, MergeScratch& S, bool debug_stages, StageInfo* info) {
-  unsigned long long s0[64] = {0}, s1[64] = {0};
+  unsigned long long s0[96] = {0}, s1[96] = {0};
   double ts = 0;
-  size_t ev0 = 0;
+  size_t ev0 = 0, evf0 = 0;
   if (debug_stages) {
     VSG_HIP(hipMemsetAsync(stats_.get() + 16, 0, 2 * sizeof(unsigned long long), stream_));
     VSG_HIP(hipMemsetAsync(stats_.get() + 48, 0, 16 * sizeof(unsigned long long), stream_));
-    D2H(s0, stats_.get(), 64, stream_);
+    D2H(s0, stats_.get(), 96, stream_);
     VSG_HIP(hipStreamSynchronize(stream_));
     ts = NowMs();
     ev0 = ev_wave_.size();
+    evf0 = ev_filter_.size();
   }
   RunBucketStage(b, j0, n, list_desc_dev_.get(), bucket_base_dev_.get(), list_slot_base_dev_.get(),
                  kept_all_.get(), nodes(), P, inert_mode, S, stream_, info);
   if (!debug_stages) return;
-  D2H(s1, stats_.get(), 64, stream_);
+  D2H(s1, stats_.get(), 96, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
   const double te = NowMs();
   float wave_ms = 0;
@@ -253,11 +258,17 @@ void DenseGraphHip::RunStageDebug(int b, int w, int windows, int j0, int n, cons
     VSG_HIP(hipEventElapsedTime(&ms, ev_pool_[ev_wave_[k].first], ev_pool_[ev_wave_[k].second]));
     wave_ms += ms;
   }
+  float filter_ms = 0;
+  for (size_t k = evf0; k < ev_filter_.size(); ++k) {
+    float ms = 0;
+    VSG_HIP(hipEventElapsedTime(&ms, ev_pool_[ev_filter_[k].first], ev_pool_[ev_filter_[k].second]));
+    filter_ms += ms;
+  }
   if (te - ts <= 1.0) return;
-  std::fprintf(stderr, "[vsg] stage b=%d w=%d/%d n=%d wall %.2f ms workers %.2f ms | replayed %d components %d | "
+  std::fprintf(stderr, "[vsg] stage b=%d w=%d/%d n=%d wall %.2f ms filter %.2f ms workers %.2f ms | replayed %d components %d | "
                "wave edges %llu batches %llu rounds %llu nwin %llu chain %llu | max_seg %llu slowest %.2f Mcyc | "
                "cyc load %.0f M loop %.0f M wait %.0f M\n",
-               b, w, windows, n, te - ts, wave_ms, info ? info->replayed : -1, info ? info->components : -1,
+               b, w, windows, n, te - ts, filter_ms, wave_ms, info ? info->replayed : -1, info ? info->components : -1,
                s1[3] - s0[3], s1[7] - s0[7], s1[5] - s0[5], s1[4] - s0[4], s1[20] - s0[20],
                s1[17], s1[16] / 1e6, (s1[18] - s0[18]) / 1e6, (s1[19] - s0[19]) / 1e6,
                (s1[26] - s0[26]) / 1e6);
@@ -268,6 +279,9 @@ void DenseGraphHip::RunStageDebug(int b, int w, int windows, int j0, int n, cons
                s1[54] / 1e3 / std::max(1.0, (double)s1[49]), s1[57] / 1e3 / std::max(1.0, (double)s1[49]),
                s1[58] / 1e3 / std::max(1.0, (double)s1[49]), s1[59] / 1e3 / std::max(1.0, (double)s1[49]),
                s1[60] / 1e3 / std::max(1.0, (double)s1[49]), s1[61], s1[62]);
+  std::fprintf(stderr, "[vsg]   chain ends (%llu): not owner %llu, flags %llu, constraint %llu, larger %llu, failed/mode %llu, "
+               "hot small %llu, none %llu\n", s1[71] - s0[71], s1[64] - s0[64], s1[65] - s0[65], s1[66] - s0[66],
+               s1[67] - s0[67], s1[68] - s0[68], s1[69] - s0[69], s1[70] - s0[70]);
 }
 
 void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, int pass) {
@@ -314,7 +328,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   LaunchBuildBucketTable(list_desc_dev_.get(), L, bucket_base_dev_.get(), stream_);
   bucket_base_host_.resize((size_t)(kNumBuckets + 1) * (L + 1));
   D2H(bucket_base_host_.data(), bucket_base_dev_.get(), bucket_base_host_.size(), stream_);
-  VSG_HIP(hipMemsetAsync(stats_.get(), 0, 64 * sizeof(unsigned long long), stream_));
+  VSG_HIP(hipMemsetAsync(stats_.get(), 0, 96 * sizeof(unsigned long long), stream_));
   LaunchInitIdentity(cc_.get(), N, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
 
@@ -507,6 +521,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   const bool debug_stages = getenv("VSG_DEBUG_STAGES") != nullptr;
   const int num_windows = getenv("VSG_WINDOWS") ? std::max(1, atoi(getenv("VSG_WINDOWS"))) : 6;
   const int window_bushy = getenv("VSG_WINDOW_BUSHY") ? atoi(getenv("VSG_WINDOW_BUSHY")) : 64;
+  const bool adapt_windows = !getenv("VSG_ADAPT_WINDOWS") || atoi(getenv("VSG_ADAPT_WINDOWS")) != 0;
   // (in units of the frame: a bucket is split into rank windows from two frames' worth of edges
   // on -- 4 M at 1080p --, a probe window that replays less than half a frame's worth -- 1 M --
   // ends the splitting)
@@ -524,6 +539,12 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   // window tells which case it is: average component size below `bushy` -> keep splitting.
   S.bucket_prefix = bucket_prefix_dev_.get();
   S.bucket_prefix_host = bucket_prefix.data();
+  if (++window_target_age_ > 8) {
+    window_target_age_ = 0;
+    for (auto& t : window_target_) {
+      if (t != 0 && t != kNoWindowTarget) t = t * 2 > (1ll << 28) ? 0 : t * 2;
+    }
+  }
   int group_width = 1;
   for (int b = 0, hi = 0; b < kNumBuckets; b = hi) {
     hi = b + 1;
@@ -537,27 +558,90 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     const int n_b = bucket_prefix[hi] - bucket_prefix[b];
     if (n_b == 0) continue;
     int64_t group_active = 0;
-    int windows = n_b >= window_min_edges ? num_windows : 1;
-
-    for (int w = 0; w < windows; ++w) {
-      const int j0 = (int)((int64_t)n_b * w / windows);
-      int j1 = (int)((int64_t)n_b * (w + 1) / windows);
-      const bool probe = windows > 1 && w == 0 && window_bushy > 0;
+    const int windows = n_b >= window_min_edges ? num_windows : 1;
+    // the window target of this bucket: what the last chunk learned for it, else what the
+    // bucket before it ended with (the force-merge buckets, where the tree replay takes the large
+    // components, hand nothing on)
+    if (window_target_.empty()) window_target_.assign(kNumBuckets + 1, 0);
+    if (window_target_[b] != 0) {
+      wave_target_active_ = window_target_[b];
+    } else if (b <= first_plain) {
+      wave_target_active_ = kNoWindowTarget;
+    }
+    // One stage; afterwards the window target follows the largest component a single wavefront
+    // had to replay.  (On a noisy input the active edges of the middle buckets percolate: one
+    // component of a million edges between a million small regions, 0.3 s on one wavefront and
+    // three seconds per chunk.  Below the percolation threshold -- fewer active edges per stage --
+    // the same edges fall into thousands of components.  The target is counted in active edges,
+    // kept per bucket between chunks, halved while a stage still produces a component above
+    // 16 K edges; it only grows between chunks -- doubled every eighth chunk, to follow the video
+    // -- because the threshold is sharp: twice the edges per stage that give components of 5 K
+    // give one of 60 K.)
+    auto run = [&](int w, int j0, int n, bool measure, bool limited) {
       StageInfo info;
-      info.want_components = probe || debug_stages;
-      RunStageDebug(b, w, windows, j0, j1 - j0, P, inert_mode, S, debug_stages, &info);
+      info.want_components = measure || debug_stages;
+      RunStageDebug(b, w, windows, j0, n, P, inert_mode, S, debug_stages, &info);
       group_active += info.replayed;
-      // (and a window that replays few edges is all overhead)
-      if (probe && ((int64_t)info.replayed >= (int64_t)window_bushy * std::max(info.components, 1) ||
-                    info.replayed < window_min_replayed)) {
-        // few, large components already: the rest of the bucket in one stage
-        StageInfo rest;
-        rest.want_components = debug_stages;
-        RunStageDebug(b, -1, windows, j1, n_b - j1, P, inert_mode, S, debug_stages, &rest);
-        group_active += rest.replayed;
-        break;
+      if (debug_stages && info.want_components && wave_target_active_ != kNoWindowTarget) {
+        std::fprintf(stderr, "[vsg]   window: max wave segment %d, target %lld active (density %.4f), limited %d\n",
+                     info.max_wave_segment, (long long)wave_target_active_, last_density_, (int)limited);
+      }
+      if (info.want_components && adapt_windows) {
+        last_density_ = std::max((double)info.replayed / (double)std::max(n, 1), 1e-6);
+        if (info.max_wave_segment > 16384) {
+          wave_target_active_ = std::max<int64_t>(std::min<int64_t>(wave_target_active_, info.replayed) / 2, 8192);
+        }
+        (void)limited;
+      }
+      return info;
+    };
+    // edges the next stage may take (from `left`), by the window target
+    auto limit = [&](int64_t want, bool* limited) {
+      *limited = false;
+      if (wave_target_active_ == kNoWindowTarget) return want;
+      const int64_t by_target = std::max<int64_t>((int64_t)((double)wave_target_active_ / last_density_), 16384);
+      if (by_target < want) {
+        *limited = true;
+        return by_target;
+      }
+      return want;
+    };
+    const bool big_enough = n_b >= (1 << 18);   // (the extra synchronisation of a measured stage)
+    int pos = 0;
+    for (int w = 0; w < windows && pos < n_b; ++w) {
+      const int j1 = (int)((int64_t)n_b * (w + 1) / windows);
+      if (j1 <= pos) continue;
+      const bool probe = windows > 1 && w == 0 && window_bushy > 0;
+      bool rest_mode = false;
+      while (pos < j1) {
+        bool limited = false;
+        const int take = (int)limit(j1 - pos, &limited);
+        const StageInfo info = run(w, pos, take, probe || (big_enough && (limited || windows == 1)) ||
+                                                      wave_target_active_ != kNoWindowTarget, limited);
+        pos += take;
+        // (and a window that replays few edges is all overhead)
+        if (probe && ((int64_t)info.replayed >= (int64_t)window_bushy * std::max(info.components, 1) ||
+                      info.replayed < (int64_t)window_min_replayed * take / std::max(j1, 1))) {
+          rest_mode = true;
+        }
+      }
+      if (rest_mode) {
+        // few, large components already: the rest of the bucket in one stage -- in as few as the
+        // tree replay can take (its rank stamps address 2^27 edges; the giant components of a
+        // low-contrast 4K bucket have 260 M, and left to the wave worker they cost seconds)
+        const int64_t rest_cap = getenv("VSG_REST_CAP") ? atoll(getenv("VSG_REST_CAP")) : (96ll << 20);
+        const int64_t rest_n = (int64_t)n_b - pos;
+        const int pieces = (int)std::max<int64_t>(1, (rest_n + rest_cap - 1) / rest_cap);
+        const int64_t piece = (rest_n + pieces - 1) / pieces;
+        for (int q = 0; pos < n_b; ++q) {
+          bool limited = false;
+          const int take = (int)limit(std::min<int64_t>(piece, n_b - pos), &limited);
+          run(-1 - q, pos, take, big_enough, limited);
+          pos += take;
+        }
       }
     }
+    window_target_[b] = wave_target_active_;
     if (b >= first_plain) {
       if (group_active < 2048) {
         group_width = std::min(group_width * 4, 512);

@@ -160,6 +160,11 @@ class DenseGraphHip {
                                           // chunk must not switch the tree replay off for good)
   int spine_low_fails_[2] = {0, 0}, spine_low_cooldown_[2] = {0, 0};   // the same for buckets 0 and 1
   DevBuf<int32_t> spine_pool_;   // scratch of the Kruskal-tree replay (merge_spine.hip)
+  static constexpr int64_t kNoWindowTarget = 1ll << 40;
+  int64_t wave_target_active_ = kNoWindowTarget;   // active edges per stage (SegmentLists), learned
+  std::vector<int64_t> window_target_;             // ... per bucket, from the last chunk (0: none yet)
+  int window_target_age_ = 0;
+  double last_density_ = 1.0;                      // active / all edges of the last measured stage
   int spine_max_edges_grown_ = 0;   // what the pool was enlarged to for this video's largest stage
   DevBuf<unsigned long long> stats_;
   DevBuf<uint8_t> cub_temp_;

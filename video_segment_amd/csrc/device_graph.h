@@ -200,6 +200,8 @@ struct StageInfo {
   bool want_components = false;   // in: also report `components` (one more synchronisation)
   int replayed = 0;     // edges handed to the workers (run leaders)
   int components = 0;   // independent components they fell into
+  int max_wave_segment = 0;   // (with want_components) edges of the largest component that one
+                              // wavefront replayed -- those of the tree replay do not count
 };
 void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const int32_t* bucket_base,
                     const uint32_t* list_slot_base, uint8_t* kept_all, NodeArrays nodes,

@@ -198,6 +198,14 @@ __device__ __forceinline__ int DecideEdge(RState& s1, RState& s2, const StageThr
   return kOutKeep;
 }
 
+// Partner of a chain edge (merge_wave.hip, merge_spine.hip): a region the larger (hot) region can
+// absorb without DecideEdge's bookkeeping -- no mark to hand on, no missing descriptor.  It may be
+// finalized: then (unconstrained case) the edge is never tested, whatever the hot region's flag --
+// the small one of the two is absorbed, two large ones are kept and nothing changes.  That is the
+// rule on noisy and on low-contrast inputs: a giant region whose neighbours have all failed a
+// test before.
+__device__ __forceinline__ bool PlainPartner(int flags) { return (flags & ~(int)kFlagFinalized) == 0; }
+
 // A tentatively settled edge stays settled only while the constraints of its two regions do not
 // change.  o1/o2: states before the edge, n1/n2: states that replace them (for a merge both are
 // the survivor's state).

@@ -569,9 +569,11 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
       // ---- chain: the leading run of plain, smaller partners that merge ---------------------------------------
       const bool fin = (H.flags & kFlagFinalized) != 0;
       const bool mode_ok = !(H.flags & kFlagNoDesc) && (!fin || H.sz >= T.min_size);
-      const bool part = valid && lane >= start && mode_ok && P.flags == 0 &&
-                        (P.cons < 0 || P.cons == H.cons) && P.sz < H.sz;
-      const bool merging = part && (P.cons >= 0 || !fin || P.sz < T.min_size);
+      const bool fin_l = fin || (P.flags & kFlagFinalized);   // this lane's (unconstrained) edge is not tested
+      const bool part = valid && lane >= start && mode_ok && PlainPartner(P.flags) &&
+                        (P.cons < 0 || P.cons == H.cons) && P.sz < H.sz &&
+                        (!fin_l || P.cons >= 0 || H.sz >= T.min_size);
+      const bool merging = part && (P.cons >= 0 || !fin_l || P.sz < T.min_size);
       const unsigned long long pend = __ballot(valid && lane >= start);
       const unsigned long long elig = __ballot(merging);
       const unsigned long long stop = pend & ~elig;
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
         const float x = r0 - P.d0, y = r1 - P.d1, z = r2 - P.d2;
         const float sd = (x * x + y * y + z * z) * (1.0f / 3.0f);
         const bool pass = case_s ? !(sd > T.split_s) : (sd <= T.pass_s);
-        const bool tested = case_s || (in_chain && !fin);
+        const bool tested = case_s || (in_chain && !fin_l);
         const unsigned long long fail = __ballot(in_chain && tested && !pass);
         const int fcut = fail ? (int)__builtin_ctzll(fail) : end;
         if (fcut > start) {
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
           }
           if (in_chain && lane < fcut) {
             nodes.parent[p] = rep;
-            if (case_s) ++n_forced; else if (fin) ++n_small; else ++n_regular;
+            if (case_s) ++n_forced; else if (fin_l) ++n_small; else ++n_regular;
           }
         }
         start = fcut;

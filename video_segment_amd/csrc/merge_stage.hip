@@ -474,6 +474,9 @@ __global__ __launch_bounds__(256) void k_resolve_followers(int n, const int32_t*
 // ------------------------------------------------------------------------------------------
 static inline unsigned Blocks(int n) { return (unsigned)((n + 255) / 256); }
 
+__global__ void k_max_segment(int max_segs, const int32_t* __restrict__ num_segs,
+                              const int32_t* __restrict__ seg_cnt, int below, int32_t* __restrict__ out);
+
 void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const int32_t* bucket_base,
                     const uint32_t* list_slot_base, uint8_t* kept_all, NodeArrays nodes,
                     const MergeParams& P, int inert_mode, MergeScratch& S, hipStream_t s,
@@ -718,7 +721,12 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   if (info) {   // how the stage decomposed (the caller sizes the next windows / groups with it)
     info->replayed = n_work;
     if (info->want_components) {
+      int32_t* d_max = S.num_active + 16;
+      VSG_HIP(hipMemsetAsync(d_max, 0, sizeof(int32_t), s));
+      hipLaunchKernelGGL(k_max_segment, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, S.num_segs, S.seg_cnt,
+                         spine ? spine_thr : 0x7fffffff, d_max);
       VSG_HIP(hipMemcpyAsync(&info->components, S.num_segs, sizeof(int), hipMemcpyDeviceToHost, s));
+      VSG_HIP(hipMemcpyAsync(&info->max_wave_segment, d_max, sizeof(int), hipMemcpyDeviceToHost, s));
       VSG_HIP(hipStreamSynchronize(s));
     }
   }
@@ -728,6 +736,20 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   }
   clear_marks();
   VSG_HIP(hipGetLastError());
+}
+
+// Largest component (in replayed edges) below `below`.
+__global__ __launch_bounds__(256) void k_max_segment(int max_segs, const int32_t* __restrict__ num_segs,
+                                                      const int32_t* __restrict__ seg_cnt, int below,
+                                                      int32_t* __restrict__ out) {
+  const int seg = blockIdx.x * 256 + threadIdx.x;
+  int v = 0;
+  if (seg < max_segs && seg < *num_segs) {
+    v = seg_cnt[seg];
+    if (v >= below) v = 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(out, v);
 }
 
 __global__ __launch_bounds__(256) void k_keep_virtual_bucket(const ListDesc* __restrict__ lists,

@@ -35,6 +35,8 @@ struct WaveTable {
   int32_t key[kTabSize];     // region id, -1: empty
   int32_t link[kTabSize];    // in-batch union-find over slots
   uint32_t res[kTabSize];    // reservation: (0xfffff - round) << 6 | lane, smaller wins
+  uint32_t res2[kTabSize];   // the same among the lanes that do not touch the hot region (only
+                             // filled in the rounds that need it)
   float4 ds[kTabSize];
   int32_t cons[kTabSize];
   int32_t flags[kTabSize];   // region flags | kTabDirty
@@ -122,6 +124,7 @@ struct WaveCounters {
   unsigned dbg_rounds = 0, dbg_nwin = 0, dbg_chain = 0, dbg_solo = 0, dbg_cut = 0, dbg_kept = 0;
   unsigned long long cyc_ph[5] = {0, 0, 0, 0, 0};   // reserve+load, closure, masks, generic, chain
   unsigned long long dbg_x[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_r[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // why the first blocked hot lane is no chain lane
 };
 
 // Replays one batch: lane `lane` holds the edge whose end regions sit in the table slots sa / sb
@@ -193,6 +196,7 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
     bool merging = false;
     bool case_s = false;
     bool fin = false;
+    int why = 0;
     // A chain starts at the first edge that touches the hot region and only if that lane is the
     // earliest pending edge on its other end; otherwise nothing can be absorbed in this round
     // and the classification below is skipped (the other hot edges just wait).
@@ -216,12 +220,15 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
       // (unconstrained partner): regular test while the hot region is not finalized, a finalized
       // hot region (>= min size) absorbs small partners only.
       const bool base = pending && mode_ok && !failed;
-      const bool part_a = base && own_a && A.flags == 0 && (A.cons < 0 || A.cons == Hs.cons) &&
-                          A.sz < Hs.sz;
-      const bool part_b = base && own_b && B.flags == 0 && (B.cons < 0 || B.cons == Hs.cons) &&
-                          B.sz < Hs.sz;
-      const bool merge_a = part_a && (A.cons >= 0 || !fin || A.sz < T.min_size);
-      const bool merge_b = part_b && (B.cons >= 0 || !fin || B.sz < T.min_size);
+      // (fin_x: the unconstrained edge to end x is not tested -- one of the two is finalized; the
+      // hot region has to be large then, or it would be the one that is absorbed as "small")
+      const bool fin_a = fin || (A.flags & kFlagFinalized), fin_b = fin || (B.flags & kFlagFinalized);
+      const bool part_a = base && own_a && PlainPartner(A.flags) && (A.cons < 0 || A.cons == Hs.cons) &&
+                          A.sz < Hs.sz && (!fin_a || A.cons >= 0 || Hs.sz >= T.min_size);
+      const bool part_b = base && own_b && PlainPartner(B.flags) && (B.cons < 0 || B.cons == Hs.cons) &&
+                          B.sz < Hs.sz && (!fin_b || B.cons >= 0 || Hs.sz >= T.min_size);
+      const bool merge_a = part_a && (A.cons >= 0 || !fin_a || A.sz < T.min_size);
+      const bool merge_b = part_b && (B.cons >= 0 || !fin_b || B.sz < T.min_size);
       const bool abs_a = pending && !own_a, abs_b = pending && !own_b;   // may be absorbed
       // A lane merges into the chain when one end is effectively hot and the other end is a
       // partner it owns (merge_x implies own_x, so that end can only be hot literally).  Hence a
@@ -248,10 +255,44 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
       P.d2 = pb_side ? B.d2 : A.d2;
       P.sz = pb_side ? B.sz : A.sz;
       P.cons = pb_side ? B.cons : A.cons;
-      P.flags = 0;
+      P.flags = pb_side ? B.flags : A.flags;
       ps = pb_side ? sb : sa;
       elig = hot_lane && !both && (pb_side ? part_b : part_a);
       merging = hot_lane && !both && (pb_side ? merge_b : merge_a);
+      // Repeats of a kept edge.  A giant region that keeps all its neighbours (both large, one of
+      // them finalized: nothing changes) meets every neighbour several times within a batch, and
+      // the repeats do not own the partner -- the chain would end at each of them, 1.4 edges per
+      // round on a component of half a million.  A repeat is kept like the first: the partner is
+      // the same region in the same state if the lane that owns it is a kept chain lane and no
+      // lane in between touches it from outside the hot region (res2, second reservation pass).
+      {
+        const int fl = pb_side ? B.flags : A.flags;
+        const bool own_p = pb_side ? own_b : own_a;
+        const int owner = pb_side ? ob : oa;
+        const bool fin_p = fin || (fl & kFlagFinalized);
+        const bool plain = base && PlainPartner(fl) && (P.cons < 0 || P.cons == Hs.cons) && P.sz < Hs.sz &&
+                           (!fin_p || P.cons >= 0 || Hs.sz >= T.min_size);
+        const bool keeps = plain && !(P.cons >= 0 || !fin_p || P.sz < T.min_size);
+        const unsigned long long kept_lanes = __ballot(elig && !merging);
+        const bool repeat = hot_lane && !both && !elig && !own_p && keeps && (a_hot || b_hot) &&
+                            ((kept_lanes >> owner) & 1ull) && !(kDbg && (dbg_flags & 512));
+        if (__ballot(repeat)) {
+          if (pending && !a_hot && !b_hot) {
+            atomicMin(&tab.res2[sa], key);
+            atomicMin(&tab.res2[sb], key);
+          }
+          WaveSync();
+          if (repeat && tab.res2[ps] > key) elig = true;   // (merging stays false)
+        }
+      }
+      if constexpr (kDbg) {
+        const bool ow = pb_side ? own_b : own_a;
+        const int fl = pb_side ? B.flags : A.flags;
+        const bool fl_l = fin || (fl & kFlagFinalized);
+        why = (!ow ? 1 : 0) | (!PlainPartner(fl) ? 2 : 0) | (!(P.cons < 0 || P.cons == Hs.cons) ? 4 : 0) |
+              (!(P.sz < Hs.sz) ? 8 : 0) | (!base ? 16 : 0) |
+              (!(!fl_l || P.cons >= 0 || Hs.sz >= T.min_size) ? 32 : 0);
+      }
       case_s = P.cons >= 0;
     }
     const unsigned long long ph2 = Clock();
@@ -287,6 +328,12 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
         C.dbg_x[3] += (chain_mask != 0);                             // rounds with a chain
         C.dbg_x[4] += (nwin_mask != 0);                              // rounds with generic commits
         C.dbg_x[5] += (unsigned)__popcll(pend_mask & ~hot_mask & ~nwin_mask);   // waiting non-hot lanes
+        if (blocked) {
+          const int wb = ReadLaneI(why, (int)__builtin_ctzll(blocked));
+          for (int q = 0; q < 6; ++q) C.dbg_r[q] += (wb >> q) & 1;
+          C.dbg_r[6] += (wb == 0);
+          ++C.dbg_r[7];
+        }
       }
     }
 
@@ -362,7 +409,8 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
       const bool in_chain = (chain_mask >> lane) & 1ull;
       merging = in_chain && merging;
       case_s = in_chain && case_s;
-      const bool tested = case_s || (in_chain && !fin);
+      const bool fin_l = fin || (P.flags & kFlagFinalized);   // this lane's edge is not tested
+      const bool tested = case_s || (in_chain && !fin_l);
       const int v = merging ? P.sz : 0;
       const int incl = WaveInclusiveSum(v);
       const int S = Hs.sz + incl - v;     // size of the hot region before this lane's merge
@@ -461,7 +509,8 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
           const int out = DecideEdge(a, b, T, st);
           const bool km = (merging_mask >> k) & 1ull;
           if (km) {
-            if (out != kOutMerge1 || st != (b0.cons >= 0 ? 1 : (fin ? 3 : 2))) ++bad;
+            if (out != kOutMerge1 ||
+                st != (b0.cons >= 0 ? 1 : ((fin || (b0.flags & kFlagFinalized)) ? 3 : 2))) ++bad;
             Hc = a;
           } else {
             if (out != kOutKeep || !SameState(a, Hc) || !SameState(b, b0)) ++bad;
@@ -480,9 +529,9 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
       if (do_commit) {
         if (merging) {
           CommitLoser(tab, nodes, ps, hot);
-          if (case_s) ++C.n_forced; else if (fin) ++C.n_small; else ++C.n_regular;
+          if (case_s) ++C.n_forced; else if (fin_l) ++C.n_small; else ++C.n_regular;
         } else {
-          my_kept = true;   // both regions large, the hot one finalized: nothing changes
+          my_kept = true;   // both regions large, one of them finalized: nothing changes
         }
         pending = false;
       }
@@ -537,6 +586,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
   for (int s = threadIdx.x; s < kTabSize; s += 128) {
     tab.key[s] = -1;
     tab.res[s] = 0xffffffffu;
+    tab.res2[s] = 0xffffffffu;
   }
   __syncthreads();
   const int nseg = *num_segs;
@@ -805,6 +855,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           }
           tab.key[s] = -1;
           tab.res[s] = 0xffffffffu;
+          tab.res2[s] = 0xffffffffu;
         }
       }
       // Make this batch's stores visible to the next batch's loads (same CU: L1 is shared).
@@ -857,6 +908,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
     atomicAdd(&stats[29], dbg_taken);
     for (int k = 0; k < 5; ++k) atomicAdd(&stats[32 + k], C.cyc_ph[k]);
     for (int k = 0; k < 6; ++k) atomicAdd(&stats[38 + k], C.dbg_x[k]);
+    for (int k = 0; k < 8; ++k) atomicAdd(&stats[64 + k], C.dbg_r[k]);
     atomicAdd(&stats[30], dbg_live);
   }
 }
