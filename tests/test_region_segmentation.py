@@ -128,6 +128,20 @@ def test_region_segmentation_bytes_match_oracle(vsg, W, H, N, chunk, flow, opts)
     assert check_structure(got, W, H) >= 1
 
 
+def test_threaded_descriptor_accumulation_is_identical(vsg, monkeypatch):
+    """The pixels of a frame's regions are visited on several host threads (dense scratch table
+    per thread, bins written back in first-touch order): forced on at a small size."""
+    monkeypatch.setenv("VSG_PARALLEL_MIN_WORK", "1")
+    W, H, N, chunk = 96, 64, 40, 8
+    fl = synth.const_flow(W, H)
+    feed = overseg(W, H, N, chunk, synth.soft_frame, fl)
+    got, want = run_both(vsg, W, H, feed, dict(chunk_set_size=3, chunk_set_overlap=1, min_region_num=3))
+    assert got == want
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (70, 53, 3), dtype=np.uint8)
+    assert np.array_equal(vsg.bgr_to_lab(img), ol.bgr_to_lab(img))
+
+
 def test_reference_abort_is_reported_not_reproduced(vsg):
     """On the bench input neighbouring checker cells have disjoint Lab histograms: distance exactly
     1.0, which RegionAgglomerationGraph files under the virtual edges and then refuses to merge
