@@ -206,6 +206,13 @@ __device__ __forceinline__ int DecideEdge(RState& s1, RState& s2, const StageThr
 // test before.
 __device__ __forceinline__ bool PlainPartner(int flags) { return (flags & ~(int)kFlagFinalized) == 0; }
 
+// DecideEdge keeps the edge and changes neither state: different constraints, or (unconstrained
+// rule) one of the two finalized -- no test -- and both at least of minimum size.
+__device__ __forceinline__ bool NoopPair(const RState& s1, const RState& s2, const StageThr& T) {
+  if (s1.cons >= 0 && s2.cons >= 0) return s1.cons != s2.cons;
+  return ((s1.flags | s2.flags) & kFlagFinalized) && s1.sz >= T.min_size && s2.sz >= T.min_size;
+}
+
 // A tentatively settled edge stays settled only while the constraints of its two regions do not
 // change.  o1/o2: states before the edge, n1/n2: states that replace them (for a merge both are
 // the survivor's state).

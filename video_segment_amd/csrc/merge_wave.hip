@@ -170,18 +170,43 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
     const unsigned long long ph0 = Clock();
     const bool a_hot = (sa == hot), b_hot = (sb == hot);
     const uint32_t key = ((0xfffffu - round) << 6) | (uint32_t)lane;
+    RState A = {}, B = {};
+    if (pending) {
+      A = TabLoad(tab, sa);
+      B = TabLoad(tab, sb);
+    }
+    // An edge that is certainly *kept without changing anything* (NoopPair: different constraints,
+    // or one region finalized and both large) does not have to wait for earlier edges of the same
+    // kind, only for earlier edges that may change one of its regions.  So beside the reservation
+    // among all pending lanes (res) there is a second one among the lanes that are not of this
+    // kind (res2, only in the rounds that have such a lane): a kept lane is free on region x when
+    // res2[x] holds no earlier lane.  (A giant region that keeps all its neighbours meets each of
+    // them several times within a batch, next to the edges between the neighbours themselves:
+    // with one reservation that was 1.4 edges per round on components of half a million.)
+    const unsigned long long lit_mask0 = __ballot(pending && (a_hot || b_hot));
+    RState Hs0 = {};
+    if (lit_mask0) Hs0 = TabLoad(tab, hot);   // uniform
+    const bool noop_l = pending && !(kDbg && (dbg_flags & 512)) &&
+                        (a_hot ? NoopPair(B, Hs0, T) : (b_hot ? NoopPair(A, Hs0, T) : NoopPair(A, B, T)));
+    const bool any_noop = __ballot(noop_l) != 0;
     if (pending) {
       if (!a_hot) atomicMin(&tab.res[sa], key);
       if (!b_hot) atomicMin(&tab.res[sb], key);
+      if (any_noop && !noop_l) {
+        if (!a_hot) atomicMin(&tab.res2[sa], key);
+        if (!b_hot) atomicMin(&tab.res2[sb], key);
+      }
     }
     WaveSync();
     uint32_t res_a = 0, res_b = 0;
-    RState A = {}, B = {};
+    bool free_a = false, free_b = false;   // (kept lanes) no earlier lane may change region x
     if (pending) {
       res_a = tab.res[sa];
       res_b = tab.res[sb];
-      A = TabLoad(tab, sa);
-      B = TabLoad(tab, sb);
+      if (noop_l) {
+        free_a = a_hot || tab.res2[sa] > key;
+        free_b = b_hot || tab.res2[sb] > key;
+      }
     }
     // own_x: this lane is the earliest pending edge on region x (the hot region is not reserved)
     const unsigned long long ph1 = Clock();
@@ -202,7 +227,8 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
     // and the classification below is skipped (the other hot edges just wait).
     const unsigned long long lit_mask = __ballot(hot_lane);
     const bool chain_possible =
-        lit_mask != 0 && ((__ballot(hot_lane && (own_a || own_b)) >> __builtin_ctzll(lit_mask)) & 1ull);
+        lit_mask != 0 && ((__ballot(hot_lane && (own_a || own_b || (noop_l && free_a && free_b))) >>
+                           __builtin_ctzll(lit_mask)) & 1ull);
     if (chain_possible) {
       Hs = TabLoad(tab, hot);   // uniform
       fin = (Hs.flags & kFlagFinalized) != 0;
@@ -223,12 +249,26 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
       // (fin_x: the unconstrained edge to end x is not tested -- one of the two is finalized; the
       // hot region has to be large then, or it would be the one that is absorbed as "small")
       const bool fin_a = fin || (A.flags & kFlagFinalized), fin_b = fin || (B.flags & kFlagFinalized);
-      const bool part_a = base && own_a && PlainPartner(A.flags) && (A.cons < 0 || A.cons == Hs.cons) &&
-                          A.sz < Hs.sz && (!fin_a || A.cons >= 0 || Hs.sz >= T.min_size);
-      const bool part_b = base && own_b && PlainPartner(B.flags) && (B.cons < 0 || B.cons == Hs.cons) &&
-                          B.sz < Hs.sz && (!fin_b || B.cons >= 0 || Hs.sz >= T.min_size);
-      const bool merge_a = part_a && (A.cons >= 0 || !fin_a || A.sz < T.min_size);
-      const bool merge_b = part_b && (B.cons >= 0 || !fin_b || B.sz < T.min_size);
+      // noop_x: the edge to end x is kept and changes nothing, whichever of the two is larger --
+      // different constraints, or (unconstrained rule) one of them finalized and both large.  The
+      // tail of the first chunk of a video is made of these: the remaining unfinalized regions
+      // against their finalized neighbours, one round per edge unless they may join the chain.
+      const bool noop_a = (A.cons >= 0 && Hs.cons >= 0) ? (A.cons != Hs.cons)
+                                                        : (fin_a && A.sz >= T.min_size && Hs.sz >= T.min_size);
+      const bool noop_b = (B.cons >= 0 && Hs.cons >= 0) ? (B.cons != Hs.cons)
+                                                        : (fin_b && B.sz >= T.min_size && Hs.sz >= T.min_size);
+      const bool plain_a = base && PlainPartner(A.flags) &&
+                           (noop_a || ((A.cons < 0 || A.cons == Hs.cons) && A.sz < Hs.sz &&
+                                       (!fin_a || A.cons >= 0 || Hs.sz >= T.min_size)));
+      const bool plain_b = base && PlainPartner(B.flags) &&
+                           (noop_b || ((B.cons < 0 || B.cons == Hs.cons) && B.sz < Hs.sz &&
+                                       (!fin_b || B.cons >= 0 || Hs.sz >= T.min_size)));
+      // (a lane that took part in the reservations as a kept lane may only be one: its view of
+      // the pair can be stale -- an end that an earlier chain lane absorbs -- and then it waits)
+      const bool part_a = plain_a && (noop_l ? (noop_a && free_a && !a_hot) : own_a);
+      const bool part_b = plain_b && (noop_l ? (noop_b && free_b && !b_hot) : own_b);
+      const bool merge_a = part_a && !noop_a && (A.cons >= 0 || !fin_a || A.sz < T.min_size);
+      const bool merge_b = part_b && !noop_b && (B.cons >= 0 || !fin_b || B.sz < T.min_size);
       const bool abs_a = pending && !own_a, abs_b = pending && !own_b;   // may be absorbed
       // A lane merges into the chain when one end is effectively hot and the other end is a
       // partner it owns (merge_x implies own_x, so that end can only be hot literally).  Hence a
@@ -259,32 +299,6 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
       ps = pb_side ? sb : sa;
       elig = hot_lane && !both && (pb_side ? part_b : part_a);
       merging = hot_lane && !both && (pb_side ? merge_b : merge_a);
-      // Repeats of a kept edge.  A giant region that keeps all its neighbours (both large, one of
-      // them finalized: nothing changes) meets every neighbour several times within a batch, and
-      // the repeats do not own the partner -- the chain would end at each of them, 1.4 edges per
-      // round on a component of half a million.  A repeat is kept like the first: the partner is
-      // the same region in the same state if the lane that owns it is a kept chain lane and no
-      // lane in between touches it from outside the hot region (res2, second reservation pass).
-      {
-        const int fl = pb_side ? B.flags : A.flags;
-        const bool own_p = pb_side ? own_b : own_a;
-        const int owner = pb_side ? ob : oa;
-        const bool fin_p = fin || (fl & kFlagFinalized);
-        const bool plain = base && PlainPartner(fl) && (P.cons < 0 || P.cons == Hs.cons) && P.sz < Hs.sz &&
-                           (!fin_p || P.cons >= 0 || Hs.sz >= T.min_size);
-        const bool keeps = plain && !(P.cons >= 0 || !fin_p || P.sz < T.min_size);
-        const unsigned long long kept_lanes = __ballot(elig && !merging);
-        const bool repeat = hot_lane && !both && !elig && !own_p && keeps && (a_hot || b_hot) &&
-                            ((kept_lanes >> owner) & 1ull) && !(kDbg && (dbg_flags & 512));
-        if (__ballot(repeat)) {
-          if (pending && !a_hot && !b_hot) {
-            atomicMin(&tab.res2[sa], key);
-            atomicMin(&tab.res2[sb], key);
-          }
-          WaveSync();
-          if (repeat && tab.res2[ps] > key) elig = true;   // (merging stays false)
-        }
-      }
       if constexpr (kDbg) {
         const bool ow = pb_side ? own_b : own_a;
         const int fl = pb_side ? B.flags : A.flags;
@@ -313,7 +327,7 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
     const bool own = pending && (a_hot || own_a) && (b_hot || own_b);
     const bool solo = hot_lane && own && !elig && !both &&
                       lane == (int)__builtin_ctzll(hot_mask | (1ull << 63));
-    bool n_win = pending && own && (!hot_lane || solo);
+    bool n_win = pending && ((own && (!hot_lane || solo)) || (noop_l && !hot_lane && free_a && free_b));
     if (kDbg && (dbg_flags & 8)) n_win = n_win && lane == (int)__builtin_ctzll(__ballot(pending));
     if constexpr (kDbg) {
       const unsigned long long nwin_mask = __ballot(n_win), solo_mask = __ballot(solo);
@@ -408,9 +422,9 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
     if (chain_mask) {
       const bool in_chain = (chain_mask >> lane) & 1ull;
       merging = in_chain && merging;
-      case_s = in_chain && case_s;
+      case_s = merging && case_s;
       const bool fin_l = fin || (P.flags & kFlagFinalized);   // this lane's edge is not tested
-      const bool tested = case_s || (in_chain && !fin_l);
+      const bool tested = merging && (case_s || !fin_l);   // (a kept lane changes nothing: noop_x)
       const int v = merging ? P.sz : 0;
       const int incl = WaveInclusiveSum(v);
       const int S = Hs.sz + incl - v;     // size of the hot region before this lane's merge
@@ -531,7 +545,7 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
           CommitLoser(tab, nodes, ps, hot);
           if (case_s) ++C.n_forced; else if (fin_l) ++C.n_small; else ++C.n_regular;
         } else {
-          my_kept = true;   // both regions large, one of them finalized: nothing changes
+          my_kept = true;   // noop_x: nothing changes
         }
         pending = false;
       }
