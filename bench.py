@@ -400,6 +400,26 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps):
         del fr
     out["workloads"] = wl
 
+    # ---- the same video over two chunk engines on the one GPU (video_segment_amd/pipelined.py) ------
+    fr = make_frames("bench", W, H, chunk + (chunk - 1) * 6, dev)
+    pipe = vsg.PipelinedDenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=device_index),
+                                          has_flow=True)
+    got = 0
+    for k, f in enumerate(fr):
+        got += pipe.process_frame(f, flow if k > 0 else None, flush=(k == len(fr) - 1))
+    stamps = pipe.stamps
+    pipe.close()
+    assert got == len(fr)
+    steady = (stamps[-2] - stamps[1]) / (len(stamps) - 3)   # without the first and the flushed chunk
+    out["pipelined"] = {
+        "workload": "the headline video, even chunks on one DenseSegmentation engine and odd chunks on a "
+                    "second one (two host threads, label planes handed over on the device): an engine "
+                    "builds its chunk graph while the other one merges; byte-identical output "
+                    "(tests/test_gpu_pipelined.py)",
+        "value": (chunk - 1) / steady, "unit": "frames/s", "ms_per_step": steady * 1e3,
+        "chunks_timed": len(stamps) - 3}
+    del fr
+
     # ---- S concurrent streams on the one GPU -------------------------------------------------------
     # One PROCESS per stream (the control flow of --gpus S with every rank on this GPU: gloo barrier
     # and reductions, no data-path collective).  Threads of one process are measured as well

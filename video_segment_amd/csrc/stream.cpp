@@ -143,6 +143,10 @@ int DenseSegmentationHip::ProcessFrame(bool flush, const uint8_t* bgr, size_t st
                                        const float* flow, bool has_flow_stream, int mem) {
   results_.clear();
   encoded_.clear();
+  if (forget_pending_) {   // first frame of another video after Restart
+    graph_->ForgetLearned();
+    forget_pending_ = false;
+  }
   if (!graph_open_) {
     graph_->Reset(options_.chunk_size);
     graph_open_ = true;
@@ -499,10 +503,12 @@ void DenseSegmentationHip::ExpectHalo() {
   VSG_REQUIRE(frames_fed_ == 0 && !graph_open_ && !pending_import_, -3, "expect_halo needs a fresh stream");
   pending_import_ = true;
   halo_deferred_ = true;
+  forget_pending_ = false;   // the same video goes on: what the graph learned about it stays
 }
 
 void DenseSegmentationHip::ImportHalo(const int32_t* virt, const int32_t* cons, int mem,
                                       const int64_t scalars[4]) {
+  forget_pending_ = false;
   const bool late = halo_deferred_ && !pending_import_;   // frames were fed before the halo
   VSG_REQUIRE(late || (frames_fed_ == 0 && !graph_open_), -3, "import_halo needs a fresh stream");
   const hipMemcpyKind kind = mem == VSG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
@@ -548,7 +554,7 @@ void DenseSegmentationHip::Restart() {
   halo_valid_ = false;
   flow_stream_seen_ = false;
   frames_fed_ = 0;
-  graph_->ForgetLearned();
+  forget_pending_ = true;   // unless the stream continues a video (ExpectHalo / ImportHalo)
   std::memset(&accum_, 0, sizeof(accum_));
 }
 

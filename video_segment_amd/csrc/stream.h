@@ -132,6 +132,7 @@ class DenseSegmentationHip {
 
   std::vector<DevPlane> feature_buffer_;
   std::vector<DevPlane> flow_dev_buffer_;     // W*H*2 f32 on the device, null = empty flow
+  bool forget_pending_ = false;   // Restart: forget what the graph learned unless the video continues
   bool halo_deferred_ = false;    // ExpectHalo(): frames may precede ImportHalo()
   bool flow_stream_seen_ = false;
   int64_t frames_fed_ = 0;   // frames handed to this handle (has_flow_stream must not change)

@@ -1,0 +1,165 @@
+"""One video, two chunk engines on one GPU: the chunk chain of multi_gpu.py folded into a single
+process.
+
+A DenseSegmentation stream is synchronous: the call that completes a chunk returns after the
+merge, the read-out and the host post-processing, and only then the caller can feed the next
+chunk's frames -- whose pre-filter, edge weights and bucket sort do not depend on the chunk before
+(SURVEY.md 8(e)).  Here even chunks go to one engine and odd chunks to the other, each on its own
+host thread: an engine builds the graph of its chunk while the other one still merges, imports the
+two label planes of the hand-off right before the frame that completes its chunk
+(vsg_stream_expect_halo / vsg_stream_import_halo) and passes its own on afterwards -- the same
+protocol, byte for byte the same output, as the multi-GPU chain (run_chain) and as a single stream.
+The merge of chunk c+1 still needs the final labels of chunk c: what overlaps is everything else.
+
+Interface of DenseSegmentation (process_frame / result_bytes / close); results arrive in frame
+order, possibly a chunk later than from a single stream (`process_frame` returns what is ready,
+`flush=True` waits for the rest)."""
+import queue
+import threading
+import time
+
+import numpy as np
+
+from .dense_segmentation import DenseSegmentation
+from .multi_gpu import product_halo
+
+
+class PipelinedDenseSegmentation:
+    def __init__(self, W, H, options, has_flow=True, device=None):
+        import torch
+        self.W, self.H = W, H
+        self.chunk = int(options.chunk_size)
+        if self.chunk < 3:
+            raise ValueError("chunk_size >= 3")
+        self.stride = self.chunk - 1
+        self.device = device if device is not None else torch.device("cuda", max(int(options.device), 0))
+        self.engines = [DenseSegmentation(W, H, options, has_flow=has_flow) for _ in range(2)]
+        self._in = [queue.Queue(maxsize=2 * self.chunk) for _ in range(2)]
+        self._halo = [queue.Queue() for _ in range(2)]
+        self._cond = threading.Condition()
+        self._done = {}          # chunk -> ([bytes], VsgTimings, completion time)
+        self._next_chunk = 0     # next chunk whose results are handed out
+        self._error = None
+        self._frames = 0
+        self._chunks_fed = 0
+        self._ready = []
+        self.timings = []        # VsgTimings of the boundaries handed out by the last call
+        self.stamps = []         # time.perf_counter() at which every chunk was complete
+        self._threads = [threading.Thread(target=self._engine_loop, args=(p,), daemon=True) for p in range(2)]
+        for t in self._threads:
+            t.start()
+
+    # ---- engine threads -------------------------------------------------------------------------
+    def _engine_loop(self, p):
+        import torch
+        eng = self.engines[p]
+        used = False
+        try:
+            torch.cuda.set_device(self.device)
+            while True:
+                msg = self._in[p].get()
+                if msg is None:
+                    return
+                c, frame, flow, first, last, flush = msg
+                if first:
+                    if used:
+                        eng.restart()
+                    used = True
+                    if c > 0:
+                        eng.expect_halo()
+                if last and c > 0:
+                    halo = self._halo[p].get()     # the labels of chunk c - 1 (the other engine)
+                    if halo is None:
+                        return
+                    virt, cons, scal = halo
+                    eng.import_halo(virt, cons, scal)
+                n = eng.process_frame(frame, flow, flush=flush)
+                if last:
+                    res = [eng.result_bytes(i) for i in range(n)]
+                    t = eng.last_timings()
+                    if not flush:
+                        virt, cons, scal = product_halo(eng, self.W, self.H, self.device)
+                        torch.cuda.current_stream().synchronize()   # the copies, before the other thread reads them
+                        self._halo[1 - p].put((virt, cons, scal.numpy()))
+                    with self._cond:
+                        self._done[c] = (res, t, time.perf_counter())
+                        self._cond.notify_all()
+                elif n:
+                    raise RuntimeError("results before the end of a chunk")
+        except BaseException as e:   # noqa: BLE001 -- handed to the caller's thread
+            with self._cond:
+                self._error = e
+                self._cond.notify_all()
+            self._halo[1 - p].put(None)
+
+    # ---- caller side ------------------------------------------------------------------------------
+    def _collect(self, wait_for_chunks):
+        """Moves the finished chunks, in order, to the ready list; waits until `wait_for_chunks`
+        chunks have been handed out in total."""
+        ready, timings = [], []
+        with self._cond:
+            while True:
+                if self._error is not None:
+                    raise self._error
+                while self._next_chunk in self._done:
+                    res, t, stamp = self._done.pop(self._next_chunk)
+                    ready += res
+                    timings.append(t)
+                    self.stamps.append(stamp)
+                    self._next_chunk += 1
+                if self._next_chunk >= wait_for_chunks:
+                    break
+                self._cond.wait(0.5)
+        self._ready, self.timings = ready, timings
+        return len(ready)
+
+    def process_frame(self, bgr, flow=None, flush=False, wait=False):
+        """Feeds frame k of the video.  Returns the number of results that are ready
+        (result_bytes(i)); wait=True: blocks until every chunk that is complete with this frame
+        has been handed out (what a single stream does)."""
+        if bgr is None:
+            raise ValueError("the pipelined unit flushes with the last frame (flush=True)")
+        k, s = self._frames, self.stride
+        self._frames += 1
+        ends_chunk = k > 0 and k % s == 0
+        if ends_chunk:
+            c = k // s - 1
+            self._in[c % 2].put((c, bgr, flow, False, True, flush))
+            self._chunks_fed = c + 1
+            if not flush:
+                self._in[(c + 1) % 2].put((c + 1, bgr, flow, True, False, False))
+        else:
+            c = k // s
+            self._in[c % 2].put((c, bgr, flow, k == 0, flush, flush))
+            if flush:
+                self._chunks_fed = c + 1
+        if flush:
+            n = self._collect(self._chunks_fed)
+            self._shutdown()
+            return n
+        return self._collect(self._chunks_fed if wait else 0)
+
+    def result_bytes(self, i):
+        return self._ready[i]
+
+    def _shutdown(self):
+        for p in range(2):
+            self._in[p].put(None)
+        for t in self._threads:
+            t.join()
+        self._threads = []
+
+    def close(self):
+        if self._threads:
+            for p in range(2):
+                self._halo[p].put(None)
+            self._shutdown()
+        for e in self.engines:
+            e.close()
+        self.engines = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
