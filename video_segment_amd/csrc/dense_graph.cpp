@@ -629,7 +629,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
         // few, large components already: the rest of the bucket in one stage -- in as few as the
         // tree replay can take (its rank stamps address 2^27 edges; the giant components of a
         // low-contrast 4K bucket have 260 M, and left to the wave worker they cost seconds)
-        const int64_t rest_cap = getenv("VSG_REST_CAP") ? atoll(getenv("VSG_REST_CAP")) : (96ll << 20);
+        const int64_t rest_cap = getenv("VSG_REST_CAP") ? atoll(getenv("VSG_REST_CAP")) : (119ll << 20);
         const int64_t rest_n = (int64_t)n_b - pos;
         const int pieces = (int)std::max<int64_t>(1, (rest_n + rest_cap - 1) / rest_cap);
         const int64_t piece = (rest_n + pieces - 1) / pieces;

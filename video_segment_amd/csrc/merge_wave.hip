@@ -170,8 +170,16 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
     const unsigned long long ph0 = Clock();
     const bool a_hot = (sa == hot), b_hot = (sb == hot);
     const uint32_t key = ((0xfffffu - round) << 6) | (uint32_t)lane;
+    if (pending) {
+      if (!a_hot) atomicMin(&tab.res[sa], key);
+      if (!b_hot) atomicMin(&tab.res[sb], key);
+    }
+    WaveSync();
+    uint32_t res_a = 0, res_b = 0;
     RState A = {}, B = {};
     if (pending) {
+      res_a = tab.res[sa];
+      res_b = tab.res[sb];
       A = TabLoad(tab, sa);
       B = TabLoad(tab, sb);
     }
@@ -183,29 +191,30 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
     // res2[x] holds no earlier lane.  (A giant region that keeps all its neighbours meets each of
     // them several times within a batch, next to the edges between the neighbours themselves:
     // with one reservation that was 1.4 edges per round on components of half a million.)
-    const unsigned long long lit_mask0 = __ballot(pending && (a_hot || b_hot));
-    RState Hs0 = {};
-    if (lit_mask0) Hs0 = TabLoad(tab, hot);   // uniform
-    const bool noop_l = pending && !(kDbg && (dbg_flags & 512)) &&
-                        (a_hot ? NoopPair(B, Hs0, T) : (b_hot ? NoopPair(A, Hs0, T) : NoopPair(A, B, T)));
-    const bool any_noop = __ballot(noop_l) != 0;
-    if (pending) {
-      if (!a_hot) atomicMin(&tab.res[sa], key);
-      if (!b_hot) atomicMin(&tab.res[sb], key);
-      if (any_noop && !noop_l) {
-        if (!a_hot) atomicMin(&tab.res2[sa], key);
-        if (!b_hot) atomicMin(&tab.res2[sb], key);
-      }
-    }
-    WaveSync();
-    uint32_t res_a = 0, res_b = 0;
+    // Most rounds of the force-merge buckets have no finalized region and no pair of constraints
+    // in the wavefront at all: they skip all of it (any_kept_kind).
+    const bool any_kept_kind =
+        __ballot(pending && (((A.flags | B.flags) & kFlagFinalized) ||
+                             (A.cons >= 0 && B.cons >= 0 && A.cons != B.cons))) != 0 &&
+        !(kDbg && (dbg_flags & 512));
+    bool noop_l = false;
     bool free_a = false, free_b = false;   // (kept lanes) no earlier lane may change region x
-    if (pending) {
-      res_a = tab.res[sa];
-      res_b = tab.res[sb];
-      if (noop_l) {
-        free_a = a_hot || tab.res2[sa] > key;
-        free_b = b_hot || tab.res2[sb] > key;
+    if (any_kept_kind) {
+      RState Hs0 = {};
+      if (__ballot(pending && (a_hot || b_hot))) Hs0 = TabLoad(tab, hot);   // uniform
+      noop_l = pending && (a_hot ? NoopPair(B, Hs0, T) : (b_hot ? NoopPair(A, Hs0, T) : NoopPair(A, B, T)));
+      if (__ballot(noop_l)) {
+        if (pending && !noop_l) {
+          if (!a_hot) atomicMin(&tab.res2[sa], key);
+          if (!b_hot) atomicMin(&tab.res2[sb], key);
+        }
+        WaveSync();
+        if (noop_l) {
+          free_a = a_hot || tab.res2[sa] > key;
+          free_b = b_hot || tab.res2[sb] > key;
+        }
+      } else {
+        noop_l = false;
       }
     }
     // own_x: this lane is the earliest pending edge on region x (the hot region is not reserved)
@@ -253,10 +262,12 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
       // different constraints, or (unconstrained rule) one of them finalized and both large.  The
       // tail of the first chunk of a video is made of these: the remaining unfinalized regions
       // against their finalized neighbours, one round per edge unless they may join the chain.
-      const bool noop_a = (A.cons >= 0 && Hs.cons >= 0) ? (A.cons != Hs.cons)
-                                                        : (fin_a && A.sz >= T.min_size && Hs.sz >= T.min_size);
-      const bool noop_b = (B.cons >= 0 && Hs.cons >= 0) ? (B.cons != Hs.cons)
-                                                        : (fin_b && B.sz >= T.min_size && Hs.sz >= T.min_size);
+      const bool noop_a = any_kept_kind &&
+                          ((A.cons >= 0 && Hs.cons >= 0) ? (A.cons != Hs.cons)
+                                                         : (fin_a && A.sz >= T.min_size && Hs.sz >= T.min_size));
+      const bool noop_b = any_kept_kind &&
+                          ((B.cons >= 0 && Hs.cons >= 0) ? (B.cons != Hs.cons)
+                                                         : (fin_b && B.sz >= T.min_size && Hs.sz >= T.min_size));
       const bool plain_a = base && PlainPartner(A.flags) &&
                            (noop_a || ((A.cons < 0 || A.cons == Hs.cons) && A.sz < Hs.sz &&
                                        (!fin_a || A.cons >= 0 || Hs.sz >= T.min_size)));
