@@ -577,16 +577,16 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     // 16 K edges; it only grows between chunks -- doubled every eighth chunk, to follow the video
     // -- because the threshold is sharp: twice the edges per stage that give components of 5 K
     // give one of 60 K.)
-    auto run = [&](int w, int j0, int n, bool measure, bool limited) {
+    auto run = [&](int w, int j0, int n, int measure, bool limited) {
       StageInfo info;
-      info.want_components = measure || debug_stages;
+      info.want_components = debug_stages ? 2 : measure;
       RunStageDebug(b, w, windows, j0, n, P, inert_mode, S, debug_stages, &info);
       group_active += info.replayed;
       if (debug_stages && info.want_components && wave_target_active_ != kNoWindowTarget) {
         std::fprintf(stderr, "[vsg]   window: max wave segment %d, target %lld active (density %.4f), limited %d\n",
                      info.max_wave_segment, (long long)wave_target_active_, last_density_, (int)limited);
       }
-      if (info.want_components && adapt_windows) {
+      if (measure && adapt_windows && (measure > 1 || info.replayed > 16384)) {
         last_density_ = std::max((double)info.replayed / (double)std::max(n, 1), 1e-6);
         if (info.max_wave_segment > 16384) {
           wave_target_active_ = std::max<int64_t>(std::min<int64_t>(wave_target_active_, info.replayed) / 2, 8192);
@@ -616,8 +616,9 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
       while (pos < j1) {
         bool limited = false;
         const int take = (int)limit(j1 - pos, &limited);
-        const StageInfo info = run(w, pos, take, probe || (big_enough && (limited || windows == 1)) ||
-                                                      wave_target_active_ != kNoWindowTarget, limited);
+        const StageInfo info = run(w, pos, take,
+                                   probe ? 2 : ((big_enough && (limited || windows == 1)) ||
+                                                wave_target_active_ != kNoWindowTarget) ? 1 : 0, limited);
         pos += take;
         // (and a window that replays few edges is all overhead)
         if (probe && ((int64_t)info.replayed >= (int64_t)window_bushy * std::max(info.components, 1) ||
@@ -636,7 +637,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
         for (int q = 0; pos < n_b; ++q) {
           bool limited = false;
           const int take = (int)limit(std::min<int64_t>(piece, n_b - pos), &limited);
-          run(-1 - q, pos, take, big_enough, limited);
+          run(-1 - q, pos, take, big_enough ? 1 : 0, limited);
           pos += take;
         }
       }

@@ -197,7 +197,8 @@ void LaunchInitIdentity(int32_t* a, size_t n, hipStream_t s);
 // bucket's edge sequence (list order, then position).  Any split of a bucket into consecutive
 // windows run one after the other is equivalent to one stage over the whole bucket.
 struct StageInfo {
-  bool want_components = false;   // in: also report `components` (one more synchronisation)
+  int want_components = 0;   // in: 1: report `components` / `max_wave_segment` of a stage that replays
+                             // more than 16 K edges (one more synchronisation), 2: of any stage
   int replayed = 0;     // edges handed to the workers (run leaders)
   int components = 0;   // independent components they fell into
   int max_wave_segment = 0;   // (with want_components) edges of the largest component that one

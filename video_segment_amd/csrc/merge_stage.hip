@@ -720,7 +720,9 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   }
   if (info) {   // how the stage decomposed (the caller sizes the next windows / groups with it)
     info->replayed = n_work;
-    if (info->want_components) {
+    // (a component above the window threshold needs that many replayed edges: small stages are
+    // not worth the synchronisation)
+    if (info->want_components && (info->want_components > 1 || n_work > 16384)) {
       int32_t* d_max = S.num_active + 16;
       VSG_HIP(hipMemsetAsync(d_max, 0, sizeof(int32_t), s));
       hipLaunchKernelGGL(k_max_segment, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, S.num_segs, S.seg_cnt,
