@@ -200,10 +200,10 @@ def test_seam3_region_list_constrained_chunk(vsg):
     assert len(gg.get_intervals(0)) == 0   # the virtual slice is never rasterized
 
 
-def run_streams(vsg, W, H, N, kind, flow, chunk, seed=5, frames=None):
+def run_streams(vsg, W, H, N, kind, flow, chunk, seed=5, frames=None, **options):
     rng = np.random.default_rng(seed)
-    go = vsg.default_options(chunk_size=chunk)
-    oo = ol.default_options(chunk_size=chunk)
+    go = vsg.default_options(chunk_size=chunk, **options)
+    oo = ol.default_options(chunk_size=chunk, **options)
     gs = vsg.DenseSegmentation(W, H, go, has_flow=flow)
     os_ = ol.OracleStream(W, H, oo, has_flow=flow)
     fl = synth.const_flow(W, H) if flow else None
@@ -249,6 +249,20 @@ def run_streams(vsg, W, H, N, kind, flow, chunk, seed=5, frames=None):
 ])
 def test_stream_byte_identical(vsg, W, H, N, kind, flow, chunk):
     run_streams(vsg, W, H, N, kind, flow, chunk)
+
+
+@pytest.mark.parametrize("W,H,N,kind,chunk", [
+    (64, 48, 12, "bench", 8),     # the golden case that caught an unsafe pass in round 3
+    (96, 64, 30, "bench", 10),
+    (80, 56, 27, "smooth", 8),
+    (128, 96, 45, "bench", 20),
+])
+def test_unfiltered_features_kept_edges(vsg, W, H, N, kind, chunk):
+    """presmoothing = NONE: noisy features, many failed tests -> finalized regions and *kept* edges
+    everywhere.  The wave worker commits kept edges ahead of earlier kept edges (merge_wave.hip,
+    res2 / res3): only past those that are committed in the same round -- a kept edge that waits
+    can turn into a merge once its other region has changed."""
+    run_streams(vsg, W, H, N, kind, True, chunk, presmoothing=0)
 
 
 def test_stream_320x240_probe(vsg):

@@ -52,8 +52,16 @@ def one_case(rng, idx):
     kind = str(rng.choice(["noise", "smooth", "blocks", "twotone", "bench"]))
     flow_kind = str(rng.choice(["none", "const", "random"]))
     has_flow = flow_kind != "none"
-    go = vsg.default_options(chunk_size=chunk)
-    oo = ol.default_options(chunk_size=chunk)
+    # (drawn last so that the cases of earlier rounds keep their inputs)
+    extra = {}
+    if os.environ.get("STRESS_OPTIONS", "1") != "0":
+        orng = np.random.default_rng([int(rng.integers(0, 1 << 30)), 7])
+        if orng.random() < 0.35:
+            extra["presmoothing"] = 0          # unfiltered features: many failed tests, finalized regions
+        if orng.random() < 0.25:
+            extra["color_distance"] = 0        # L1
+    go = vsg.default_options(chunk_size=chunk, **extra)
+    oo = ol.default_options(chunk_size=chunk, **extra)
     gs = vsg.DenseSegmentation(W, H, go, has_flow=has_flow)
     os_ = ol.OracleStream(W, H, oo, has_flow=has_flow)
     total = 0
@@ -79,7 +87,7 @@ def one_case(rng, idx):
     assert total == N
     gs.close()
     os_.close()
-    return W, H, N, chunk, kind, flow_kind
+    return W, H, N, chunk, kind, flow_kind, extra
 
 
 def main():

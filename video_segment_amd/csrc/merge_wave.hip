@@ -35,8 +35,8 @@ struct WaveTable {
   int32_t key[kTabSize];     // region id, -1: empty
   int32_t link[kTabSize];    // in-batch union-find over slots
   uint32_t res[kTabSize];    // reservation: (0xfffff - round) << 6 | lane, smaller wins
-  uint32_t res2[kTabSize];   // the same among the lanes that do not touch the hot region (only
-                             // filled in the rounds that need it)
+  uint32_t res2[kTabSize];   // earliest lane a kept lane must not pass (ReplayRounds; only filled
+  uint32_t res3[kTabSize];   // in the rounds that have a kept lane)
   float4 ds[kTabSize];
   int32_t cons[kTabSize];
   int32_t flags[kTabSize];   // region flags | kTabDirty
@@ -185,34 +185,74 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
     }
     // An edge that is certainly *kept without changing anything* (NoopPair: different constraints,
     // or one region finalized and both large) does not have to wait for earlier edges of the same
-    // kind, only for earlier edges that may change one of its regions.  So beside the reservation
-    // among all pending lanes (res) there is a second one among the lanes that are not of this
-    // kind (res2, only in the rounds that have such a lane): a kept lane is free on region x when
-    // res2[x] holds no earlier lane.  (A giant region that keeps all its neighbours meets each of
-    // them several times within a batch, next to the edges between the neighbours themselves:
-    // with one reservation that was 1.4 edges per round on components of half a million.)
+    // kind *that are committed in the same round*, only for earlier edges whose outcome is open.
+    // (A giant region that keeps all its neighbours meets each of them several times within a
+    // batch, next to the edges between the neighbours themselves: with one reservation that was
+    // 1.4 edges per round on components of half a million.)  Two more reservation words per region,
+    // filled only in the rounds that have such a lane:
+    //   res3[x]: earliest *blocker* on x -- a lane that may change a state, or a kept lane away from
+    //            the hot region that does not commit in this round (found by iteration: a kept lane
+    //            behind a blocker becomes a blocker itself; a kept lane that waits may well change
+    //            something once its other region has changed);
+    //   res2[x]: the same plus the kept lanes on the hot region (they commit with the chain or
+    //            not at all, which is not known yet: lanes away from the hot region do not pass
+    //            them).
+    // A kept lane away from the hot region commits when res2 holds no earlier lane on either
+    // end; a kept lane on the hot region may join the chain when res3 holds no earlier lane on its
+    // partner (what it passes are committed kept lanes and earlier chain lanes on the same partner).
     // Most rounds of the force-merge buckets have no finalized region and no pair of constraints
     // in the wavefront at all: they skip all of it (any_kept_kind).
     const bool any_kept_kind =
         __ballot(pending && (((A.flags | B.flags) & kFlagFinalized) ||
                              (A.cons >= 0 && B.cons >= 0 && A.cons != B.cons))) != 0 &&
         !(kDbg && (dbg_flags & 512));
-    bool noop_l = false;
-    bool free_a = false, free_b = false;   // (kept lanes) no earlier lane may change region x
+    bool noop_l = false;      // this lane is kept and changes nothing (as the states are now)
+    bool kept_now = false;    // ... is away from the hot region and commits in this round
+    bool free_p = false;      // ... is on the hot region and nothing open precedes it on its partner
     if (any_kept_kind) {
+      const bool lit = a_hot || b_hot;
       RState Hs0 = {};
-      if (__ballot(pending && (a_hot || b_hot))) Hs0 = TabLoad(tab, hot);   // uniform
+      if (__ballot(pending && lit)) Hs0 = TabLoad(tab, hot);   // uniform
       noop_l = pending && (a_hot ? NoopPair(B, Hs0, T) : (b_hot ? NoopPair(A, Hs0, T) : NoopPair(A, B, T)));
+      if (__ballot(pending && !noop_l) == 0) {
+        // Every pending lane of the batch is of this kind: nothing can change a state any more, so
+        // nothing can change what they are -- all of them are kept, in one round.  (The stages that
+        // consist of kept edges only -- 400 K of them around one giant region in the first chunk of
+        // a low-contrast video -- took 26 rounds per batch.)
+        if (pending) my_kept = true;
+        pending = false;
+        break;
+      }
       if (__ballot(noop_l)) {
         if (pending && !noop_l) {
-          if (!a_hot) atomicMin(&tab.res2[sa], key);
-          if (!b_hot) atomicMin(&tab.res2[sb], key);
+          if (!a_hot) {
+            atomicMin(&tab.res2[sa], key);
+            atomicMin(&tab.res3[sa], key);
+          }
+          if (!b_hot) {
+            atomicMin(&tab.res2[sb], key);
+            atomicMin(&tab.res3[sb], key);
+          }
+        } else if (noop_l && lit) {
+          atomicMin(&tab.res2[a_hot ? sb : sa], key);
         }
         WaveSync();
-        if (noop_l) {
-          free_a = a_hot || tab.res2[sa] > key;
-          free_b = b_hot || tab.res2[sb] > key;
+        bool cand = noop_l && !lit;
+        for (;;) {
+          const bool ok = cand && tab.res2[sa] > key && tab.res2[sb] > key;
+          const bool drop = cand && !ok;
+          cand = ok;
+          if (!__ballot(drop)) break;
+          if (drop) {
+            atomicMin(&tab.res2[sa], key);
+            atomicMin(&tab.res2[sb], key);
+            atomicMin(&tab.res3[sa], key);
+            atomicMin(&tab.res3[sb], key);
+          }
+          WaveSync();
         }
+        kept_now = cand;
+        free_p = noop_l && lit && tab.res3[a_hot ? sb : sa] > key;
       } else {
         noop_l = false;
       }
@@ -236,8 +276,7 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
     // and the classification below is skipped (the other hot edges just wait).
     const unsigned long long lit_mask = __ballot(hot_lane);
     const bool chain_possible =
-        lit_mask != 0 && ((__ballot(hot_lane && (own_a || own_b || (noop_l && free_a && free_b))) >>
-                           __builtin_ctzll(lit_mask)) & 1ull);
+        lit_mask != 0 && ((__ballot(hot_lane && (own_a || own_b || free_p)) >> __builtin_ctzll(lit_mask)) & 1ull);
     if (chain_possible) {
       Hs = TabLoad(tab, hot);   // uniform
       fin = (Hs.flags & kFlagFinalized) != 0;
@@ -274,10 +313,10 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
       const bool plain_b = base && PlainPartner(B.flags) &&
                            (noop_b || ((B.cons < 0 || B.cons == Hs.cons) && B.sz < Hs.sz &&
                                        (!fin_b || B.cons >= 0 || Hs.sz >= T.min_size)));
-      // (a lane that took part in the reservations as a kept lane may only be one: its view of
-      // the pair can be stale -- an end that an earlier chain lane absorbs -- and then it waits)
-      const bool part_a = plain_a && (noop_l ? (noop_a && free_a && !a_hot) : own_a);
-      const bool part_b = plain_b && (noop_l ? (noop_b && free_b && !b_hot) : own_b);
+      // (a lane that took part in the reservations as a kept lane may only be one: on the hot
+      // region as a chain lane, away from it through the generic code below -- or it waits)
+      const bool part_a = plain_a && (noop_l ? (noop_a && free_p && b_hot) : own_a);
+      const bool part_b = plain_b && (noop_l ? (noop_b && free_p && a_hot) : own_b);
       const bool merge_a = part_a && !noop_a && (A.cons >= 0 || !fin_a || A.sz < T.min_size);
       const bool merge_b = part_b && !noop_b && (B.cons >= 0 || !fin_b || B.sz < T.min_size);
       const bool abs_a = pending && !own_a, abs_b = pending && !own_b;   // may be absorbed
@@ -338,7 +377,7 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
     const bool own = pending && (a_hot || own_a) && (b_hot || own_b);
     const bool solo = hot_lane && own && !elig && !both &&
                       lane == (int)__builtin_ctzll(hot_mask | (1ull << 63));
-    bool n_win = pending && ((own && (!hot_lane || solo)) || (noop_l && !hot_lane && free_a && free_b));
+    bool n_win = pending && ((own && (!hot_lane || solo)) || kept_now);
     if (kDbg && (dbg_flags & 8)) n_win = n_win && lane == (int)__builtin_ctzll(__ballot(pending));
     if constexpr (kDbg) {
       const unsigned long long nwin_mask = __ballot(n_win), solo_mask = __ballot(solo);
@@ -612,6 +651,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
     tab.key[s] = -1;
     tab.res[s] = 0xffffffffu;
     tab.res2[s] = 0xffffffffu;
+    tab.res3[s] = 0xffffffffu;
   }
   __syncthreads();
   const int nseg = *num_segs;
@@ -881,6 +921,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           tab.key[s] = -1;
           tab.res[s] = 0xffffffffu;
           tab.res2[s] = 0xffffffffu;
+          tab.res3[s] = 0xffffffffu;
         }
       }
       // Make this batch's stores visible to the next batch's loads (same CU: L1 is shared).

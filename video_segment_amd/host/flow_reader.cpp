@@ -1,34 +1,45 @@
-// flow_reader.cpp -- see flow_reader.h.  Follows video_framework/flow_reader.cpp:63-170.
+// flow_reader.cpp -- see flow_reader.h.  Same file format and unit behaviour as
+// video_framework/flow_reader.cpp:63-170.
 #include "flow_reader.h"
 
 #include <cstdio>
+#include <memory>
 
 namespace video_framework {
 
+// The 12-byte header in one read; the number of fields the file holds follows from its length, so
+// "is there another frame" is arithmetic instead of a peek at the stream.
 bool DenseFlowReader::OpenAndReadHeader() {
-  ifs_.open(filename_.c_str(), std::ios_base::in | std::ios_base::binary);
-  if (!ifs_) {
-    std::fprintf(stderr, "ERROR: DenseFlowReader: can not open binary flow file %s\n",
-                 filename_.c_str());
+  ifs_.open(filename_.c_str(), std::ios_base::in | std::ios_base::binary | std::ios_base::ate);
+  const std::streamoff file_bytes = ifs_ ? (std::streamoff)ifs_.tellg() : -1;
+  int32_t header[3] = {0, 0, -1};
+  if (file_bytes >= (std::streamoff)sizeof(header)) {
+    ifs_.seekg(0);
+    ifs_.read(reinterpret_cast<char*>(header), sizeof(header));
+  }
+  if (file_bytes < 0) {
+    std::fprintf(stderr, "ERROR: DenseFlowReader: can not open binary flow file %s\n", filename_.c_str());
     return false;
   }
-  ifs_.read(reinterpret_cast<char*>(&width_), sizeof(width_));
-  ifs_.read(reinterpret_cast<char*>(&height_), sizeof(height_));
-  ifs_.read(reinterpret_cast<char*>(&flow_type_), sizeof(flow_type_));
-  if (!ifs_ || width_ <= 0 || height_ <= 0 || flow_type_ < FLOW_FORWARD || flow_type_ > FLOW_BOTH) {
+  width_ = header[0];
+  height_ = header[1];
+  flow_type_ = header[2];
+  const bool type_ok = flow_type_ == FLOW_FORWARD || flow_type_ == FLOW_BACKWARD || flow_type_ == FLOW_BOTH;
+  if (!ifs_ || width_ <= 0 || height_ <= 0 || !type_ok) {
     std::fprintf(stderr, "ERROR: DenseFlowReader: malformed header in %s\n", filename_.c_str());
     return false;
   }
+  payload_left_ = file_bytes - (std::streamoff)sizeof(header);
   return true;
 }
 
-bool DenseFlowReader::MoreFramesAvailable() {
-  return ifs_.peek() != std::char_traits<char>::eof();
-}
+bool DenseFlowReader::MoreFramesAvailable() { return payload_left_ > 0; }
 
 bool DenseFlowReader::GetNextFlowFrame(uint8_t* buffer) {
-  ifs_.read(reinterpret_cast<char*>(buffer), RequiredBufferSize());
-  return ifs_.gcount() == RequiredBufferSize();
+  const std::streamsize want = RequiredBufferSize();
+  ifs_.read(reinterpret_cast<char*>(buffer), want);
+  payload_left_ -= ifs_.gcount();
+  return ifs_.gcount() == want;
 }
 
 bool DenseFlowWriter::OpenAndWriteHeader(int width, int height, int flow_type) {
@@ -47,25 +58,26 @@ void DenseFlowWriter::AddFlowFrame(const float* interleaved_xy) {
 }
 
 bool DenseFlowReaderUnit::OpenStreams(StreamSet* set) {
+  auto fail = [](const char* what) {
+    std::fprintf(stderr, "ERROR: DenseFlowReaderUnit: %s\n", what);
+    return false;
+  };
   vid_stream_idx_ = FindStreamIdx(options_.video_stream_name, set);
-  if (vid_stream_idx_ < 0) {
-    std::fprintf(stderr, "ERROR: DenseFlowReaderUnit: can not find video stream\n");
-    return false;
-  }
-  const VideoStream& vid_stream = set->at(vid_stream_idx_)->As<VideoStream>();
-  frame_width_ = vid_stream.frame_width();
-  frame_height_ = vid_stream.frame_height();
+  if (vid_stream_idx_ < 0) return fail("can not find video stream");
   if (!reader_.OpenAndReadHeader()) return false;
+  const VideoStream& video = set->at(vid_stream_idx_)->As<VideoStream>();
+  frame_width_ = video.frame_width();
+  frame_height_ = video.frame_height();
   if (reader_.width() != frame_width_ || reader_.height() != frame_height_) {
-    std::fprintf(stderr, "ERROR: flow file has different dimension than input video\n");
-    return false;
+    return fail("flow file has different dimension than input video");
   }
-  // Forward stream first, then backward (flow_reader.cpp:107-119); plain DataStreams.
-  if (reader_.FlowType() == FLOW_FORWARD || reader_.FlowType() == FLOW_BOTH) {
-    set->push_back(std::shared_ptr<DataStream>(new DataStream(options_.forward_flow_stream_name)));
-  }
-  if (reader_.FlowType() == FLOW_BACKWARD || reader_.FlowType() == FLOW_BOTH) {
-    set->push_back(std::shared_ptr<DataStream>(new DataStream(options_.backward_flow_stream_name)));
+  // One plain DataStream per direction the file holds, forward before backward
+  // (flow_reader.cpp:107-119).
+  const int type = reader_.FlowType();
+  const std::string* names[2] = {&options_.forward_flow_stream_name, &options_.backward_flow_stream_name};
+  const bool present[2] = {type != FLOW_BACKWARD, type != FLOW_FORWARD};
+  for (int d = 0; d < 2; ++d) {
+    if (present[d]) set->push_back(std::make_shared<DataStream>(*names[d]));
   }
   frame_number_ = 0;
   return true;

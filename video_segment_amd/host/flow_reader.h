@@ -37,6 +37,7 @@ class DenseFlowReader {
   std::string filename_;
   int32_t width_ = 0, height_ = 0, flow_type_ = FLOW_FORWARD;
   std::ifstream ifs_;
+  std::streamoff payload_left_ = 0;   // bytes of flow fields not read yet
 };
 
 // Writer side of the same format (what DenseFlowUnit does when flow_output_file is set).
