@@ -18,8 +18,6 @@ import queue
 import threading
 import time
 
-import numpy as np
-
 from .dense_segmentation import DenseSegmentation
 from .multi_gpu import product_halo
 
