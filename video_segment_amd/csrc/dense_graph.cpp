@@ -544,6 +544,9 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     for (auto& t : window_target_) {
       if (t != 0 && t != kNoWindowTarget) t = t * 2 > (1ll << 28) ? 0 : t * 2;
     }
+    std::fill(window_last_seg_.begin(), window_last_seg_.end(), 0);
+    std::fill(window_frozen_.begin(), window_frozen_.end(), 0);
+    std::fill(window_unpaid_.begin(), window_unpaid_.end(), 0);
   }
   int group_width = 1;
   for (int b = 0, hi = 0; b < kNumBuckets; b = hi) {
@@ -562,7 +565,12 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     // the window target of this bucket: what the last chunk learned for it, else what the
     // bucket before it ended with (the force-merge buckets, where the tree replay takes the large
     // components, hand nothing on)
-    if (window_target_.empty()) window_target_.assign(kNumBuckets + 1, 0);
+    if (window_target_.empty()) {
+      window_target_.assign(kNumBuckets + 1, 0);
+      window_last_seg_.assign(kNumBuckets + 1, 0);
+      window_frozen_.assign(kNumBuckets + 1, 0);
+      window_unpaid_.assign(kNumBuckets + 1, 0);
+    }
     if (window_target_[b] != 0) {
       wave_target_active_ = window_target_[b];
     } else if (b <= first_plain) {
@@ -588,8 +596,22 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
       }
       if (measure && adapt_windows && (measure > 1 || info.replayed > 16384)) {
         last_density_ = std::max((double)info.replayed / (double)std::max(n, 1), 1e-6);
-        if (info.max_wave_segment > 16384) {
-          wave_target_active_ = std::max<int64_t>(std::min<int64_t>(wave_target_active_, info.replayed) / 2, 8192);
+        if (info.max_wave_segment > 16384 && !window_frozen_[b]) {
+          // Halving has to pay: below the percolation threshold the largest component collapses
+          // (184 K -> 57 K -> 10 K edges); the edges of ONE region against its neighbours just
+          // split in two with the window, the same serial work in twice the stages -- then the
+          // last step is undone and the bucket keeps its target.
+          // (two halvings in a row that did not pay: the windows differ, one is not evidence)
+          const bool paid = window_last_seg_[b] == 0 || info.max_wave_segment <= 0.4 * window_last_seg_[b];
+          if (!paid && window_frozen_[b] == 0 && ++window_unpaid_[b] >= 2) {
+            if (wave_target_active_ != kNoWindowTarget) wave_target_active_ *= 4;
+            window_frozen_[b] = 1;
+          } else {
+            if (paid) window_unpaid_[b] = 0;
+            window_last_seg_[b] = info.max_wave_segment;
+            wave_target_active_ =
+                std::max<int64_t>(std::min<int64_t>(wave_target_active_, info.replayed) / 2, 8192);
+          }
         }
         (void)limited;
       }
@@ -599,7 +621,9 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     auto limit = [&](int64_t want, bool* limited) {
       *limited = false;
       if (wave_target_active_ == kNoWindowTarget) return want;
-      const int64_t by_target = std::max<int64_t>((int64_t)((double)wave_target_active_ / last_density_), 16384);
+      // (at most 64 stages per bucket, whatever the target)
+      const int64_t by_target = std::max<int64_t>(
+          std::max<int64_t>((int64_t)((double)wave_target_active_ / last_density_), 16384), ((int64_t)n_b + 63) / 64);
       if (by_target < want) {
         *limited = true;
         return by_target;

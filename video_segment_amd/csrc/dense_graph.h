@@ -164,6 +164,9 @@ class DenseGraphHip {
   int64_t wave_target_active_ = kNoWindowTarget;   // active edges per stage (SegmentLists), learned
   std::vector<int64_t> window_target_;             // ... per bucket, from the last chunk (0: none yet)
   int window_target_age_ = 0;
+  std::vector<int> window_last_seg_;      // per bucket: largest wave segment when the target was last halved
+  std::vector<uint8_t> window_frozen_;    // per bucket: halving stopped paying
+  std::vector<uint8_t> window_unpaid_;    // per bucket: halvings in a row that did not pay
   double last_density_ = 1.0;                      // active / all edges of the last measured stage
   int spine_max_edges_grown_ = 0;   // what the pool was enlarged to for this video's largest stage
   DevBuf<unsigned long long> stats_;
