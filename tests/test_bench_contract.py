@@ -60,3 +60,24 @@ def test_two_ranks_control_flow(mode, port):
     # two ranks x two timed steps x 19 frames (streams) or one 4-chunk video (chain: 20 + 3 x 19)
     frames = out["value"] * out["ms_per_step"] * out["steps"] / 1e3
     assert abs(frames - (76 if mode == "streams" else 77)) < 1e-6
+
+
+def test_committed_round_line_carries_every_key():
+    """The default `python bench.py` line of the round (profiles/, produced on an MI355X by
+    tools/measure_round.sh): the contract keys plus what the headline depends on -- the other
+    single-GPU configs, the other inputs, the streams sweep."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r3_*_bench_1080p.json")))
+    assert paths, "no round-3 bench line under profiles/"
+    out = last_json_line(open(paths[-1]).read())
+    check(out, 1, out["steps"], out["warmup"])
+    assert out["vs_baseline"] is None and out["parity_checked"] is True
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["peak"] == 8000.0
+    cfg = out["configs"]
+    assert cfg["configs[1]"]["cpu_baseline"]["value"] > 0 and cfg["configs[1]"]["parity_checked"] is True
+    assert cfg["3840x2160"]["value"] > 0 and cfg["configs[4]"]["value"] > 0
+    assert set(out["workloads"]) >= {"checker (headline input)", "blobs", "noise"}
+    assert [s["streams"] for s in out["streams_sweep"]] == [1, 2, 4, 8]
+    assert out["pipelined"]["value"] > 0
