@@ -234,15 +234,16 @@ def stage_ms(acc, steps):
             "readout": acc["readout_ms"] / steps, "host_post": acc["host_ms"] / steps}
 
 
-def extra_measurements(vsg, args, dev, device_index, headline_fps):
+def extra_measurements(vsg, args, dev, device_index, headline_fps, out):
     """What the headline number depends on (rank 0, N = 1, after the timed region; information
     only): the other single-GPU configs of BASELINE.json, the same 1080p shape on inputs with many
-    small regions, and S concurrent streams on the one GPU."""
+    small regions, and S concurrent streams on the one GPU.  Fills `out` leg by leg (a leg that
+    fails must not cost the headline line: the caller records the error)."""
     import oracle_lib as ol
     import synth
     W, H, chunk = args.width, args.height, args.chunk
     px_bytes = BYTES_PER_PX_FRAME
-    out = {}
+    out["configs"] = {}
 
     # ---- BASELINE configs[1]: 640x480, 32-slice window, spatial-only graph through seam 3 ----
     cw, chh, cf = 640, 480, 32
@@ -287,7 +288,7 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps):
                               "sample": "the same 32-slice window, oracle/libvs_oracle.so, %.1f s" % dt_o}
         c1["parity_checked"] = bool(og.num_regions() == nreg)
         og.close()
-    out["configs"] = {"configs[1]": c1}
+    out["configs"]["configs[1]"] = c1
 
     # ---- 3840x2160 + flow (the over-segmentation half of configs[4]) --------------------------
     w4, h4 = 3840, 2160
@@ -648,7 +649,12 @@ def main():
         if world == 1 and args.mode == "streams" and not args.no_extras and not args.host_inputs \
                 and args.streams == 1 and (W, H) == (1920, 1080):
             torch.cuda.empty_cache()
-            out.update(extra_measurements(vsg, args, dev, local_rank, fps))
+            extras = {}
+            try:
+                extra_measurements(vsg, args, dev, local_rank, fps, extras)
+            except Exception as e:   # noqa: BLE001 -- information only: the headline line still goes out
+                extras["extras_error"] = "%s: %s" % (type(e).__name__, e)
+            out.update(extras)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
