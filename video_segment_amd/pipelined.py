@@ -23,15 +23,25 @@ from .multi_gpu import product_halo
 
 
 class PipelinedDenseSegmentation:
-    def __init__(self, W, H, options, has_flow=True, device=None):
-        import torch
+    """engine_factory / halo_of: any two engines with the stream interface (process_frame,
+    result_bytes, restart, expect_halo, import_halo, close) and a function that returns what an
+    engine hands over after a chunk, (labels_virtual, labels_constrained, scalars[4]) -- the CPU
+    tests run the routing and the hand-off with two oracle streams.  Default: two product engines
+    on `device`, label planes copied on the device (product_halo)."""
+
+    def __init__(self, W, H, options, has_flow=True, device=None, engine_factory=None, halo_of=None):
         self.W, self.H = W, H
         self.chunk = int(options.chunk_size)
         if self.chunk < 3:
             raise ValueError("chunk_size >= 3")
         self.stride = self.chunk - 1
-        self.device = device if device is not None else torch.device("cuda", max(int(options.device), 0))
-        self.engines = [DenseSegmentation(W, H, options, has_flow=has_flow) for _ in range(2)]
+        self.device = None
+        if engine_factory is None:
+            import torch
+            self.device = device if device is not None else torch.device("cuda", max(int(options.device), 0))
+            engine_factory = lambda: DenseSegmentation(W, H, options, has_flow=has_flow)   # noqa: E731
+        self._halo_of = halo_of
+        self.engines = [engine_factory() for _ in range(2)]
         self._in = [queue.Queue(maxsize=2 * self.chunk) for _ in range(2)]
         self._halo = [queue.Queue() for _ in range(2)]
         self._cond = threading.Condition()
@@ -48,12 +58,22 @@ class PipelinedDenseSegmentation:
             t.start()
 
     # ---- engine threads -------------------------------------------------------------------------
-    def _engine_loop(self, p):
+    def _hand_over(self, eng):
+        """What the engine passes on after a chunk: (labels_virtual, labels_constrained, scalars)."""
+        if self._halo_of is not None:
+            return self._halo_of(eng)
         import torch
+        virt, cons, scal = product_halo(eng, self.W, self.H, self.device)
+        torch.cuda.current_stream().synchronize()   # the copies, before the other thread reads them
+        return virt, cons, scal.numpy()
+
+    def _engine_loop(self, p):
         eng = self.engines[p]
         used = False
         try:
-            torch.cuda.set_device(self.device)
+            if self.device is not None:
+                import torch
+                torch.cuda.set_device(self.device)
             while True:
                 msg = self._in[p].get()
                 if msg is None:
@@ -74,11 +94,9 @@ class PipelinedDenseSegmentation:
                 n = eng.process_frame(frame, flow, flush=flush)
                 if last:
                     res = [eng.result_bytes(i) for i in range(n)]
-                    t = eng.last_timings()
+                    t = eng.last_timings() if hasattr(eng, "last_timings") else None
                     if not flush:
-                        virt, cons, scal = product_halo(eng, self.W, self.H, self.device)
-                        torch.cuda.current_stream().synchronize()   # the copies, before the other thread reads them
-                        self._halo[1 - p].put((virt, cons, scal.numpy()))
+                        self._halo[1 - p].put(self._hand_over(eng))
                     with self._cond:
                         self._done[c] = (res, t, time.perf_counter())
                         self._cond.notify_all()
