@@ -958,10 +958,20 @@ class DenseGraph {
     }
     const float merge_thr = 0.05f;   // pixel_distance.h:471
     const float split_thr = 0.15f;   // pixel_distance.h:472
+    // Analysis aid (VSO_DEPTH_STATS=1, stderr): per bucket, the longest chain of edges that have
+    // to be evaluated one after the other -- an edge waits for the last edge that CHANGED one of
+    // its two regions (merge, finalisation, dropped constraint); kept edges change nothing.  That
+    // is the floor of any schedule that keeps the reference's order exactly.
+    const bool depth_stats = getenv("VSO_DEPTH_STATS") != nullptr;
+    std::vector<int> dep;
+    if (depth_stats) dep.assign(regions_.size(), 0);
     for (int bucket_idx = 0; bucket_idx < num_buckets_; ++bucket_idx) {
       const float weight = (float)bucket_idx * inv_scale;
       BucketCensus& cs = census_[bucket_idx];
       cs = BucketCensus();
+      long long d_edges = 0, d_changing = 0;
+      int d_max = 0;
+      if (depth_stats) std::fill(dep.begin(), dep.end(), 0);
       for (int bl : *bucket_list_ids) {
         if (bl >= (int)bucket_lists_.size()) continue;
         EdgeList remaining;
@@ -973,6 +983,31 @@ class DenseGraph {
           if (rep_1 == rep_2) {
             ++cs.internal;
             continue;
+          }
+          int d_id1 = 0, d_id2 = 0, d_here = 0;
+          long long d_before = 0;
+          if (depth_stats) {
+            d_id1 = rep_1->my_id;
+            d_id2 = rep_2->my_id;
+            d_here = 1 + std::max(dep[d_id1], dep[d_id2]);
+            d_before = cs.regular + cs.small + cs.forced + cs.fail;
+            ++d_edges;
+          }
+          struct DepthNote {   // runs when the edge has been decided
+            std::function<void()> f;
+            ~DepthNote() { if (f) f(); }
+          } note;
+          if (depth_stats) {
+            const int c1 = rep_1->constraint_id, c2 = rep_2->constraint_id;
+            note.f = [&, c1, c2]() {
+              const bool changed = (cs.regular + cs.small + cs.forced + cs.fail) != d_before ||
+                                   rep_1->constraint_id != c1 || rep_2->constraint_id != c2;
+              if (!changed) return;
+              ++d_changing;
+              d_max = std::max(d_max, d_here);
+              dep[d_id1] = dep[d_id2] = d_here;
+              dep[GetRegion(d_id1)->my_id] = d_here;   // the survivor of a merge
+            };
           }
           if (rep_1->constraint_id < 0 || rep_2->constraint_id < 0) {
             if (!rep_1->region_finalized && !rep_2->region_finalized) {
@@ -1021,6 +1056,10 @@ class DenseGraph {
           }
         }
         edges.swap(remaining);
+      }
+      if (depth_stats && d_edges >= 10000) {
+        std::fprintf(stderr, "[vso] bucket %d: %lld edges between different regions, %lld change a state, "
+                     "longest chain %d\n", bucket_idx, d_edges, d_changing, d_max);
       }
     }
     if (force_constraints) MergeConstrainedRegions();
