@@ -640,7 +640,7 @@ def main():
             out["pcie_inclusive"] = result["pcie"]
         if result.get("handoff"):
             out["config"]["handoff"] = result["handoff"]
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # (rank 0 at N = 1 only: the other ranks would wait)
             out["cpu_baseline"], threaded, out["parity_checked"] = cpu_baseline(
                 W, H, chunk, args.cpu_frames, local_rank)
             if threaded is not None:
