@@ -2,8 +2,7 @@
 
 The round-based wave worker has debug switches that disable its mechanisms
 one by one (VSG_WAVE_DBG bit mask), a self check that replays every committed chain with the
-generic edge code, and the edge-by-edge worker of round 1a (VSG_WAVE_V1).  Every mode must give the
-oracle's bytes.  Shapes: odd sizes, padded rows, tiny frames, random (out of range) flow."""
+generic edge code.  Every mode must give the oracle's bytes.  Shapes: odd sizes, padded rows, tiny frames, random (out of range) flow."""
 import os
 
 import numpy as np
@@ -64,8 +63,12 @@ def test_stage_decomposition_variants(vsg, monkeypatch, env):
         sp.one_case(np.random.default_rng([77, idx]), idx)
 
 
-def test_edge_by_edge_worker(vsg, monkeypatch):
-    monkeypatch.setenv("VSG_WAVE_V1", "1")
+@pytest.mark.parametrize("small", ["1", "128", "100000"])
+def test_lane_worker_threshold(vsg, monkeypatch, small):
+    """The size up to which a component is replayed by a single lane (k_merge_small) instead of a
+    wavefront is a tuning knob: every value gives the same bytes (1: nearly everything on the wave
+    worker, 100000: everything on single lanes)."""
+    monkeypatch.setenv("VSG_SMALL_SEG", small)
     for (W, H, N, kind, chunk) in CASES:
         run_streams(vsg, W, H, N, kind, True, chunk)
 

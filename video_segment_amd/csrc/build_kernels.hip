@@ -15,6 +15,8 @@
 //
 // These are HBM-bound stencil / integer kernels: coalesced plane loads, LDS tile for the
 // bilateral window, no MFMA.
+#include <atomic>
+
 #include "device_graph.h"
 
 namespace vsg {
@@ -184,16 +186,21 @@ __global__ __launch_bounds__(256) void k_bilateral(const uint8_t* __restrict__ b
   }
 }
 
+constexpr int kMaxAttrDevices = 64;
 size_t BilateralSmemBytes() { return (size_t)(kLutBins + 3 * kHaloH * kHaloW) * sizeof(float); }
 
 void LaunchBilateral(const uint8_t* bgr, size_t stride, int W, int H, const float* lut,
                      float scale, float* planes /* 3*W*H */, hipStream_t s) {
-  static bool attr_set = false;
+  // The attribute belongs to the (function, device) pair: a process may hold handles on several
+  // devices, and stream threads call this concurrently.
+  static std::atomic<bool> attr_set[kMaxAttrDevices];
   const size_t smem = BilateralSmemBytes();
-  if (!attr_set) {
+  int dev = 0;
+  VSG_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxAttrDevices || !attr_set[dev].load(std::memory_order_acquire)) {
     VSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bilateral),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
+    if (dev >= 0 && dev < kMaxAttrDevices) attr_set[dev].store(true, std::memory_order_release);
   }
   const int tiles_x = (W + kTileW - 1) / kTileW;
   const int tiles_y = (H + kTileH - 1) / kTileH;

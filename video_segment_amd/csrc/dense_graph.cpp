@@ -395,7 +395,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.bk_cons = bk_cons_.get();
   S.bk_flags = bk_flags_.get();
   S.force_rollback = getenv("VSG_FORCE_ROLLBACK") ? 1 : 0;
-  S.wave_v1 = getenv("VSG_WAVE_V1") ? 1 : 0;
+  S.small_seg = getenv("VSG_SMALL_SEG") ? std::max(1, atoi(getenv("VSG_SMALL_SEG"))) : 24;
   // Sizes that follow the graph rather than the 1080p bench: the tree replay's scratch pool holds
   // the large components of one stage, which together are at most about one bucket of the chunk
   // graph (1.15 N edges: 48 M at 1080p x 21 slices; the stamped ranks of the spanning forest allow
@@ -429,6 +429,8 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.spine_nested_factor = getenv("VSG_SPINE_NESTED") ? std::max(1, atoi(getenv("VSG_SPINE_NESTED"))) : 2;
   S.spine_debug = getenv("VSG_SPINE_DEBUG") ? 1 : 0;
   S.spine_check = getenv("VSG_SPINE_CHECK") ? 1 : 0;
+  S.spine_fast = getenv("VSG_SPINE_FAST") ? atoi(getenv("VSG_SPINE_FAST")) : 2;   // streamed passes
+  S.spine_fast_min = getenv("VSG_SPINE_FAST_MIN") ? atoi(getenv("VSG_SPINE_FAST_MIN")) : 32768;
   if (S.spine_min > 0) {
     const size_t ints = SpinePoolInts((size_t)S.spine_max_edges);
     if (spine_pool_.size() < ints) spine_pool_.alloc(ints);

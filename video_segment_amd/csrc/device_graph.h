@@ -107,7 +107,7 @@ void UniqueU64(void* temp, size_t temp_bytes, const unsigned long long* in,
                unsigned long long* out,
                int32_t* num_out, int n, hipStream_t s);
 
-// ---- merge_stage.hip (workers: merge_wave.hip, merge_wave_v1.hip) ----------------------------------------------------------------
+// ---- merge_stage.hip (worker: merge_wave.hip) ----------------------------------------------------------------
 // What k_filter found, three bits per edge of the stage: one 64-bit word per wavefront (64
 // consecutive edges) and class, and the number of active edges per workgroup of 256 edges.
 struct FilterMasks {
@@ -160,6 +160,8 @@ struct MergeScratch {
   int spine_nested_factor;   // side clusters go one level down from spine_min * this many edges
   int spine_max_edges;   // at most this many edges per stage (scratch pool)
   int spine_debug, spine_check;
+  int spine_fast;        // the plain steps of a spine through the streamed chain (k_spine_chain)
+  int spine_fast_min;    // ... from this many tree edges on (seven more launches)
   int32_t* spine_pool;   // scratch, SpinePoolInts(spine_max_edges) ints
   size_t spine_pool_ints;
   // Enlarges the pool so that it holds `edges` edges (all streams of the graph are idle when it is
@@ -170,7 +172,7 @@ struct MergeScratch {
   hipStream_t aux_stream;   // the ordinary workers run here while the trees are built on the main stream
   hipStream_t aux2_stream;  // the ordinary side clusters of a tree level, beside the level below
   hipEvent_t aux_fork, aux_join;
-  int wave_v1;           // debug hook: use the sequential wave worker (k_merge_wave_v1)
+  int small_seg;         // components of up to this many replayed edges: one lane each (k_merge_small)
   int wave_debug;        // use the instrumented build of the wave worker (counters, self checks)
   int wave_dbg;          // debug hook (bit mask): 1 no chain, 4 no hot region, 8 one generic lane per round,
                          // 16 chain self check, 32 no jumping over pending lanes, 64 one chain lane per round

@@ -1,5 +1,5 @@
-// merge_common.h -- device helpers shared by the merge kernels (merge_stage.hip and the workers
-// merge_wave_v1.hip / merge_wave.hip): union-find, the exact edge semantics on
+// merge_common.h -- device helpers shared by the merge kernels (merge_stage.hip and the worker
+// merge_wave.hip): union-find, the exact edge semantics on
 // plain values, wave-level primitives, and the launchers of the workers.
 #ifndef VSG_MERGE_COMMON_H_
 #define VSG_MERGE_COMMON_H_
@@ -11,7 +11,8 @@
 
 namespace vsg {
 
-constexpr int kSmallSegment = 24;   // components with more active edges go to a wavefront / workgroup
+constexpr int kSmallSegment = 24;   // default of MergeScratch::small_seg: components with more
+                                    // replayed edges go to a wavefront
 constexpr int kTabDirty = 0x100;    // region table entry changed since it was loaded
 
 // ------------------------------------------------------------------------------------------
@@ -330,6 +331,7 @@ struct WorkerArgs {
   int optimistic;
   int32_t* violation;
   unsigned long long* stats;
+  int small_seg;            // components of up to small_seg edges are replayed by one lane (k_merge_small)
   int wave_min;             // the wave worker takes components of more than wave_min and less than
   int wave_max;             // wave_max edges (k_merge_small: up to kSmallSegment, when wave_min is that)
   // Work list of the wave worker (null: every workgroup strides over all segments).  k_merge_small
@@ -343,8 +345,6 @@ struct WorkerArgs {
 constexpr int kWaveClasses = 3;
 constexpr int kWaveClassMin1 = 192;    // class 1: at least this many edges
 constexpr int kWaveClassMin0 = 1536;   // class 0: at least this many edges
-// Edge-by-edge replay by one wavefront (round 1a; debug reference, VSG_WAVE_V1).
-void LaunchMergeWaveV1(int grid, const WorkerArgs& a, hipStream_t s);
 // Round-based replay by one consumer wavefront + one reader wavefront (the default).
 void LaunchMergeWave(int grid, const WorkerArgs& a, bool instrumented, int dbg_flags, hipStream_t s);
 

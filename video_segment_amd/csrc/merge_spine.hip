@@ -457,16 +457,24 @@ __device__ __forceinline__ void WaveSyncS() {
 }
 
 __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const int32_t* __restrict__ comp_spine,
-                                               const int32_t* __restrict__ root_vertex,
+                                               int32_t* __restrict__ root_vertex,
                                                const int32_t* __restrict__ sp_child,
                                                const int32_t* __restrict__ sp_is_a, NodeArrays nodes, StageThr T,
                                                int optimistic, int32_t* __restrict__ violation,
-                                               unsigned long long* __restrict__ stats) {
+                                               unsigned long long* __restrict__ stats,
+                                               int32_t* __restrict__ start_pos, int max_steps) {
   __shared__ SpineRing ring;
   const int k = blockIdx.x;
   if (k >= K) return;
   const int lane = threadIdx.x & 63;
-  const int beg = comp_spine[k], n = comp_spine[k + 1] - beg;
+  // start_pos: what the streamed chain (k_spine_chain and friends, below) has absorbed already;
+  // max_steps: this launch only replays that many steps (one batch past the step that stopped the
+  // streamed chain) and leaves where it got to -- start_pos, the representative -- behind.
+  const int done = start_pos ? start_pos[k] : 0;
+  const int beg = comp_spine[k] + done;
+  int n = comp_spine[k + 1] - beg;
+  if (n <= 0) return;
+  if (n > max_steps) n = max_steps;
   if (threadIdx.x < kSpineFills) ring.ready[threadIdx.x] = 0;
   if (threadIdx.x == 0) {
     ring.consumed = 0;
@@ -696,6 +704,10 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
   if (lane == 0) {
     StoreState(nodes, rep, H);
     atomicAdd(&stats[24], (unsigned long long)n);   // spine edges absorbed
+    if (start_pos) {
+      start_pos[k] = done + n;
+      root_vertex[k] = rep;
+    }
   }
   for (int off = 32; off > 0; off >>= 1) {
     n_forced += __shfl_down(n_forced, off);
@@ -707,6 +719,340 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
     if (n_regular) atomicAdd(&stats[1], (unsigned long long)n_regular);
     if (n_small) atomicAdd(&stats[2], (unsigned long long)n_small);
   }
+}
+
+// ---- the spine, streamed ------------------------------------------------------------------------------------
+// k_spine above spends 24 of its ~30 cycles per side cluster in the recurrence  h <- ca*p + cb*h
+// (three channels x two dependent VALU operations through DPP), because one wavefront does
+// everything.  Nearly every step of a spine is the same plain step, though -- R's cluster absorbs a
+// smaller, unflagged side cluster -- and for a run of such steps everything but the recurrence is
+// data parallel over the WHOLE spine, because the side clusters are final before the spine starts:
+//   k_spine_prep    (all CUs) representative and state of every side cluster; whether the step is
+//                   plain, given R's state at the start (the first step that is not ends the run);
+//   exclusive scan  of the side cluster sizes: the size of R's cluster before every step;
+//   k_spine_chain   one workgroup per component: producer wavefronts turn (state, size prefix)
+//                   into the step's coefficients (u = ca*p per channel, c = cb) in an LDS ring; the
+//                   chain wavefront replays  h = u + c*h  with one lane per channel -- two dependent
+//                   VALU operations per step for all three channels at once (the dependent pair
+//                   alone costs 4.2 ns, tools/micro/dep_chain.hip) --, leaving the mean after every
+//                   16th step behind;
+//   k_spine_verify  (all CUs) one lane per block of 16 steps replays the block from the mean before
+//                   it with the same operations and checks every merge test (and that R's cluster is
+//                   the larger one) against the mean before the step; the first failure cuts the run;
+//   k_spine_commit / k_spine_finish: parent links and statistics of the steps before the cut, R's
+//                   state at the cut, and where k_spine has to take over (start_pos).
+// k_spine then replays one batch from the cut (the step that is not plain: a side cluster larger
+// than R's cluster, a flag, a failed test), and the rest of the spine gets a second streamed pass.
+// Same float operations in the same order as MergeStates: the result is bit-identical to k_spine's.
+constexpr int kChRing = 4096;   // ring positions (a multiple of the fill)
+constexpr int kChFill = 256;    // positions per producer fill
+constexpr int kChFills = kChRing / kChFill;
+constexpr int kChProducers = 4;
+constexpr int kChBlock = 16;    // steps per block = lanes of a DPP row
+
+struct SpineFastArrays {
+  int32_t* p;        // [mt] representative of the side cluster
+  float4* ds;        // [mt] its mean and size
+  int32_t* meta;     // [mt] bit 0: constrained step (forced), bit 1: tested, bit 2: finalized pair (small)
+  int32_t* sizes;    // [mt + 1] side cluster sizes (0 outside the run)
+  int32_t* pre;      // [mt + 1] exclusive scan of sizes
+  float* ck;         // [3][ck_stride] mean after every block of 16 steps, per channel
+  int32_t* stop;     // [K] first step of the component that is not plain (its local index; n: none)
+  int32_t* fail;     // [K] first step whose merge test fails
+  int32_t* start_pos;   // [K] steps absorbed so far (by earlier passes and by k_spine)
+  int ck_stride;
+};
+
+// Where component k's block means start in ck.
+__device__ __forceinline__ int SpineCkOfs(const int32_t* __restrict__ comp_spine, int k) {
+  return (comp_spine[k] >> 4) + 2 * k;
+}
+
+__global__ void k_spine_fast_init(int K, const int32_t* __restrict__ comp_spine, SpineFastArrays F, int first) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= K) return;
+  const int n = comp_spine[k + 1] - comp_spine[k];
+  F.stop[k] = n;
+  F.fail[k] = n;
+  if (first) F.start_pos[k] = 0;
+}
+
+// Is the step "R's cluster (state H at the start of the run) absorbs P" a plain chain step?  The
+// conditions of k_spine's chain that do not involve the evolving size of R's cluster, except the
+// minimum-size ones, for which the size at the start of the run is good enough (it only grows).
+__device__ __forceinline__ bool SpinePlainStep(const RState& H, const RState& P, const StageThr& T, int& meta) {
+  const bool fin = (H.flags & kFlagFinalized) != 0;
+  const bool mode_ok = !(H.flags & kFlagNoDesc) && (!fin || H.sz >= T.min_size);
+  const bool fin_l = fin || (P.flags & kFlagFinalized);
+  // (P.sz < size of R's cluster: checked with the exact size before the step, by k_spine_verify)
+  const bool part = mode_ok && PlainPartner(P.flags) && (P.cons < 0 || P.cons == H.cons) &&
+                    (!fin_l || P.cons >= 0 || H.sz >= T.min_size);
+  const bool merging = part && (P.cons >= 0 || !fin_l || P.sz < T.min_size);
+  const bool case_s = P.cons >= 0;
+  meta = (case_s ? 1 : 0) | ((case_s || !fin_l) ? 2 : 0) | (fin_l ? 4 : 0);
+  return merging;
+}
+
+__global__ __launch_bounds__(256) void k_spine_prep(int mt, int K, const int32_t* __restrict__ comp_spine,
+                                                     const int32_t* __restrict__ root_vertex,
+                                                     const int32_t* __restrict__ sp_child, NodeArrays nodes,
+                                                     StageThr T, SpineFastArrays F) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > mt) return;
+  const int mS = comp_spine[K];
+  if (i >= mS) {
+    F.sizes[i] = 0;
+    return;
+  }
+  const int k = CompOf(comp_spine, K, i);
+  const int local = i - comp_spine[k];
+  if (local < F.start_pos[k]) {   // absorbed already
+    F.sizes[i] = 0;
+    return;
+  }
+  int c = sp_child[i];
+  for (int pa = nodes.parent[c]; pa != c; pa = nodes.parent[c]) c = pa;
+  const RState P = LoadState(nodes, c);
+  const RState H = LoadState(nodes, root_vertex[k]);
+  int meta;
+  if (!SpinePlainStep(H, P, T, meta)) atomicMin(&F.stop[k], local);
+  F.p[i] = c;
+  F.ds[i] = make_float4(P.d0, P.d1, P.d2, __int_as_float(P.sz));
+  F.meta[i] = meta;
+  F.sizes[i] = P.sz;
+}
+
+// One step of MergeStates with o = side cluster (mean d, size psz), m = R's cluster (size S before
+// the step): coefficients of  h <- u + c*h.
+__device__ __forceinline__ void SpineCoefficients(const float4& ds, int S, float& u0, float& u1, float& u2,
+                                                  float& c) {
+  const int psz = __float_as_int(ds.w);
+  const float denom = 1.0f / (float)(psz + S);
+  const float ca = (float)psz * denom;
+  c = (float)S * denom;
+  u0 = ca * ds.x;
+  u1 = ca * ds.y;
+  u2 = ca * ds.z;
+}
+
+struct ChainRing {
+  alignas(16) float u[3][kChRing];
+  alignas(16) float c[kChRing];
+  int ready[kChFills];   // fill f is complete when ready[f % kChFills] == f + 1
+  int consumed;          // positions the chain wavefront is done with
+};
+
+__global__ __launch_bounds__(64 * (1 + kChProducers)) void k_spine_chain(int K, const int32_t* __restrict__ comp_spine,
+                                                      const int32_t* __restrict__ root_vertex, NodeArrays nodes,
+                                                      SpineFastArrays F) {
+  __shared__ ChainRing ring;
+  const int k = blockIdx.x;
+  if (k >= K) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int beg = comp_spine[k];
+  const int start = F.start_pos[k], stop = F.stop[k];   // the run: steps [start, stop)
+  if (stop <= start) return;
+  const int f0 = start / kChFill;
+  if (threadIdx.x < kChFills) ring.ready[threadIdx.x] = 0;
+  if (threadIdx.x == 0) ring.consumed = f0 * kChFill;
+  __syncthreads();
+  const RState H = LoadState(nodes, root_vertex[k]);
+  const int nfill = (stop + kChFill - 1) / kChFill;
+  if (wave >= 1) {
+    // ---- producers: coefficients of every step -----------------------------------------------------------
+    const int pre0 = F.pre[beg];
+    for (int f = f0 + wave - 1; f < nfill; f += kChProducers) {
+      const int first = f * kChFill;
+      while (first + kChFill - __hip_atomic_load(&ring.consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >
+             kChRing) {
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int q = 0; q < kChFill / 64; ++q) {
+        const int i = first + q * 64 + lane;
+        float u0 = 0.0f, u1 = 0.0f, u2 = 0.0f, cc = 1.0f;   // outside the run: the mean stays
+        if (i >= start && i < stop) {
+          SpineCoefficients(F.ds[beg + i], H.sz + (F.pre[beg + i] - pre0), u0, u1, u2, cc);
+        }
+        const int slot = i & (kChRing - 1);
+        ring.u[0][slot] = u0;
+        ring.u[1][slot] = u1;
+        ring.u[2][slot] = u2;
+        ring.c[slot] = cc;
+      }
+      WaveSyncS();
+      if (lane == 0) {
+        __hip_atomic_store(&ring.ready[f % kChFills], f + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    return;
+  }
+  // ---- the chain: lane ch replays channel ch (the other lanes repeat channel lane % 3, unused) ---------------
+  // (Coefficients through DPP row shifts -- one lane per row, the 16 steps of a block in the lanes
+  // of the row -- need no LDS reads at all, but a dependent DPP operation has three times the
+  // latency of a plain one: 12 ns per step instead of 5.)
+  const int ch = lane % 3;
+  float h = ch == 0 ? H.d0 : (ch == 1 ? H.d1 : H.d2);
+  float* ckout = F.ck + (size_t)ch * F.ck_stride + SpineCkOfs(comp_spine, k);
+  const float* urow = ring.u[ch];
+  const float* crow = ring.c;
+  for (int f = f0; f < nfill; ++f) {
+    while (__hip_atomic_load(&ring.ready[f % kChFills], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != f + 1) {
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const int first = f * kChFill;
+    const int slot0 = first & (kChRing - 1);   // a fill never wraps
+    // 16 steps per block; the coefficients of the next block are read from LDS while this block's
+    // dependent chain runs (the chain itself is the only thing the wavefront may wait for).
+    float4 un[4], cn[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      un[q] = *reinterpret_cast<const float4*>(urow + slot0 + 4 * q);
+      cn[q] = *reinterpret_cast<const float4*>(crow + slot0 + 4 * q);
+    }
+    for (int b = 0; b < kChFill / kChBlock; ++b) {
+      float4 u[4], c[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u[q] = un[q];
+        c[q] = cn[q];
+      }
+      if (b + 1 < kChFill / kChBlock) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          un[q] = *reinterpret_cast<const float4*>(urow + slot0 + kChBlock * (b + 1) + 4 * q);
+          cn[q] = *reinterpret_cast<const float4*>(crow + slot0 + kChBlock * (b + 1) + 4 * q);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the reads are issued here, not where the scheduler would sink them
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        h = u[q].x + c[q].x * h;
+        h = u[q].y + c[q].y * h;
+        h = u[q].z + c[q].z * h;
+        h = u[q].w + c[q].w * h;
+      }
+      const int at = first + kChBlock * b;
+      if (lane < 3 && at < stop) ckout[at >> 4] = h;
+    }
+    WaveSyncS();   // the fill has been read: its slots may be reused
+    if (lane == 0) {
+      __hip_atomic_store(&ring.consumed, first + kChFill, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+
+// The block of 16 steps that holds step `upto` (or the whole block `b` when upto < 0), replayed from
+// the mean before it; checks every step when `check` is set.  Returns the mean before step `upto`
+// (after the block otherwise) in h; the first step that fails (-1: none) as the result.
+__device__ __forceinline__ int SpineReplayBlock(int k, int b, int upto, bool check,
+                                                const int32_t* __restrict__ comp_spine, const RState& H,
+                                                int start, int stop, const StageThr& T, const SpineFastArrays& F,
+                                                float& h0, float& h1, float& h2) {
+  const int beg = comp_spine[k];
+  const int lo = max(kChBlock * b, start);
+  int hi = min(kChBlock * b + kChBlock, stop);
+  if (upto >= 0) hi = min(hi, upto);
+  if (kChBlock * b <= start) {   // the run starts in this block: R's state
+    h0 = H.d0;
+    h1 = H.d1;
+    h2 = H.d2;
+  } else {
+    const size_t at = (size_t)SpineCkOfs(comp_spine, k) + b - 1;
+    h0 = F.ck[at];
+    h1 = F.ck[(size_t)F.ck_stride + at];
+    h2 = F.ck[2 * (size_t)F.ck_stride + at];
+  }
+  const int pre0 = F.pre[beg];
+  for (int i = lo; i < hi; ++i) {
+    const float4 ds = F.ds[beg + i];
+    const int S = H.sz + (F.pre[beg + i] - pre0);
+    if (check) {
+      // R's cluster has to be the larger one (ties go to the edge's second region: k_spine decides)
+      if (!(__float_as_int(ds.w) < S)) return i;
+      const int meta = F.meta[beg + i];
+      if (meta & 2) {
+        const float x = h0 - ds.x, y = h1 - ds.y, z = h2 - ds.z;
+        const float sd = (x * x + y * y + z * z) * (1.0f / 3.0f);
+        const bool pass = (meta & 1) ? !(sd > T.split_s) : (sd <= T.pass_s);
+        if (!pass) return i;
+      }
+    }
+    float u0, u1, u2, c;
+    SpineCoefficients(ds, S, u0, u1, u2, c);
+    h0 = u0 + c * h0;
+    h1 = u1 + c * h1;
+    h2 = u2 + c * h2;
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(256) void k_spine_verify(int K, const int32_t* __restrict__ comp_spine,
+                                                       const int32_t* __restrict__ root_vertex, NodeArrays nodes,
+                                                       StageThr T, SpineFastArrays F) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= F.ck_stride) return;
+  int lo = 0, hi = K;   // the component whose blocks hold slot t of ck
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (SpineCkOfs(comp_spine, mid) <= t) lo = mid; else hi = mid;
+  }
+  const int k = lo, b = t - SpineCkOfs(comp_spine, k);
+  const int start = F.start_pos[k], stop = F.stop[k];
+  if (b < 0 || kChBlock * b >= stop || kChBlock * b + kChBlock <= start) return;
+  const RState H = LoadState(nodes, root_vertex[k]);
+  float h0, h1, h2;
+  const int bad = SpineReplayBlock(k, b, -1, true, comp_spine, H, start, stop, T, F, h0, h1, h2);
+  if (bad >= 0) atomicMin(&F.fail[k], bad);
+}
+
+__global__ __launch_bounds__(256) void k_spine_commit(int mt, int K, const int32_t* __restrict__ comp_spine,
+                                                       const int32_t* __restrict__ root_vertex, NodeArrays nodes,
+                                                       SpineFastArrays F, unsigned long long* __restrict__ stats) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool forced = false, small = false, regular = false;
+  if (i < mt && i < comp_spine[K]) {
+    const int k = CompOf(comp_spine, K, i);
+    const int local = i - comp_spine[k];
+    if (local >= F.start_pos[k] && local < min(F.stop[k], F.fail[k])) {
+      nodes.parent[F.p[i]] = root_vertex[k];
+      const int meta = F.meta[i];
+      forced = (meta & 1) != 0;
+      small = !forced && (meta & 4);
+      regular = !forced && !small;
+    }
+  }
+  const unsigned long long mf = __ballot(forced), ms = __ballot(small), mr = __ballot(regular);
+  if ((threadIdx.x & 63) == 0) {
+    if (mf) atomicAdd(&stats[0], (unsigned long long)__popcll(mf));
+    if (mr) atomicAdd(&stats[1], (unsigned long long)__popcll(mr));
+    if (ms) atomicAdd(&stats[2], (unsigned long long)__popcll(ms));
+  }
+}
+
+// R's state after the committed steps, and where k_spine goes on.
+__global__ void k_spine_finish(int K, const int32_t* __restrict__ comp_spine,
+                               const int32_t* __restrict__ root_vertex, NodeArrays nodes, StageThr T,
+                               SpineFastArrays F, unsigned long long* __restrict__ stats) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= K) return;
+  const int start = F.start_pos[k], stop = F.stop[k];
+  const int a = min(stop, F.fail[k]);
+  if (a <= start) return;
+  const int rep = root_vertex[k];
+  const int beg = comp_spine[k];
+  RState H = LoadState(nodes, rep);
+  float h0, h1, h2;
+  // the mean before step a: the block that holds step a - 1, up to a
+  SpineReplayBlock(k, (a - 1) >> 4, a, false, comp_spine, H, start, stop, T, F, h0, h1, h2);
+  H.d0 = h0;
+  H.d1 = h1;
+  H.d2 = h2;
+  H.sz += F.pre[beg + a] - F.pre[beg];
+  nodes.desc_sz[rep] = make_float4(H.d0, H.d1, H.d2, __int_as_float(H.sz));
+  F.start_pos[k] = a;
+  atomicAdd(&stats[24], (unsigned long long)(a - start));
 }
 
 // Debug self check (VSG_SPINE_CHECK): the classification against a sequential replay of the
@@ -1105,7 +1451,7 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
     w2.s_rb = o_rb;
     w2.s_gpos = o_gpos;
     w2.T.side = 1;
-    w2.work_cap = n_side / (kSmallSegment + 1) + 1;
+    w2.work_cap = n_side / (w2.small_seg + 1) + 1;
     w2.work_list = (size_t)kWaveClasses * w2.work_cap <= ns ? seg_key : nullptr;
     w2.work_ctl = scalars + 8;
     // A large side cluster is a component like any other: one level down.
@@ -1146,8 +1492,66 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   Mark(5);
   const int es0 = NextEvent(S);
   if (es0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[es0], s));
-  hipLaunchKernelGGL(k_spine, dim3(K), dim3(64 * (1 + kSpineReaders)), 0, s, K, comp_spine, root_vertex, sp_child, sp_is_a, wa.nodes,
-                     wa.T, wa.optimistic, wa.violation, wa.stats);
+  // The streamed chain first (the plain steps up to the first step that is not, or whose test
+  // fails), one batch of k_spine from there, a second streamed pass; k_spine takes the rest.
+  int32_t* start_pos = nullptr;
+  const auto LaunchSpine = [&](int max_steps) {
+    hipLaunchKernelGGL(k_spine, dim3(K), dim3(64 * (1 + kSpineReaders)), 0, s, K, comp_spine, root_vertex, sp_child,
+                       sp_is_a, wa.nodes, wa.T, wa.optimistic, wa.violation, wa.stats, start_pos, max_steps);
+  };
+  if (S.spine_fast > 0 && mt >= S.spine_fast_min) {
+    SpineFastArrays F;
+    F.ck_stride = (mt >> 4) + 2 * K + 4;
+    F.p = pool.take(mt);
+    F.ds = reinterpret_cast<float4*>(pool.take(4 * (size_t)mt));
+    F.meta = pool.take(mt);
+    F.sizes = pool.take((size_t)mt + 1);
+    F.pre = pool.take((size_t)mt + 1);
+    F.ck = reinterpret_cast<float*>(pool.take(3 * (size_t)F.ck_stride));
+    F.stop = pool.take(K);
+    F.fail = pool.take(K);
+    F.start_pos = pool.take(K);
+    if (pool.ok) {
+      start_pos = F.start_pos;
+      for (int pass = 0; pass < S.spine_fast; ++pass) {
+        if (pass > 0) LaunchSpine(64);
+        hipLaunchKernelGGL(k_spine_fast_init, dim3((K + 63) / 64), dim3(64), 0, s, K, comp_spine, F, pass == 0 ? 1 : 0);
+        hipLaunchKernelGGL(k_spine_prep, dim3(Blocks((size_t)mt + 1)), dim3(256), 0, s, mt, K, comp_spine,
+                           root_vertex, sp_child, wa.nodes, wa.T, F);
+        ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, F.sizes, F.pre, mt + 1, s);
+        hipLaunchKernelGGL(k_spine_chain, dim3(K), dim3(64 * (1 + kChProducers)), 0, s, K, comp_spine, root_vertex,
+                           wa.nodes, F);
+        hipLaunchKernelGGL(k_spine_verify, dim3(Blocks((size_t)F.ck_stride)), dim3(256), 0, s, K, comp_spine,
+                           root_vertex, wa.nodes, wa.T, F);
+        hipLaunchKernelGGL(k_spine_commit, dim3(Blocks(mt)), dim3(256), 0, s, mt, K, comp_spine, root_vertex,
+                           wa.nodes, F, wa.stats);
+        hipLaunchKernelGGL(k_spine_finish, dim3((K + 63) / 64), dim3(64), 0, s, K, comp_spine, root_vertex,
+                           wa.nodes, wa.T, F, wa.stats);
+        if (S.spine_debug) {
+          VSG_HIP(hipStreamSynchronize(s));
+          std::vector<int32_t> cs(K + 1), sp(K), st(K), fl(K);
+          VSG_HIP(hipMemcpy(cs.data(), comp_spine, (K + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+          VSG_HIP(hipMemcpy(sp.data(), F.start_pos, K * sizeof(int32_t), hipMemcpyDeviceToHost));
+          VSG_HIP(hipMemcpy(st.data(), F.stop, K * sizeof(int32_t), hipMemcpyDeviceToHost));
+          VSG_HIP(hipMemcpy(fl.data(), F.fail, K * sizeof(int32_t), hipMemcpyDeviceToHost));
+          long long total = 0, fast = 0;
+          int longest = 0, stopped = 0, failed = 0;
+          for (int k = 0; k < K; ++k) {
+            const int n = cs[k + 1] - cs[k];
+            total += n;
+            fast += sp[k];
+            longest = std::max(longest, n);
+            stopped += st[k] < n;
+            failed += fl[k] < n;
+          }
+          std::fprintf(stderr, "[vsg]   streamed chain, pass %d: %lld of %lld spine steps done (longest spine %d; %d of %d "
+                       "components stopped at a step that is not plain, %d at a failed test or a larger side "
+                       "cluster)\n", pass, fast, total, longest, stopped, K, failed);
+        }
+      }
+    }
+  }
+  LaunchSpine(0x7fffffff);
   const int es1 = NextEvent(S);
   if (es1 >= 0) {
     VSG_HIP(hipEventRecord((*S.ev_pool)[es1], s));

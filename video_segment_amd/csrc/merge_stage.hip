@@ -25,7 +25,7 @@
 //
 // This is memory-latency / dependency bound integer + scalar float work: no MFMA, no LDS tiling;
 // what matters is coalesced streaming in the filter and keeping the serial chains in registers.
-// merge_wave_v1.hip is the edge-by-edge debug worker; shared device helpers in merge_common.h.
+// Shared device helpers in merge_common.h.
 #include <algorithm>
 
 #include "merge_common.h"
@@ -343,20 +343,21 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
                                                       StageThr T, int optimistic,
                                                       int32_t* __restrict__ violation,
                                                       unsigned long long* __restrict__ stats,
-                                                      int wave_max, uint32_t* __restrict__ work_list,
+                                                      int small_seg, int wave_max,
+                                                      uint32_t* __restrict__ work_list,
                                                       int work_cap, int32_t* __restrict__ work_ctl) {
   const int seg = blockIdx.x * 256 + threadIdx.x;
   unsigned n_forced = 0, n_regular = 0, n_small = 0;
   if (seg < *num_segs) {
     const int cnt = seg_cnt[seg];
-    if (cnt > kSmallSegment && cnt < wave_max && work_list) {
+    if (cnt > small_seg && cnt < wave_max && work_list) {
       // the wave worker's: filed under its size class (the order inside a class is arbitrary --
       // components are independent)
       const int cls = cnt >= kWaveClassMin0 ? 0 : (cnt >= kWaveClassMin1 ? 1 : 2);
       const int at = atomicAdd(&work_ctl[cls], 1);
       work_list[(size_t)cls * work_cap + at] = (uint32_t)seg;
     }
-    if (cnt <= kSmallSegment) {
+    if (cnt <= small_seg) {
       const int beg = seg_off[seg];
       for (int p = beg; p < beg + cnt; ++p) {
         // An optimistic stage must stay undoable from the backed-up region states alone, so it
@@ -557,7 +558,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   SpineInput spine_in;
   int spine_thr = 0x7fffffff;
   if (S.spine_min > 0 && !S.spine_off && bucket < *S.spine_limit_bucket &&
-      !(bucket < 2 && S.spine_low_skip[bucket]) && inert_mode != 0 && !S.wave_v1 && n_work >= S.spine_min) {
+      !(bucket < 2 && S.spine_low_skip[bucket]) && inert_mode != 0 && n_work >= S.spine_min) {
     long long wanted = 0;
     spine_thr = SelectLargeSegments(n_work, S.num_segs, S.seg_off, S.seg_cnt, S.spine_min,
                                     S.spine_max_edges, S.spine_pool, s, &spine_in, &wanted);
@@ -593,9 +594,12 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   uint32_t* s_gpos = reinterpret_cast<uint32_t*>(S.e_apos);
   hipLaunchKernelGGL(k_gather_sorted, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, S.s_idx, w_ra,
                      w_rb, w_gpos, s_ra, s_rb, s_gpos);
-  const int wave_grid = n_work / (kSmallSegment + 1) < 1 ? 1
-                        : (n_work / (kSmallSegment + 1) > 8192 ? 8192
-                                                               : n_work / (kSmallSegment + 1));
+  const int small_seg = S.small_seg;
+  auto WaveGrid = [small_seg](int n) {
+    const int g = n / (small_seg + 1);
+    return g < 1 ? 1 : (g > 8192 ? 8192 : g);
+  };
+  const int wave_grid = WaveGrid(n_work);
   WorkerArgs wa;
   wa.num_segs = S.num_segs;
   wa.seg_off = S.seg_off;
@@ -609,29 +613,26 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   wa.optimistic = optimistic ? 1 : 0;
   wa.violation = d_violation;
   wa.stats = S.stats;
-  wa.wave_min = kSmallSegment;
+  wa.small_seg = small_seg;
+  wa.wave_min = small_seg;
   wa.wave_max = spine_thr;
   // work list of the wave worker: the RLE keys are not read again, the control words follow the
   // stage's scalars
-  wa.work_cap = n_work / (kSmallSegment + 1) + 1;
-  wa.work_list = (size_t)kWaveClasses * wa.work_cap <= (size_t)n_work && !S.wave_v1 ? S.seg_key : nullptr;
+  wa.work_cap = n_work / (small_seg + 1) + 1;
+  wa.work_list = (size_t)kWaveClasses * wa.work_cap <= (size_t)n_work ? S.seg_key : nullptr;
   wa.work_ctl = S.num_active + 8;
   auto general_workers = [&](const WorkerArgs& w, int small_threads, int grid, hipStream_t s) {
-    if (w.wave_min == kSmallSegment) {
+    if (w.wave_min == w.small_seg) {
       if (w.work_list) VSG_HIP(hipMemsetAsync(w.work_ctl, 0, 2 * kWaveClasses * sizeof(int32_t), s));
       hipLaunchKernelGGL(k_merge_small, dim3(Blocks(small_threads)), dim3(256), 0, s, w.num_segs,
                          w.seg_off, w.seg_cnt, w.s_ra, w.s_rb, w.s_gpos, w.nodes, w.kept_all, w.T,
-                         w.optimistic, w.violation, w.stats, w.wave_max, w.work_list, w.work_cap,
+                         w.optimistic, w.violation, w.stats, w.small_seg, w.wave_max, w.work_list, w.work_cap,
                          w.work_ctl);
     }
     // the wave worker is timed on the stream it runs on
     const int ew0 = NextEvent(S);
     if (ew0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ew0], s));
-    if (S.wave_v1) {
-      LaunchMergeWaveV1(grid, w, s);
-    } else {
-      LaunchMergeWave(grid, w, S.wave_debug != 0, S.wave_dbg, s);
-    }
+    LaunchMergeWave(grid, w, S.wave_debug != 0, S.wave_dbg, s);
     const int ew1 = NextEvent(S);
     if (ew1 >= 0) {
       VSG_HIP(hipEventRecord((*S.ev_pool)[ew1], s));
@@ -648,8 +649,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     general_workers(wa, n_work, wave_grid, S.aux_stream);
     VSG_HIP(hipEventRecord(S.aux_join, S.aux_stream));
     const bool done = RunSpineComponents(spine_in, wa, S, s, [&](const WorkerArgs& w, int n, hipStream_t st) {
-      const int g = n / (kSmallSegment + 1) < 1 ? 1 : (n / (kSmallSegment + 1) > 8192 ? 8192 : n / (kSmallSegment + 1));
-      general_workers(w, n, g, st);
+      general_workers(w, n, WaveGrid(n), st);
     }, kSpineListInts, 0);
     if (!done) {   // no room in the scratch pool: the wave worker replays them
       WorkerArgs w3 = wa;

@@ -8,7 +8,7 @@ namespace vsg {
 // Worker B: one wavefront replays one large component, 64 edges per batch, in *rounds*.
 // ------------------------------------------------------------------------------------------
 // A lone wavefront issues roughly one instruction every 4-8 cycles, so replaying the 64 edges of
-// a batch one after the other (k_merge_wave_v1, ~130 instructions per edge) leaves the stage bound
+// a batch one after the other (the worker of round 1a, ~130 instructions per edge) leaves the stage bound
 // by its largest component.  This worker keeps the regions of the batch in an LDS table and
 // commits as many edges per round as the sequential semantics allow:
 //
