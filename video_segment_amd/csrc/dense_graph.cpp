@@ -67,6 +67,29 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   hist_sums_.alloc(EdgeSortSumInts(wh_) + 1);
   scalars_.alloc(32);
   stats_.alloc(96);
+  {
+    // mailbox: 256 slots of four words + a list of 2 * 4095 ints, mapped and coherent (the device
+    // writes it while kernels run, the host polls it)
+    const int slots = 256;
+    const size_t list_cap = 8192;
+    const size_t bytes = (size_t)slots * kMailValues * sizeof(unsigned long long) + list_cap * sizeof(int32_t);
+    VSG_HIP(hipHostMalloc(&mail_mem_, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(mail_mem_, 0, bytes);
+    void* dev = nullptr;
+    VSG_HIP(hipHostGetDevicePointer(&dev, mail_mem_, 0));
+    mail_.host = static_cast<volatile unsigned long long*>(mail_mem_);
+    mail_.dev = static_cast<unsigned long long*>(dev);
+    mail_.slots = slots;
+    mail_.list_host = reinterpret_cast<volatile int32_t*>(static_cast<char*>(mail_mem_) +
+                                                          (size_t)slots * kMailValues * sizeof(unsigned long long));
+    mail_.list_dev = reinterpret_cast<int32_t*>(static_cast<char*>(dev) +
+                                                (size_t)slots * kMailValues * sizeof(unsigned long long));
+    mail_.list_cap = (int)list_cap;
+    zero_pool_mem_.alloc(1 << 18);
+    zero_pool_.base = zero_pool_mem_.get();
+    zero_pool_.cap = zero_pool_mem_.size();
+    zero_pool_.used = zero_pool_.cap;   // cleared before its first use
+  }
   VSG_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
   VSG_HIP(hipStreamCreateWithFlags(&aux2_stream_, hipStreamNonBlocking));
   VSG_HIP(hipEventCreateWithFlags(&aux_fork_, hipEventDisableTiming));
@@ -83,6 +106,7 @@ DenseGraphHip::~DenseGraphHip() {
   if (aux_join_) (void)hipEventDestroy(aux_join_);
   if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
   if (aux2_stream_) (void)hipStreamDestroy(aux2_stream_);
+  if (mail_mem_) (void)hipHostFree(mail_mem_);
 }
 
 void DenseGraphHip::Reset(int max_frames) {
@@ -329,6 +353,9 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   bucket_base_host_.resize((size_t)(kNumBuckets + 1) * (L + 1));
   D2H(bucket_base_host_.data(), bucket_base_dev_.get(), bucket_base_host_.size(), stream_);
   VSG_HIP(hipMemsetAsync(stats_.get(), 0, 96 * sizeof(unsigned long long), stream_));
+  // (the counters of the last chunk's stages: nothing is in flight on the other streams here)
+  VSG_HIP(hipMemsetAsync(zero_pool_.base, 0, zero_pool_.cap * sizeof(int32_t), stream_));
+  zero_pool_.used = 0;
   LaunchInitIdentity(cc_.get(), N, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
 
@@ -492,6 +519,9 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.ev_filter = &ev_filter_;
   S.ev_spine = &ev_spine_;
   S.ev_used = &ev_used_;
+  S.mail = &mail_;
+  S.zeros = &zero_pool_;
+  S.main_stream = stream_;
 
   MergeParams P;
   P.spatial_survivors = pass == 2 ? kept_spatial_pass_.get() : nullptr;

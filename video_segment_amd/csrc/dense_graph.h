@@ -154,6 +154,10 @@ class DenseGraphHip {
   DevBuf<int32_t> bk_cons_;
   int64_t optimistic_stages_ = 0, rollbacks_ = 0;
   DevBuf<int32_t> scalars_;   // num_active, num_segs, misc
+  Mailbox mail_;              // host-visible scalars (device_graph.h); mapped host memory
+  void* mail_mem_ = nullptr;
+  DevBuf<int32_t> zero_pool_mem_;
+  ZeroPool zero_pool_;
   DevBuf<int32_t> bucket_prefix_dev_;   // edges in the buckets before b
   int spine_limit_bucket_ = 0x7fffffff;   // learned per stream: where the tree replay stops paying
   int spine_limit_age_ = 0;               // chunks since it was learned (forgotten after 8: one atypical

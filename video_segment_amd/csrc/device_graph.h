@@ -107,6 +107,48 @@ void UniqueU64(void* temp, size_t temp_bytes, const unsigned long long* in,
                unsigned long long* out,
                int32_t* num_out, int n, hipStream_t s);
 
+// Scalars the host has to wait for (sizes, flags) reach it through a mailbox in mapped, coherent
+// host memory: the kernel that produces the value stores (sequence number << 32 | value) with system
+// scope and the host spins on the word -- no copy kernel, no stream synchronisation (a read-back
+// through hipMemcpyAsync + hipStreamSynchronize costs 30-40 us of idle GPU, 250 times per chunk).
+// A slot holds up to four values; slots rotate, sequence numbers never repeat.
+constexpr int kMailValues = 4;
+struct MailSlot {
+  unsigned long long* dev;              // device address of the slot's words
+  volatile unsigned long long* host;    // the same words as the host sees them
+  unsigned seq;
+};
+struct Mailbox {
+  unsigned long long* dev = nullptr;
+  volatile unsigned long long* host = nullptr;
+  int slots = 0;
+  int next = 0;
+  unsigned seq = 0;
+  // a small list in mapped memory (the large components of a stage, merge_spine.hip)
+  int32_t* list_dev = nullptr;
+  volatile int32_t* list_host = nullptr;
+  int list_cap = 0;
+};
+inline MailSlot NextMail(Mailbox& m) {
+  MailSlot s{m.dev + (size_t)kMailValues * m.next, m.host + (size_t)kMailValues * m.next, ++m.seq};
+  m.next = (m.next + 1) % m.slots;
+  return s;
+}
+// Waits until the first `count` values of the slot have arrived (spins; looks at the stream for
+// errors now and then) and returns them.
+void MailWait(const MailSlot& slot, int count, int* values, hipStream_t s);
+// Posts up to four device scalars from a one-thread kernel (where no kernel of the algorithm is at
+// hand to do it): values[i] = *ptrs[i].
+void LaunchMailPost(const MailSlot& slot, const int32_t* p0, const int32_t* p1, const int32_t* p2,
+                    const int32_t* p3, hipStream_t s);
+
+// Zeroed device counters, handed out in order and cleared in one go per chunk (a hipMemsetAsync per
+// counter per stage was 450 launches per chunk).
+struct ZeroPool {
+  int32_t* base = nullptr;
+  size_t cap = 0, used = 0;
+};
+
 // ---- merge_stage.hip (worker: merge_wave.hip) ----------------------------------------------------------------
 // What k_filter found, three bits per edge of the stage: one 64-bit word per wavefront (64
 // consecutive edges) and class, and the number of active edges per workgroup of 256 edges.
@@ -189,7 +231,13 @@ struct MergeScratch {
   std::vector<std::pair<int, int>>* ev_filter;
   std::vector<std::pair<int, int>>* ev_spine;    // k_spine launches
   int* ev_used;
+  Mailbox* mail;
+  ZeroPool* zeros;
+  hipStream_t main_stream;
 };
+// n zeroed ints (see ZeroPool); when the pool is used up all three streams are drained and it is
+// cleared again.
+int32_t* TakeZeroed(MergeScratch& S, size_t n);
 
 // bucket_base[b * (L+1) + l] = number of bucket-b edges in lists < l; [.. + L] = total.
 void LaunchBuildBucketTable(const ListDesc* lists, int num_lists, int32_t* bucket_base,

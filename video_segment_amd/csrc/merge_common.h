@@ -75,6 +75,12 @@ __device__ __forceinline__ void CcUnion(int32_t* cc, int a, int b) {
   }
 }
 
+// Value i of a mailbox slot (device_graph.h).
+__device__ __forceinline__ void MailPost(unsigned long long* slot, unsigned seq, int i, int value) {
+  __hip_atomic_store(slot + i, ((unsigned long long)seq << 32) | (unsigned)value, __ATOMIC_RELEASE,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------------------------------------------
 // Edge decoding.
 // ------------------------------------------------------------------------------------------
@@ -370,16 +376,15 @@ struct SpineInput {
 };
 // Launches the ordinary workers (k_merge_small + wave worker) on the given segments.
 using SpineWorkers = std::function<void(const WorkerArgs&, int n_edges, hipStream_t)>;
-// The head of the spine scratch pool holds the list SelectLargeSegments reads back.
+// The list SelectLargeSegments reads (the mailbox's mapped list, device_graph.h).
 constexpr int kSpineListCap = 4095;
-constexpr size_t kSpineListInts = 8192;
 // Chooses the components (segments) of at least min_cnt edges for the Kruskal-tree replay, raising
 // the threshold until all of them fit max_edges; returns the threshold (the ordinary workers leave
-// segments of at least that many edges alone), 0x7fffffff when there is none.  Synchronises.
+// segments of at least that many edges alone), 0x7fffffff when there is none.  Waits for the list.
 // wanted_edges (optional): edges of all components of at least min_cnt edges (what the pool would
 // have to hold for none of them to be left to the wave worker).
 int SelectLargeSegments(int max_segs, const int32_t* num_segs, const int32_t* seg_off, const int32_t* seg_cnt,
-                        int min_cnt, long long max_edges, int32_t* d_list, hipStream_t s, SpineInput* out,
+                        int min_cnt, long long max_edges, MergeScratch& S, hipStream_t s, SpineInput* out,
                         long long* wanted_edges);
 // pool_used: ints of S.spine_pool already taken (by the caller's lists and outer levels).
 bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch& S, hipStream_t s,

@@ -230,8 +230,10 @@ __global__ __launch_bounds__(256) void k_compact_tree(int mE, const int32_t* __r
 }
 
 __global__ void k_scan_total(int n, const int32_t* __restrict__ flag, const int32_t* __restrict__ scan,
-                             int32_t* __restrict__ count) {
-  *count = scan[n - 1] + flag[n - 1];
+                             int32_t* __restrict__ count, unsigned long long* __restrict__ mail, unsigned mail_seq) {
+  const int total = scan[n - 1] + flag[n - 1];
+  *count = total;
+  MailPost(mail, mail_seq, 0, total);
 }
 
 __global__ __launch_bounds__(256) void k_arc_keys(int mt, const int32_t* __restrict__ te_e,
@@ -1129,18 +1131,20 @@ void SpineSelfCheck(const std::vector<int32_t>& base, int mE, const int32_t* d_e
 
 // Components of at least min_cnt replayed edges: (offset, count) pairs.  out[0] = number found
 // (may exceed the capacity).
+// (offset, count) pairs go straight into the mailbox's list in mapped host memory; *found may exceed
+// the capacity.
 __global__ __launch_bounds__(256) void k_list_large_segments(int max_segs, const int32_t* __restrict__ num_segs,
                                                               const int32_t* __restrict__ seg_off,
                                                               const int32_t* __restrict__ seg_cnt, int min_cnt,
-                                                              int32_t* __restrict__ out) {
+                                                              int32_t* __restrict__ found, int32_t* __restrict__ out) {
   const int seg = blockIdx.x * 256 + threadIdx.x;
   if (seg >= max_segs || seg >= *num_segs) return;
   const int cnt = seg_cnt[seg];
   if (cnt < min_cnt) return;
-  const int i = atomicAdd(&out[0], 1);
+  const int i = atomicAdd(found, 1);
   if (i < kSpineListCap) {
-    out[1 + 2 * i] = seg_off[seg];
-    out[2 + 2 * i] = cnt;
+    out[2 * i] = seg_off[seg];
+    out[2 * i + 1] = cnt;
   }
 }
 
@@ -1169,21 +1173,26 @@ struct Pool {   // stack allocator over the spine scratch
 size_t SpinePoolInts(size_t max_edges) { return 16 * max_edges + 64 * 1024; }
 
 int SelectLargeSegments(int max_segs, const int32_t* num_segs, const int32_t* seg_off, const int32_t* seg_cnt,
-                        int min_cnt, long long max_edges, int32_t* d_list, hipStream_t s, SpineInput* out,
+                        int min_cnt, long long max_edges, MergeScratch& S, hipStream_t s, SpineInput* out,
                         long long* wanted_edges) {
   out->segs.clear();
   if (wanted_edges) *wanted_edges = 0;
+  Mailbox& mb = *S.mail;
+  VSG_REQUIRE(mb.list_cap >= 2 * kSpineListCap, -4, "mailbox list too small");
   std::vector<int32_t> large(1 + 2 * kSpineListCap);
   int found = 0;
   for (;; min_cnt *= 4) {   // too many for the list: only the larger ones
-    VSG_HIP(hipMemsetAsync(d_list, 0, sizeof(int32_t), s));
+    int32_t* d_found = TakeZeroed(S, 1);
     hipLaunchKernelGGL(k_list_large_segments, dim3(Blocks(max_segs)), dim3(256), 0, s, max_segs, num_segs, seg_off,
-                       seg_cnt, min_cnt, d_list);
-    VSG_HIP(hipMemcpyAsync(large.data(), d_list, large.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    VSG_HIP(hipStreamSynchronize(s));
-    found = large[0];
+                       seg_cnt, min_cnt, d_found, mb.list_dev);
+    // (the post follows the end of the listing kernel: its stores to the mapped list are complete)
+    const MailSlot m = NextMail(mb);
+    LaunchMailPost(m, d_found, nullptr, nullptr, nullptr, s);
+    MailWait(m, 1, &found, s);
     if (found <= kSpineListCap) break;
   }
+  large[0] = found;
+  for (int i = 0; i < 2 * found; ++i) large[1 + i] = mb.list_host[i];
   if (getenv("VSG_SPINE_DEBUG") && max_segs > 1000000) {
     long long sum = 0;
     int mx = 0;
@@ -1254,7 +1263,7 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   int32_t* d_off = pool.take(K);
   int32_t* root_vertex = pool.take(K);
   int32_t* comp_spine = pool.take(K + 1);
-  unsigned long long* root_key = reinterpret_cast<unsigned long long*>(pool.take(2 * (size_t)K));
+  unsigned long long* root_key = reinterpret_cast<unsigned long long*>(TakeZeroed(S, 2 * (size_t)K));
   int32_t* scalars = pool.take(64);
   int32_t* eu = pool.take(mE);
   int32_t* ev = pool.take(mE);
@@ -1271,7 +1280,6 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
 
   VSG_HIP(hipMemcpyAsync(d_base, base.data(), (K + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
   VSG_HIP(hipMemcpyAsync(d_off, off.data(), K * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  VSG_HIP(hipMemsetAsync(root_key, 0, K * sizeof(unsigned long long), s));
   hipLaunchKernelGGL(k_spine_gather, dim3(Blocks(mE)), dim3(256), 0, s, mE, K, d_base, d_off, wa.s_ra,
                      wa.s_rb, eu, ev, estate, cc, best);
   hipLaunchKernelGGL(k_spine_pick_root, dim3(Blocks((size_t)K + (mE + kRootStride - 1) / kRootStride)), dim3(256), 0,
@@ -1279,7 +1287,6 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   hipLaunchKernelGGL(k_spine_roots, dim3((K + 63) / 64), dim3(64), 0, s, K, root_key, root_vertex, childidx);
 
   // ---- tree edges ----------------------------------------------------------------------------------------
-  int32_t* d_alive = scalars;
   int dbg_rounds = 0;
   auto NowMs = [] {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -1298,15 +1305,16 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
     for (int round = 0;; ++round) {
       dbg_rounds = round;
       VSG_REQUIRE(round < 32, -4, "spine: the spanning forest did not converge");
-      VSG_HIP(hipMemsetAsync(d_alive, 0, sizeof(int32_t), s));
+      int32_t* d_alive = TakeZeroed(S, 1);
       // ecu / ecv (the components of the round) live in the side_key / spine_flag arrays, which are
       // only written once the forest is done
       hipLaunchKernelGGL(k_bor_min, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, round, eu, ev, estate, cc,
                          best, side_key, spine_flag, d_alive);
       const double tr0 = dbg_big ? NowMs() : 0;
       int alive = 0;
-      VSG_HIP(hipMemcpyAsync(&alive, d_alive, sizeof(int), hipMemcpyDeviceToHost, s));
-      VSG_HIP(hipStreamSynchronize(s));
+      const MailSlot m_alive = NextMail(*S.mail);
+      LaunchMailPost(m_alive, d_alive, nullptr, nullptr, nullptr, s);
+      MailWait(m_alive, 1, &alive, s);
       if (dbg_big) std::fprintf(stderr, "[vsg]   forest round %d: %d in list, %d alive, min %.2f ms\n", round, n_list, alive, NowMs() - tr0);
       if (alive == 0) break;
       if (alive < n_list / 2 && n_list > (1 << 16)) {   // drop the settled edges from the rounds to come
@@ -1344,10 +1352,10 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   Mark(1);
   hipLaunchKernelGGL(k_flag_state, dim3(Blocks(mE)), dim3(256), 0, s, mE, estate, 1, flag);
   ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, flag, scan, mE, s);
-  hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, s, mE, flag, scan, scalars + 1);
+  const MailSlot m_mt = NextMail(*S.mail);
+  hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, s, mE, flag, scan, scalars + 1, m_mt.dev, m_mt.seq);
   int mt = 0;
-  VSG_HIP(hipMemcpyAsync(&mt, scalars + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-  VSG_HIP(hipStreamSynchronize(s));
+  MailWait(m_mt, 1, &mt, s);
   VSG_REQUIRE(mt > 0, -4, "spine: a component without tree edges");
   const int na = 2 * mt;
   int32_t* te_e = pool.take(mt);
@@ -1406,10 +1414,10 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   // ---- side clusters: segments for the ordinary workers ------------------------------------------------------
   pool.release(arcs_mark);   // the tour is done with
   ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, flag, scan, mE, s);
-  hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, s, mE, flag, scan, scalars + 2);
+  const MailSlot m_side = NextMail(*S.mail);
+  hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, s, mE, flag, scan, scalars + 2, m_side.dev, m_side.seq);
   int n_side = 0;
-  VSG_HIP(hipMemcpyAsync(&n_side, scalars + 2, sizeof(int), hipMemcpyDeviceToHost, s));
-  VSG_HIP(hipStreamSynchronize(s));
+  MailWait(m_side, 1, &n_side, s);
   const size_t ns = (size_t)(n_side > 0 ? n_side : 1);
   uint32_t* sk_in = reinterpret_cast<uint32_t*>(pool.take(ns));
   uint32_t* si_in = reinterpret_cast<uint32_t*>(pool.take(ns));
@@ -1453,16 +1461,15 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
     w2.T.side = 1;
     w2.work_cap = n_side / (w2.small_seg + 1) + 1;
     w2.work_list = (size_t)kWaveClasses * w2.work_cap <= ns ? seg_key : nullptr;
-    w2.work_ctl = scalars + 8;
+    w2.work_ctl = w2.work_list ? TakeZeroed(S, 2 * kWaveClasses) : nullptr;
     // A large side cluster is a component like any other: one level down.
     SpineInput nested;
-    int32_t* d_list = pool.take(kSpineListInts);
     w2.wave_max = 0x7fffffff;
     if (pool.ok && depth < 8 && n_side >= S.spine_min * S.spine_nested_factor) {
       const long long room = (long long)((S.spine_pool_ints - pool_used - pool.used) / 16);
       // (a level costs about a millisecond of launches: only for what the wave worker needs longer for)
       w2.wave_max = SelectLargeSegments(n_side, d_nseg, seg_off, seg_cnt, S.spine_min * S.spine_nested_factor,
-                                        room < S.spine_max_edges ? room : S.spine_max_edges, d_list, s, &nested,
+                                        room < S.spine_max_edges ? room : S.spine_max_edges, S, s, &nested,
                                         nullptr);
     }
     if (nested.segs.empty()) {

@@ -27,6 +27,8 @@
 // what matters is coalesced streaming in the filter and keeping the serial chains in registers.
 // Shared device helpers in merge_common.h.
 #include <algorithm>
+#include <chrono>
+#include <thread>
 
 #include "merge_common.h"
 
@@ -62,6 +64,71 @@ __global__ __launch_bounds__(256) void k_init_identity(int32_t* a, size_t n) {
 void LaunchInitIdentity(int32_t* a, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_init_identity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n);
   VSG_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------
+// Mailbox and zeroed counters (device_graph.h).
+// ------------------------------------------------------------------------------------------
+__global__ void k_mail_post(unsigned long long* slot, unsigned seq, const int32_t* p0, const int32_t* p1,
+                            const int32_t* p2, const int32_t* p3) {
+  if (p0) MailPost(slot, seq, 0, *p0);
+  if (p1) MailPost(slot, seq, 1, *p1);
+  if (p2) MailPost(slot, seq, 2, *p2);
+  if (p3) MailPost(slot, seq, 3, *p3);
+}
+
+void LaunchMailPost(const MailSlot& slot, const int32_t* p0, const int32_t* p1, const int32_t* p2,
+                    const int32_t* p3, hipStream_t s) {
+  hipLaunchKernelGGL(k_mail_post, dim3(1), dim3(1), 0, s, slot.dev, slot.seq, p0, p1, p2, p3);
+  VSG_HIP(hipGetLastError());
+}
+
+void MailWait(const MailSlot& slot, int count, int* values, hipStream_t s) {
+  using clk = std::chrono::steady_clock;
+  clk::time_point t0;
+  bool timed = false;
+  for (int i = 0; i < count; ++i) {
+    for (unsigned long long spins = 0;; ++spins) {
+      const unsigned long long w = slot.host[i];
+      if ((unsigned)(w >> 32) == slot.seq) {
+        values[i] = (int)(unsigned)(w & 0xffffffffull);
+        break;
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+      if ((spins & 0xffffull) == 0xffffull) {
+        // nothing for a while: a kernel that died would never post
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipSuccess && e != hipErrorNotReady) VSG_HIP(e);
+        if (!timed) {
+          t0 = clk::now();
+          timed = true;
+        } else if (e == hipSuccess && clk::now() - t0 > std::chrono::seconds(2)) {
+          // the stream is idle and the value is not there: whoever should post it did not
+          const unsigned long long w2 = slot.host[i];
+          if ((unsigned)(w2 >> 32) != slot.seq) throw Error(-4 /* VSG_ERR_INTERNAL */, "mailbox: a value never arrived");
+        }
+        std::this_thread::yield();
+      }
+    }
+  }
+}
+
+int32_t* TakeZeroed(MergeScratch& S, size_t n) {
+  ZeroPool& z = *S.zeros;
+  n = (n + 3) & ~(size_t)3;
+  VSG_REQUIRE(n <= z.cap, -4, "zero pool: request too large");
+  if (z.used + n > z.cap) {
+    VSG_HIP(hipStreamSynchronize(S.main_stream));
+    if (S.aux_stream) VSG_HIP(hipStreamSynchronize(S.aux_stream));
+    if (S.aux2_stream) VSG_HIP(hipStreamSynchronize(S.aux2_stream));
+    VSG_HIP(hipMemsetAsync(z.base, 0, z.cap * sizeof(int32_t), S.main_stream));
+    z.used = 0;
+  }
+  int32_t* p = z.base + z.used;
+  z.used += n;
+  return p;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -226,8 +293,10 @@ __global__ __launch_bounds__(256) void k_backup_roots(int n, const int32_t* __re
                                                        const int32_t* __restrict__ a_rb,
                                                        NodeArrays nodes, float4* __restrict__ bk_ds,
                                                        int32_t* __restrict__ bk_cons,
-                                                       uint8_t* __restrict__ bk_flags) {
+                                                       uint8_t* __restrict__ bk_flags,
+                                                       unsigned long long* __restrict__ stats) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 8) stats[8 + i] = stats[i];   // the merge statistics are undone with the stage
   if (i >= n) return;
   const int ra = a_ra[i], rb = a_rb[i];
   bk_ds[2 * i] = nodes.desc_sz[ra];
@@ -243,8 +312,10 @@ __global__ __launch_bounds__(256) void k_restore_roots(int n, const int32_t* __r
                                                         NodeArrays nodes,
                                                         const float4* __restrict__ bk_ds,
                                                         const int32_t* __restrict__ bk_cons,
-                                                        const uint8_t* __restrict__ bk_flags) {
+                                                        const uint8_t* __restrict__ bk_flags,
+                                                        unsigned long long* __restrict__ stats) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 8) stats[i] = stats[8 + i];
   if (i >= n) return;
   const int ra = a_ra[i], rb = a_rb[i];
   nodes.parent[ra] = ra;
@@ -276,7 +347,9 @@ __global__ __launch_bounds__(256) void k_compact_active(int n_b, FilterMasks M,
                                                          int32_t* __restrict__ a_ra,
                                                          int32_t* __restrict__ a_rb,
                                                          uint32_t* __restrict__ a_gpos,
-                                                         int32_t* __restrict__ num_active) {
+                                                         int32_t* __restrict__ num_active,
+                                                         const int32_t* __restrict__ num_ti,
+                                                         unsigned long long* __restrict__ mail, unsigned mail_seq) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t gw0 = (size_t)blockIdx.x * 4;
@@ -290,7 +363,12 @@ __global__ __launch_bounds__(256) void k_compact_active(int n_b, FilterMasks M,
     a_rb[p] = e_rb[slot];
     a_gpos[p] = e_gpos[slot];
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *num_active = base + (int)__popcll(m);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+    const int total = base + (int)__popcll(m);
+    *num_active = total;
+    MailPost(mail, mail_seq, 0, total);
+    MailPost(mail, mail_seq, 1, *num_ti);   // (k_filter's sum: complete, it is the kernel before)
+  }
 }
 
 __global__ __launch_bounds__(256) void k_component_ids(int n, const int32_t* __restrict__ a_ra,
@@ -305,8 +383,12 @@ __global__ __launch_bounds__(256) void k_component_ids(int n, const int32_t* __r
 
 __global__ __launch_bounds__(256) void k_reset_cc(int n, const int32_t* __restrict__ a_ra,
                                                    const int32_t* __restrict__ a_rb,
-                                                   int32_t* __restrict__ cc) {
+                                                   int32_t* __restrict__ cc,
+                                                   const int32_t* __restrict__ violation,
+                                                   unsigned long long* __restrict__ mail, unsigned mail_seq) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  // (the workers of the stage are done: this kernel follows the join of their streams)
+  if (i == 0 && mail) MailPost(mail, mail_seq, 0, *violation);
   if (i >= n) return;
   const int ra = a_ra[i], rb = a_rb[i];
   cc[ra] = ra;
@@ -447,7 +529,8 @@ __global__ __launch_bounds__(256) void k_compact_leaders(int n, const int32_t* _
                                                           int32_t* __restrict__ l_ra,
                                                           int32_t* __restrict__ l_rb,
                                                           uint32_t* __restrict__ l_gpos,
-                                                          int32_t* __restrict__ num_leaders) {
+                                                          int32_t* __restrict__ num_leaders,
+                                                          unsigned long long* __restrict__ mail, unsigned mail_seq) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
   if (lead[p]) {
@@ -456,7 +539,10 @@ __global__ __launch_bounds__(256) void k_compact_leaders(int n, const int32_t* _
     l_rb[q] = a_rb[p];
     l_gpos[q] = a_gpos[p];
   }
-  if (p == n - 1) *num_leaders = lpos[p] + lead[p];
+  if (p == n - 1) {
+    *num_leaders = lpos[p] + lead[p];
+    MailPost(mail, mail_seq, 0, lpos[p] + lead[p]);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_resolve_followers(int n, const int32_t* __restrict__ lead,
@@ -488,10 +574,9 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   }
   if (n_b <= 0) return;
   const int bucket_hi = S.group_hi > bucket ? S.group_hi : bucket + 1;
-  int32_t* d_num_ti = S.num_active + 2;
-  int32_t* d_violation = S.num_active + 3;
+  int32_t* d_num_ti = TakeZeroed(S, 2);   // fresh counters per stage: nothing to clear
+  int32_t* d_violation = d_num_ti + 1;
   int32_t* d_num_leaders = S.num_active + 5;
-  VSG_HIP(hipMemsetAsync(d_num_ti, 0, 2 * sizeof(int32_t), s));
   const int ef0 = NextEvent(S);
   if (ef0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ef0], s));
   hipLaunchKernelGGL(k_filter, dim3(Blocks(n_b)), dim3(256), 0, s, bucket, bucket_hi, j0, n_b, lists,
@@ -503,14 +588,15 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     S.ev_filter->emplace_back(ef0, ef1);
   }
   ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, S.masks.block_cnt, S.block_off, (int)Blocks(n_b), s);
+  const MailSlot m_active = NextMail(*S.mail);
   hipLaunchKernelGGL(k_compact_active, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks, S.block_off,
-                     S.e_ra, S.e_rb, S.e_gpos, S.a_ra, S.a_rb, S.a_gpos, S.num_active);
+                     S.e_ra, S.e_rb, S.e_gpos, S.a_ra, S.a_rb, S.a_gpos, S.num_active, d_num_ti, m_active.dev,
+                     m_active.seq);
   VSG_HIP(hipGetLastError());
-  int h[4] = {0, 0, 0, 0};   // num_active, num_segs (unused), num_ti, violation
-  VSG_HIP(hipMemcpyAsync(h, S.num_active, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-  VSG_HIP(hipStreamSynchronize(s));
+  int h[2] = {0, 0};   // num_active, num_ti
+  MailWait(m_active, 2, h, s);
   const int n_active = h[0];
-  const int n_ti = h[2];
+  const int n_ti = h[1];
   auto clear_marks = [&]() {
     if (n_ti > 0) {
       hipLaunchKernelGGL(k_clear_tentative, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks, S.e_ra,
@@ -534,11 +620,11 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     hipLaunchKernelGGL(k_mark_leaders, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra,
                        S.a_rb, lead);
     ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, lead, S.lead_pos, n_active, s);
+    const MailSlot m_lead = NextMail(*S.mail);
     hipLaunchKernelGGL(k_compact_leaders, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, lead,
                        S.lead_pos, S.a_ra, S.a_rb, S.a_gpos, S.l_ra, S.l_rb, S.l_gpos,
-                       d_num_leaders);
-    VSG_HIP(hipMemcpyAsync(&n_work, d_num_leaders, sizeof(int), hipMemcpyDeviceToHost, s));
-    VSG_HIP(hipStreamSynchronize(s));
+                       d_num_leaders, m_lead.dev, m_lead.seq);
+    MailWait(m_lead, 1, &n_work, s);
     w_ra = S.l_ra;
     w_rb = S.l_rb;
     w_gpos = S.l_gpos;
@@ -561,12 +647,12 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       !(bucket < 2 && S.spine_low_skip[bucket]) && inert_mode != 0 && n_work >= S.spine_min) {
     long long wanted = 0;
     spine_thr = SelectLargeSegments(n_work, S.num_segs, S.seg_off, S.seg_cnt, S.spine_min,
-                                    S.spine_max_edges, S.spine_pool, s, &spine_in, &wanted);
+                                    S.spine_max_edges, S, s, &spine_in, &wanted);
     if (wanted > S.spine_max_edges && S.grow_spine_pool && S.grow_spine_pool(wanted)) {
       // the pool was too small for this input (it is sized for a typical bucket, not for the
       // largest one a video can produce): it has grown, choose again
       spine_thr = SelectLargeSegments(n_work, S.num_segs, S.seg_off, S.seg_cnt, S.spine_min,
-                                      S.spine_max_edges, S.spine_pool, s, &spine_in, nullptr);
+                                      S.spine_max_edges, S, s, &spine_in, nullptr);
     }
   }
   const bool spine = !spine_in.segs.empty();
@@ -575,9 +661,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   const bool optimistic = ((inert_mode == 2) && (n_ti > 0 || rle)) || spine;
   if (optimistic) {
     hipLaunchKernelGGL(k_backup_roots, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, w_rb,
-                       nodes, S.bk_ds, S.bk_cons, S.bk_flags);
-    VSG_HIP(hipMemcpyAsync(S.stats + 8, S.stats, 8 * sizeof(unsigned long long),
-                           hipMemcpyDeviceToDevice, s));
+                       nodes, S.bk_ds, S.bk_cons, S.bk_flags, S.stats);
   }
 
   const float weight = (float)bucket * P.inv_scale;
@@ -620,10 +704,9 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   // stage's scalars
   wa.work_cap = n_work / (small_seg + 1) + 1;
   wa.work_list = (size_t)kWaveClasses * wa.work_cap <= (size_t)n_work ? S.seg_key : nullptr;
-  wa.work_ctl = S.num_active + 8;
+  wa.work_ctl = wa.work_list ? TakeZeroed(S, 2 * kWaveClasses) : nullptr;
   auto general_workers = [&](const WorkerArgs& w, int small_threads, int grid, hipStream_t s) {
     if (w.wave_min == w.small_seg) {
-      if (w.work_list) VSG_HIP(hipMemsetAsync(w.work_ctl, 0, 2 * kWaveClasses * sizeof(int32_t), s));
       hipLaunchKernelGGL(k_merge_small, dim3(Blocks(small_threads)), dim3(256), 0, s, w.num_segs,
                          w.seg_off, w.seg_cnt, w.s_ra, w.s_rb, w.s_gpos, w.nodes, w.kept_all, w.T,
                          w.optimistic, w.violation, w.stats, w.small_seg, w.wave_max, w.work_list, w.work_cap,
@@ -650,7 +733,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     VSG_HIP(hipEventRecord(S.aux_join, S.aux_stream));
     const bool done = RunSpineComponents(spine_in, wa, S, s, [&](const WorkerArgs& w, int n, hipStream_t st) {
       general_workers(w, n, WaveGrid(n), st);
-    }, kSpineListInts, 0);
+    }, 0, 0);
     if (!done) {   // no room in the scratch pool: the wave worker replays them
       WorkerArgs w3 = wa;
       w3.wave_min = spine_thr - 1;
@@ -660,20 +743,20 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     }
     VSG_HIP(hipStreamWaitEvent(s, S.aux_join, 0));
   }
-  hipLaunchKernelGGL(k_reset_cc, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, w_rb, S.cc);
+  MailSlot m_vio = {nullptr, nullptr, 0};
+  if (optimistic) m_vio = NextMail(*S.mail);
+  hipLaunchKernelGGL(k_reset_cc, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, w_rb, S.cc, d_violation,
+                     m_vio.dev, m_vio.seq);
   VSG_HIP(hipGetLastError());
   if (optimistic) {
     int violated = 0;
-    VSG_HIP(hipMemcpyAsync(&violated, d_violation, sizeof(int), hipMemcpyDeviceToHost, s));
-    VSG_HIP(hipStreamSynchronize(s));
+    MailWait(m_vio, 1, &violated, s);
     ++*S.optimistic_stages;
     if (violated || S.force_rollback) {
       // Undo the stage and replay it without any tentatively settled edge, every edge on its own.
       ++*S.rollbacks;
       hipLaunchKernelGGL(k_restore_roots, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, w_rb,
-                         nodes, S.bk_ds, S.bk_cons, S.bk_flags);
-      VSG_HIP(hipMemcpyAsync(S.stats, S.stats + 8, 8 * sizeof(unsigned long long),
-                             hipMemcpyDeviceToDevice, s));
+                         nodes, S.bk_ds, S.bk_cons, S.bk_flags, S.stats);
       hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks, S.e_gpos, kept_all);
       clear_marks();
       VSG_HIP(hipGetLastError());
@@ -723,13 +806,15 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     // (a component above the window threshold needs that many replayed edges: small stages are
     // not worth the synchronisation)
     if (info->want_components && (info->want_components > 1 || n_work > 16384)) {
-      int32_t* d_max = S.num_active + 16;
-      VSG_HIP(hipMemsetAsync(d_max, 0, sizeof(int32_t), s));
+      int32_t* d_max = TakeZeroed(S, 1);
       hipLaunchKernelGGL(k_max_segment, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, S.num_segs, S.seg_cnt,
                          spine ? spine_thr : 0x7fffffff, d_max);
-      VSG_HIP(hipMemcpyAsync(&info->components, S.num_segs, sizeof(int), hipMemcpyDeviceToHost, s));
-      VSG_HIP(hipMemcpyAsync(&info->max_wave_segment, d_max, sizeof(int), hipMemcpyDeviceToHost, s));
-      VSG_HIP(hipStreamSynchronize(s));
+      const MailSlot m_info = NextMail(*S.mail);
+      LaunchMailPost(m_info, S.num_segs, d_max, nullptr, nullptr, s);
+      int v[2] = {0, 0};
+      MailWait(m_info, 2, v, s);
+      info->components = v[0];
+      info->max_wave_segment = v[1];
     }
   }
   if (rle && n_work < n_active) {
