@@ -88,13 +88,15 @@ __device__ __forceinline__ uint32_t BorKey(int round, int e) { return ((uint32_t
 
 // The kernels of a round run over all edges (list == null) or over the list of the edges that were
 // still alive a round or two ago.
-__global__ __launch_bounds__(256) void k_bor_min(int n, const int32_t* __restrict__ list, int round,
+__global__ __launch_bounds__(256) void k_bor_min(int n, const int32_t* __restrict__ list,
+                                                  const int32_t* __restrict__ list_len, int round,
                                                   const int32_t* __restrict__ eu,
                                                   const int32_t* __restrict__ ev, int32_t* __restrict__ estate,
                                                   int32_t* __restrict__ cc, uint32_t* __restrict__ best,
                                                   int32_t* __restrict__ ecu, int32_t* __restrict__ ecv,
                                                   int32_t* __restrict__ alive) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (list_len) n = min(n, *list_len);   // (the list was compacted on the device: n is its capacity)
   const int e = i < n ? (list ? list[i] : i) : -1;
   bool live = false;
   int cu = -1, cv = -1;
@@ -118,10 +120,11 @@ __global__ __launch_bounds__(256) void k_bor_min(int n, const int32_t* __restric
   // so a lane whose component already appears in the lane before it has nothing to add; and a
   // plain (cached, possibly stale: only ever too large) read keeps all but the first few of the
   // others away from the atomic.
-  const int pu = __shfl_up(cu, 1), pv = __shfl_up(cv, 1);
+  const int pu = __shfl_up(cu, 1), pv = __shfl_up(cv, 1), pe = __shfl_up(e, 1);
   if (live) {
     const uint32_t key = BorKey(round, e);
-    const bool has_prev = (threadIdx.x & 63) != 0;
+    // (a compacted list is in rank order only piecewise: the lane before must hold a smaller rank)
+    const bool has_prev = (threadIdx.x & 63) != 0 && pe < e;
     if (!(has_prev && (cu == pu || cu == pv)) && key < best[cu]) atomicMin(&best[cu], key);
     if (!(has_prev && (cv == pu || cv == pv)) && key < best[cv]) atomicMin(&best[cv], key);
   }
@@ -129,45 +132,46 @@ __global__ __launch_bounds__(256) void k_bor_min(int n, const int32_t* __restric
   if (m && (threadIdx.x & 63) == 0) atomicAdd(alive, (int)__popcll(m));
 }
 
-__global__ __launch_bounds__(256) void k_bor_mark(int n, const int32_t* __restrict__ list, int round,
-                                                   const int32_t* __restrict__ eu,
-                                                   const int32_t* __restrict__ ev,
-                                                   int32_t* __restrict__ estate,
+// The edges that are the minimum of one of their two components join them (tree edges); the first
+// thread reports the number of edges k_bor_min found alive.
+__global__ __launch_bounds__(256) void k_bor_hook(int n, const int32_t* __restrict__ list,
+                                                   const int32_t* __restrict__ list_len, int round,
+                                                   const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
+                                                   int32_t* __restrict__ estate, int32_t* __restrict__ cc,
                                                    const uint32_t* __restrict__ best,
-                                                   const int32_t* __restrict__ ecu, const int32_t* __restrict__ ecv) {
+                                                   const int32_t* __restrict__ ecu, const int32_t* __restrict__ ecv,
+                                                   const int32_t* __restrict__ alive,
+                                                   unsigned long long* __restrict__ mail, unsigned mail_seq) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) MailPost(mail, mail_seq, 0, *alive);
+  if (list_len) n = min(n, *list_len);
   if (i >= n) return;
   const int e = list ? list[i] : i;
   if (estate[e] != 0) return;
   const uint32_t key = BorKey(round, e);
   const int cu = round == 0 ? eu[e] : ecu[e], cv = round == 0 ? ev[e] : ecv[e];
-  if (best[cu] == key || best[cv] == key) estate[e] = 3;
+  if (best[cu] == key || best[cv] == key) {
+    CcUnion(cc, eu[e], ev[e]);
+    estate[e] = 1;
+  }
 }
 
-__global__ __launch_bounds__(256) void k_bor_union(int n, const int32_t* __restrict__ list,
-                                                    const int32_t* __restrict__ eu,
-                                                    const int32_t* __restrict__ ev, int32_t* __restrict__ estate,
-                                                    int32_t* __restrict__ cc) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int e = list ? list[i] : i;
-  if (estate[e] != 3) return;
-  CcUnion(cc, eu[e], ev[e]);
-  estate[e] = 1;
-}
-
-__global__ __launch_bounds__(256) void k_bor_alive_flags(int n, const int32_t* __restrict__ list,
-                                                          const int32_t* __restrict__ estate,
-                                                          int32_t* __restrict__ flag) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) flag[i] = estate[list ? list[i] : i] == 0 ? 1 : 0;
-}
-
+// The edges that are still alive, in any order (the rounds only take minima over them).
 __global__ __launch_bounds__(256) void k_bor_compact(int n, const int32_t* __restrict__ list,
-                                                      const int32_t* __restrict__ flag,
-                                                      const int32_t* __restrict__ scan, int32_t* __restrict__ out) {
+                                                      const int32_t* __restrict__ list_len,
+                                                      const int32_t* __restrict__ estate, int32_t* __restrict__ out,
+                                                      int32_t* __restrict__ out_len) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n && flag[i]) out[scan[i]] = list ? list[i] : i;
+  if (list_len) n = min(n, *list_len);
+  const int e = i < n ? (list ? list[i] : i) : -1;
+  const bool keep = e >= 0 && estate[e] == 0;
+  const unsigned long long m = __ballot(keep);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(out_len, (int)__popcll(m));
+  base = __shfl(base, 0);
+  if (keep) out[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = e;
 }
 
 // ---- R: the largest region of every component --------------------------------------------------------
@@ -321,9 +325,10 @@ __global__ __launch_bounds__(256) void k_jump_init(int mt, const int32_t* __rest
   val[j] = te_e[j];
 }
 
+// more (optional): set when some vertex has not reached the root yet after this step.
 __global__ __launch_bounds__(256) void k_jump_max(int mt, const int32_t* __restrict__ j_in,
                                                    const int32_t* __restrict__ v_in, int32_t* __restrict__ j_out,
-                                                   int32_t* __restrict__ v_out) {
+                                                   int32_t* __restrict__ v_out, int32_t* __restrict__ more) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= mt) return;
   const int p = j_in[j];
@@ -331,26 +336,20 @@ __global__ __launch_bounds__(256) void k_jump_max(int mt, const int32_t* __restr
     j_out[j] = kNone;
     v_out[j] = v_in[j];
   } else {
-    j_out[j] = j_in[p];
+    const int pp = j_in[p];
+    j_out[j] = pp;
     v_out[j] = max(v_in[j], v_in[p]);
+    if (more && pp != kNone) *more = 1;
   }
 }
 
-// head: the spine edge through which the vertex joins R's cluster (itself for the child of a spine
-// edge, otherwise the head of the parent: a non-spine edge has a smaller rank than t(parent)).
-__global__ __launch_bounds__(256) void k_head_init(int mt, const int32_t* __restrict__ te_e,
-                                                    const int32_t* __restrict__ tval,
-                                                    const int32_t* __restrict__ par,
-                                                    const int32_t* __restrict__ childidx, int32_t* __restrict__ head) {
+// head: the spine edge through which the vertex joins R's cluster -- the tree edge whose rank is
+// t(vertex) (ranks are edge indices: unique), found through the scan that compacted the tree edges
+// (te_e[scan[e]] == e).
+__global__ __launch_bounds__(256) void k_head_lookup(int mt, const int32_t* __restrict__ tval,
+                                                      const int32_t* __restrict__ scan, int32_t* __restrict__ head) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= mt) return;
-  head[j] = (tval[j] == te_e[j]) ? j : childidx[par[j]];
-}
-
-__global__ __launch_bounds__(256) void k_head_step(int mt, const int32_t* __restrict__ h_in,
-                                                    int32_t* __restrict__ h_out) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j < mt) h_out[j] = h_in[h_in[j]];
+  if (j < mt) head[j] = scan[tval[j]];
 }
 
 // ---- classification of every edge ----------------------------------------------------------------------
@@ -1298,24 +1297,26 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   }
   {
     const size_t forest_mark = pool.mark();
-    const int32_t* list = nullptr;   // the edges the rounds still look at (null: all)
-    int n_list = mE;
+    const int32_t* list = nullptr;      // the edges the rounds still look at (null: all)
+    const int32_t* list_len = nullptr;  // its length, on the device
+    int n_list = mE;                    // its capacity
     int32_t* lists[2] = {nullptr, nullptr};
     int which = 0;
     for (int round = 0;; ++round) {
       dbg_rounds = round;
       VSG_REQUIRE(round < 32, -4, "spine: the spanning forest did not converge");
-      int32_t* d_alive = TakeZeroed(S, 1);
+      int32_t* d_ctr = TakeZeroed(S, 2);   // [0] edges alive in this round, [1] length of the next list
       // ecu / ecv (the components of the round) live in the side_key / spine_flag arrays, which are
       // only written once the forest is done
-      hipLaunchKernelGGL(k_bor_min, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, round, eu, ev, estate, cc,
-                         best, side_key, spine_flag, d_alive);
+      hipLaunchKernelGGL(k_bor_min, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, list_len, round, eu, ev,
+                         estate, cc, best, side_key, spine_flag, d_ctr);
+      const MailSlot m_alive = NextMail(*S.mail);
+      hipLaunchKernelGGL(k_bor_hook, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, list_len, round, eu, ev,
+                         estate, cc, best, side_key, spine_flag, d_ctr, m_alive.dev, m_alive.seq);
       const double tr0 = dbg_big ? NowMs() : 0;
       int alive = 0;
-      const MailSlot m_alive = NextMail(*S.mail);
-      LaunchMailPost(m_alive, d_alive, nullptr, nullptr, nullptr, s);
       MailWait(m_alive, 1, &alive, s);
-      if (dbg_big) std::fprintf(stderr, "[vsg]   forest round %d: %d in list, %d alive, min %.2f ms\n", round, n_list, alive, NowMs() - tr0);
+      if (dbg_big) std::fprintf(stderr, "[vsg]   forest round %d: %d in list, %d alive, %.2f ms\n", round, n_list, alive, NowMs() - tr0);
       if (alive == 0) break;
       if (alive < n_list / 2 && n_list > (1 << 16)) {   // drop the settled edges from the rounds to come
         if (!lists[0]) {
@@ -1329,22 +1330,14 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
           }
         }
         if (lists[0]) {
-          hipLaunchKernelGGL(k_bor_alive_flags, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, estate, flag);
-          ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, flag, scan, n_list, s);
-          hipLaunchKernelGGL(k_bor_compact, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, flag, scan,
-                             lists[which]);
+          // (at most `alive` edges are left: the ones this round hooked are gone as well)
+          hipLaunchKernelGGL(k_bor_compact, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, list_len, estate,
+                             lists[which], d_ctr + 1);
           list = lists[which];
+          list_len = d_ctr + 1;
           which ^= 1;
           n_list = alive;
         }
-      }
-      hipLaunchKernelGGL(k_bor_mark, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, round, eu, ev, estate,
-                         best, side_key, spine_flag);
-      hipLaunchKernelGGL(k_bor_union, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, eu, ev, estate, cc);
-      if (dbg_big) {
-        const double tr1 = NowMs();
-        VSG_HIP(hipStreamSynchronize(s));
-        std::fprintf(stderr, "[vsg]   forest round %d: compaction+mark+union %.2f ms\n", round, NowMs() - tr1);
       }
     }
     pool.release(forest_mark);
@@ -1363,7 +1356,7 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   int32_t* par = pool.take(mt);
   int32_t* jump[2] = {pool.take(mt), pool.take(mt)};
   int32_t* val[2] = {pool.take(mt), pool.take(mt)};
-  int32_t* head[2] = {pool.take(mt), pool.take(mt)};
+  int32_t* head = pool.take(mt);
   int32_t* sp_child = pool.take(mt);
   int32_t* sp_is_a = pool.take(mt);
   const size_t arcs_mark = pool.mark();
@@ -1395,19 +1388,26 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   Mark(2);
   // ---- t(x), side clusters -------------------------------------------------------------------------------------
   hipLaunchKernelGGL(k_jump_init, dim3(Blocks(mt)), dim3(256), 0, s, mt, te_e, par, childidx, jump[0], val[0]);
+  // The jumps double the distance covered; the trees are usually shallow (a hub and what hangs off
+  // it), so every few steps the device says whether any vertex is still short of its root.
   int cj = 0;
-  for (int span = 1; span < mt; span *= 2) {
+  for (int span = 1, step = 0; span < mt; span *= 2, ++step) {
+    const bool ask = (step % 3 == 2) && span * 2 < mt;
+    int32_t* d_more = ask ? TakeZeroed(S, 1) : nullptr;
     hipLaunchKernelGGL(k_jump_max, dim3(Blocks(mt)), dim3(256), 0, s, mt, jump[cj], val[cj], jump[cj ^ 1],
-                       val[cj ^ 1]);
+                       val[cj ^ 1], d_more);
     cj ^= 1;
+    if (ask) {
+      const MailSlot m = NextMail(*S.mail);
+      LaunchMailPost(m, d_more, nullptr, nullptr, nullptr, s);
+      int more = 0;
+      MailWait(m, 1, &more, s);
+      if (!more) break;
+    }
   }
-  hipLaunchKernelGGL(k_head_init, dim3(Blocks(mt)), dim3(256), 0, s, mt, te_e, val[cj], par, childidx, head[0]);
-  int ch = 0;
-  for (int span = 1; span < mt; span *= 2) {
-    hipLaunchKernelGGL(k_head_step, dim3(Blocks(mt)), dim3(256), 0, s, mt, head[ch], head[ch ^ 1]);
-    ch ^= 1;
-  }
-  hipLaunchKernelGGL(k_classify, dim3(Blocks(mE)), dim3(256), 0, s, mE, eu, ev, estate, childidx, head[ch],
+  // (scan still maps an edge to its position among the tree edges)
+  hipLaunchKernelGGL(k_head_lookup, dim3(Blocks(mt)), dim3(256), 0, s, mt, val[cj], scan, head);
+  hipLaunchKernelGGL(k_classify, dim3(Blocks(mE)), dim3(256), 0, s, mE, eu, ev, estate, childidx, head,
                      te_e, flag, side_key, spine_flag);
 
   Mark(3);
