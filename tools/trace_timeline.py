@@ -79,3 +79,14 @@ for a, b in zip(fl, fl[1:] + [(t1, t1, "", 0)]):
         names[r[2]] += r[1] - r[0]
     top = sorted(names.items(), key=lambda kv: -kv[1])[:5]
     print("  %7.2f  grid %9d  %s" % ((b[0] - a[0]) / 1e6, 0, ", ".join("%s %.2f" % (n, t / 1e6) for n, t in top)))
+
+# optional: the launches of one stage, in start order (argv[3] = stage index)
+if len(sys.argv) > 3:
+    st = int(sys.argv[3])
+    fidx = [i for i, r in enumerate(seg) if r[2] == "k_filter"]
+    lo = fidx[st]
+    hi = fidx[st + 1] if st + 1 < len(fidx) else len(seg)
+    base = seg[lo][0]
+    print("launches of stage %d:" % st)
+    for r in seg[lo:hi]:
+        print("  %9.1f us  +%8.1f us  stream %d  %s" % ((r[0] - base) / 1e3, (r[1] - r[0]) / 1e3, r[3], r[2]))
