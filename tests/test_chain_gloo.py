@@ -77,8 +77,10 @@ def _worker(rank, world, port, outfile):
     got = run_chain(lambda: ol.OracleStream(W, H, ol.default_options(chunk_size=CHUNK), has_flow=True),
                     lambda k: synth.bench_frame(W, H, k), lambda k: fl, N, CHUNK, W, H, rank, world,
                     tr)
+    from video_segment_amd.multi_gpu import chain_nonce
+    nonces = (chain_nonce(), chain_nonce())     # what two launches in a row would draw
     with open(outfile, "wb") as f:
-        pickle.dump(got, f)
+        pickle.dump((got, nonces), f)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -98,10 +100,15 @@ def test_chain_world2_gloo():
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
-    got = []
+    got, nonces = [], []
     for f in files:
         with open(f, "rb") as fh:
-            got += pickle.load(fh)
+            g, nn = pickle.load(fh)
+            got += g
+            nonces.append(nn)
+    # the nonce of the RCCL id file (vsg_chain_create): the same on every rank of a launch, another
+    # one for the next launch although the launcher's environment has not changed
+    assert nonces[0] == nonces[1] and nonces[0][0] != nonces[0][1] and all(0 < n < 2 ** 63 for n in nonces[0])
     got.sort(key=lambda kv: kv[0])
     want = single_stream()
     assert [k for k, _ in got] == list(range(N))

@@ -66,3 +66,58 @@ def test_close_in_the_middle_of_a_video():
     for f in frames:
         p.process_frame(f)
     p.close()      # engines may be waiting for frames or for a hand-off: must not hang
+
+
+class _FailingEngine:
+    """Stream interface whose third frame raises: what a device fault in one engine looks like."""
+
+    def __init__(self):
+        self.frames = 0
+
+    def process_frame(self, frame, flow, flush=False):
+        self.frames += 1
+        if self.frames == 3:
+            raise RuntimeError("engine failed")
+        return 0
+
+    def restart(self):
+        pass
+
+    def expect_halo(self):
+        pass
+
+    def import_halo(self, *a):
+        pass
+
+    def result_bytes(self, i):
+        return b""
+
+    def close(self):
+        pass
+
+
+@pytest.mark.timeout(60)
+def test_failed_engine_reaches_a_fast_caller_and_close_does_not_hang():
+    """A caller that feeds faster than the engines consume sits in a full input queue most of the
+    time; when an engine dies it has to see the error there (not block for ever), and closing the
+    unit afterwards has to return.  The engine threads do not keep the unit alive either."""
+    import gc
+    import weakref
+    W, H, chunk = 40, 30, 8
+    frames = frames_of("probe", W, H, 2)
+    p = PipelinedDenseSegmentation(W, H, ol.default_options(chunk_size=chunk), has_flow=False,
+                                   engine_factory=_FailingEngine, halo_of=lambda e: (None, None, None))
+    with pytest.raises(RuntimeError, match="engine failed"):
+        for k in range(400):
+            p.process_frame(frames[k % 2])
+    p.close()
+    q = PipelinedDenseSegmentation(W, H, ol.default_options(chunk_size=chunk), has_flow=False,
+                                   engine_factory=_FailingEngine, halo_of=lambda e: (None, None, None))
+    ref = weakref.ref(q)
+    threads = list(q._threads)
+    del q
+    gc.collect()
+    assert ref() is None            # collected although nobody called close() ...
+    for t in threads:
+        t.join(10)
+        assert not t.is_alive()     # ... and its __del__ stopped the engine threads

@@ -175,3 +175,34 @@ def test_options_contract(vsg):
     with pytest.raises(VsgError):
         p.process_frame(b"\xff\xff\xff", np.zeros((48, 64, 3), np.uint8))   # malformed message
     p.close()
+
+
+def test_foreign_or_corrupt_oversegmentation_is_rejected(vsg):
+    """The rasters of the dense unit's message index the frame, the flow field and the id image of
+    the vectorisation: a message of another frame size, or one whose scan intervals leave the
+    frame, is refused (VSG_ERR_INVALID) before anything is indexed with it."""
+    from video_segment_amd._lib import VsgError
+    W, H, chunk = 64, 48, 8
+    frame = np.zeros((H, W, 3), np.uint8)
+    other = overseg(80, 60, 1, chunk, synth.soft_frame, None)[0][2]     # a unit of another size
+    p = vsg.RegionSegmentation(W, H)
+    with pytest.raises(VsgError, match="another frame size"):
+        p.process_frame(other, frame)
+    good = overseg(W, H, 1, chunk, synth.soft_frame, None)[0][2]
+    Msg = build_schema()
+    for field, value in (("right_x", W + 5), ("y", H), ("left_x", -1)):
+        m = Msg()
+        m.ParseFromString(good)
+        iv = m.region[0].raster.scan_inter[0]
+        setattr(iv, field, value)
+        if field == "left_x":
+            iv.right_x = 0
+        with pytest.raises(VsgError, match="outside the frame"):
+            vsg.RegionSegmentation(W, H).process_frame(m.SerializeToString(), frame)
+    inverted = Msg()
+    inverted.ParseFromString(good)
+    iv = inverted.region[0].raster.scan_inter[0]
+    iv.left_x, iv.right_x = 7, 3
+    with pytest.raises(VsgError, match="outside the frame"):
+        vsg.RegionSegmentation(W, H).process_frame(inverted.SerializeToString(), frame)
+    assert vsg.RegionSegmentation(W, H).process_frame(good, frame, flush=True) == 1   # the intact one is fine

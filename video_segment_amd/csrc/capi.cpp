@@ -88,6 +88,7 @@ struct vsg_stream {
 
 struct vsg_regionseg {
   std::unique_ptr<vsg::RegionSegmentationHost> impl;
+  int W = 0, H = 0;
 };
 
 struct vsg_graph {
@@ -514,6 +515,8 @@ int vsg_regionseg_create(const vsg_regionseg_options* o, int width, int height, 
     d.compute_vectorization = o->compute_vectorization != 0;
     std::unique_ptr<vsg_regionseg> r(new vsg_regionseg);
     r->impl.reset(new vsg::RegionSegmentationHost(d, width, height));
+    r->W = width;
+    r->H = height;
     *out = r.release();
   });
 }
@@ -527,6 +530,17 @@ int vsg_regionseg_process_frame(vsg_regionseg* r, int flush, const uint8_t* seg_
     if (seg_desc) {
       vsg::SegDesc d;
       VSG_REQUIRE(vsg::DecodeSegDesc(seg_desc, seg_len, &d), VSG_ERR_INVALID, "malformed SegmentationDesc");
+      // The rasters index the frame, the flow field and the id image of the vectorisation: a message
+      // from a dense unit of another size (or a corrupt one) must not get that far.
+      VSG_REQUIRE(d.frame_width == r->W && d.frame_height == r->H, VSG_ERR_INVALID,
+                  "SegmentationDesc of another frame size");
+      for (const vsg::Region2DOut& reg : d.regions) {
+        for (const vsg::Interval& iv : reg.raster) {
+          VSG_REQUIRE(iv.y >= 0 && iv.y < r->H && iv.lx >= 0 && iv.lx <= iv.rx && iv.rx < r->W, VSG_ERR_INVALID,
+                      "malformed SegmentationDesc: scan interval outside the frame");
+        }
+      }
+      VSG_REQUIRE(bgr != nullptr && stride >= (size_t)r->W * 3, VSG_ERR_INVALID, "frame missing or stride too small");
       *num_results = r->impl->ProcessFrame(flush != 0, &d, bgr, stride, flow);
     } else {
       *num_results = r->impl->ProcessFrame(flush != 0, nullptr, bgr, stride, flow);

@@ -173,13 +173,29 @@ def run_chain(engine_factory, get_frame, get_flow, num_frames, chunk, width, hei
 
 
 def chain_nonce():
-    """A nonce the ranks of one launch share (see vsg_chain_create): from the launcher's
-    environment, which torchrun gives every rank of a run and changes between runs."""
+    """A nonce all ranks of ONE launch share and no other launch has (see vsg_chain_create: a stale
+    id file of a crashed job must not be mistaken for this job's).  With a process group: rank 0
+    draws it at random and broadcasts it -- the launcher's environment is not enough, a default
+    torchrun start has the same TORCHELASTIC_RUN_ID ('none'), address and port every time.  Without
+    one (or with VSG_CHAIN_NONCE set, for launchers of their own): derived from the environment."""
     import hashlib
     import os
-    key = "|".join(os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT",
-                                                    "VSG_CHAIN_NONCE"))
-    return int.from_bytes(hashlib.sha256(key.encode()).digest()[:8], "little")
+    import secrets
+    if "VSG_CHAIN_NONCE" not in os.environ:
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                box = [secrets.randbits(63) | 1 if dist.get_rank() == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                return int(box[0])
+        except ImportError:
+            pass
+    key = "|".join(os.environ.get(k, "") for k in ("VSG_CHAIN_NONCE", "TORCHELASTIC_RUN_ID", "MASTER_ADDR",
+                                                    "MASTER_PORT"))
+    return int.from_bytes(hashlib.sha256(key.encode()).digest()[:8], "little") >> 1
+
+
+import sys
 
 
 def run_chain_bench(args, rank, world, local_rank):
@@ -210,6 +226,8 @@ def run_chain_bench(args, rank, world, local_rank):
         id_file = os.path.join(tempfile.gettempdir(), "vsg_chain_%016x.id" % nonce)
         chain = vsg.ChunkChain(rank, world, id_file, nonce=nonce, device=local_rank)
         rccl_rank, rccl_world = chain.info()
+        print("[bench chain] rank %d of %d: RCCL communicator rank %d of %d on device %d" %
+              (rank, world, rccl_rank, rccl_world, local_rank), file=sys.stderr, flush=True)
         assert (rccl_rank, rccl_world) == (rank, world), (rccl_rank, rccl_world, rank, world)
         transport = ChainTransport(chain, W, H, dev)
     else:
