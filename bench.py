@@ -167,6 +167,8 @@ def time_streams(vsg, frames, flow, W, H, chunk, S, warm, steps, device_index, b
     chunk boundaries per stream, then exactly `steps` timed ones between two synchronisations.
     Every SegmentationDesc of a boundary is fetched inside the timed region."""
     import threading
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(device_index)[0]
     streams = [vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=device_index),
                                      has_flow=True) for _ in range(S)]
     torch.cuda.synchronize()
@@ -221,10 +223,44 @@ def time_streams(vsg, frames, flow, W, H, chunk, S, warm, steps, device_index, b
     run_all(steps, True)          # exactly `steps` timed boundaries per stream
     sync()
     dt = time.perf_counter() - t0
+    # what the streams hold on the device after warm-up and the timed chunks (their scratch only
+    # grows): the drop in free device memory since before they were created
+    device_bytes = max(0, free_before - torch.cuda.mem_get_info(device_index)[0]) // S
     for st_ in streams:
         st_.close()
     acc = dict((k_, sum(a[k_] for a in accs) / S) for k_ in ACC_KEYS)
-    return {"dt": dt, "frames": sum(outs), "acc": acc}
+    return {"dt": dt, "frames": sum(outs), "acc": acc, "device_bytes_per_stream": int(device_bytes)}
+
+
+def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=5):
+    """the roofline also against what a device-to-device copy reaches on this box
+    (bytes read + bytes written per second), timed with HIP events on torch's current stream."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
+def kernel_table(W, H, chunk):
+    """Per-kernel rows (name, ms per step, raw HBM GB/s, fraction of peak) of the top kernels, from
+    the committed rocprofv3 summary of this same command (tools/measure_round.sh writes
+    profiles/<round>_kernel_table.json): counters cannot be collected inside the timed process."""
+    if (W, H, chunk) != (1920, 1080, 20):
+        return None
+    for tag in ("r4",):
+        path = os.path.join(ROOT, "profiles", "%s_kernel_table.json" % tag)
+        if os.path.exists(path):
+            return json.load(open(path))
+    return None
 
 
 def stage_ms(acc, steps):
@@ -534,6 +570,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.all_reduce(fo, op=dist.ReduceOp.SUM)
         result = {"dt": float(tt.item()), "frames": float(fo.item()), "acc": r["acc"],
+                  "device_bytes_per_stream": r["device_bytes_per_stream"],
                   "parallelism": "%d independent 1080p stream(s) per GPU x %d GPU(s)" % (S, world)}
         # PCIe-inclusive leg (rank 0, one stream, not `value`): the same steady-state chunks with
         # frames and flow handed over as host buffers, so that the H2D copies are timed as well.
@@ -583,13 +620,21 @@ def main():
         # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes cannot run inside the
         # timed process, so the committed summary of the same workload is quoted (null if absent).
         traffic, traffic_note = None, "no PMC summary under profiles/"
-        pmc_path = os.path.join(ROOT, "profiles", "r3_pmc_%s.json" % dom[0])
-        if not os.path.exists(pmc_path):
-            pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_%s.json" % dom[0])
-        if os.path.exists(pmc_path) and (W, H, chunk) == (1920, 1080, 20):
+        traffic_same_run = None
+        pmc_path = None
+        for tag in ("r4", "r3", "r2"):
+            cand = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag, dom[0]))
+            if os.path.exists(cand):
+                pmc_path = cand
+                break
+        if pmc_path and (W, H, chunk) == (1920, 1080, 20):
             pmc = json.load(open(pmc_path))
             traffic = pmc["fetch_bytes_per_launch_raw"] + pmc["write_bytes_per_launch_raw"]
             traffic_note = ("FETCH_SIZE + WRITE_SIZE per launch, raw counters, from " + pmc["source"])
+            # (the counter passes are a run of their own, with their own number of launches: the
+            # algorithmic bytes per launch OF THAT RUN are what the traffic is to be held against)
+            traffic_same_run = pmc.get("algorithmic_bytes_per_launch_same_run")
+        copy_gbps = measured_copy_bandwidth(dev) if args.mode == "streams" else None
         out = {
             "metric": "over-segmented frames/sec at 1080p",
             "value": fps,
@@ -624,6 +669,13 @@ def main():
                 "traffic": traffic,
                 "traffic_unit": "B/launch",
                 "traffic_note": traffic_note,
+                "traffic_vs_algorithmic_same_run": (traffic / traffic_same_run) if (traffic and traffic_same_run)
+                else None,
+                "peak_measured": copy_gbps,
+                "peak_measured_note": "device-to-device copy of 1 GiB on this box, bytes read + written per "
+                                      "second (SURVEY 8(d))",
+                "frac_of_measured": (achieved / copy_gbps) if copy_gbps else None,
+                "kernels": kernel_table(W, H, chunk),
                 "launches": acc[dom[0] + "_launches"],
                 "avg_launch_ms": wave_avg_s * 1e3,
                 "bytes_per_launch": wave_bytes_per_launch,
@@ -633,6 +685,7 @@ def main():
                            fps / world * px * BYTES_PER_PX_FRAME / 1e9),
             },
             "stage_ms_per_step": stage_ms(acc, K),
+            "device_bytes_per_stream": result.get("device_bytes_per_stream"),
             "edges_per_step": acc["edges_total"] / K,
             "merges_per_step": acc["merges"] / K,
         }

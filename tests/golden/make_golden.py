@@ -5,7 +5,12 @@ these vectors are produced by oracle/libvs_oracle.so, which is itself pinned bit
 reference-derived values recorded in SURVEY.md App. B (tests/test_oracle_pins.py).  The vectors
 freeze the complete serialized output (every SegmentationDesc byte) for inputs that the survey's
 probe did not cover: noise, constant colour, single frame, the bench generator, L1 distance,
-no pre-smoothing, many short chunks.
+no pre-smoothing, many short chunks; and, in their own files, for the two stages on the caller side
+of the path -- the boundary vectorisation of the dense unit (vector_golden.json: every byte of
+Region2D.vectorization and vector_mesh) and the hierarchical RegionSegmentation behind it
+(hierarchy_golden.json: every hierarchy level, two and three chunk sets with overlap and
+constraints).  Both are "parity unpinned" like the oracle code they come from:
+they freeze today's bytes against regressions, they do not anchor them to the reference.
 
     python tests/golden/make_golden.py
 """
@@ -61,7 +66,66 @@ def run_case(make_stream, W, H, N, kind, flow):
     return digests, "%08x" % synth.fnv1a32_fast(planes)
 
 
+# ---- f2: dense stream with compute_vectorization ----------------------------------------------------
+VECTOR_CASES = [
+    ("vector_bench_96x64x20_c8", 96, 64, 20, "bench", True, 8, {"compute_vectorization": 1}),
+    ("vector_probe_64x48x12_c8", 64, 48, 12, "probe", False, 8, {"compute_vectorization": 1}),
+    ("vector_noise_nosmooth_48x40x9_c8", 48, 40, 9, "noise", True, 8,
+     {"compute_vectorization": 1, "presmoothing": 0}),
+]
+
+# ---- f3: hierarchical RegionSegmentation over the oracle's over-segmentation ---------------------------
+HIERARCHY_CASES = [
+    # name, W, H, N, chunk, flow, region options
+    ("hier_soft_96x64x60_c8_sets3", 96, 64, 60, 8, True,
+     dict(chunk_set_size=3, chunk_set_overlap=1, constraint_chunks=1, min_region_num=3)),
+    ("hier_soft_80x60x24_c8_noflow", 80, 60, 24, 8, False, dict(use_flow=0, min_region_num=4)),
+    ("hier_soft_96x64x30_c10_cut", 96, 64, 30, 10, True,
+     dict(chunk_set_size=2, chunk_set_overlap=1, max_region_num=20, min_region_num=3)),
+]
+
+
+def run_hierarchy_case(make_region_seg, W, H, N, chunk, flow):
+    """Dense over-segmentation by the oracle stream (soft generator: the bench checker makes the
+    reference abort), hierarchy by `make_region_seg()`; sha256 of every result."""
+    fl = synth.const_flow(W, H) if flow else None
+    o = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=flow)
+    frames = [synth.soft_frame(W, H, k) for k in range(N)]
+    seg = []
+    for k in range(N):
+        n = o.process_frame(frames[k], fl if (flow and k > 0) else None, flush=(k == N - 1))
+        seg += [o.result_bytes(i) for i in range(n)]
+    o.close()
+    r = make_region_seg()
+    digests = []
+    for k in range(N):
+        n = r.process_frame(seg[k], frames[k], fl if (flow and k > 0) else None, flush=(k == N - 1))
+        assert n >= 0
+        digests += [hashlib.sha256(r.result_bytes(i)).hexdigest() for i in range(n)]
+    r.close()
+    return digests
+
+
 def main():
+    out = {}
+    for name, W, H, N, kind, flow, chunk, extra in VECTOR_CASES:
+        opts = dict(chunk_size=chunk, **extra)
+        digests, lhash = run_case(
+            lambda: ol.OracleStream(W, H, ol.default_options(**opts), has_flow=flow), W, H, N, kind, flow)
+        out[name] = {"W": W, "H": H, "N": N, "kind": kind, "flow": flow, "chunk": chunk,
+                     "options": extra, "label_fnv1a32": lhash, "sha256_per_frame": digests}
+        print(name, lhash, len(digests))
+    with open(os.path.join(HERE, "vector_golden.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    out = {}
+    for name, W, H, N, chunk, flow, ropts in HIERARCHY_CASES:
+        digests = run_hierarchy_case(lambda: ol.OracleRegionSegmentation(W, H, ol.region_options(**ropts)),
+                                     W, H, N, chunk, flow)
+        out[name] = {"W": W, "H": H, "N": N, "chunk": chunk, "flow": flow, "region_options": ropts,
+                     "sha256_per_frame": digests}
+        print(name, len(digests))
+    with open(os.path.join(HERE, "hierarchy_golden.json"), "w") as f:
+        json.dump(out, f, indent=1)
     out = {}
     for name, W, H, N, kind, flow, chunk, extra in CASES:
         opts = dict(chunk_size=chunk, **extra)

@@ -139,3 +139,69 @@ def test_unit_tree_with_region_segmentation_unit(vsg):
         assert int(m.group(1)) == N and int(m.group(3)) == total_regions and int(m.group(5)) == nbytes
         assert int(m.group(4), 16) == synth.fnv1a32_fast(planes)
         assert int(m.group(6)) == len(m0.hierarchy) >= 2
+
+
+def test_bench_checker_through_both_stages_reports_invalid(vsg):
+    """The headline input (un-softened checker) behind the GPU dense unit: neighbouring cells have
+    disjoint Lab histograms, the reference aborts on its CHECK (region_segmentation_graph.cpp:165).
+    The product's answer is the documented one, VSG_ERR_INVALID with the diagnosis -- from the same
+    frame on which the oracle reports the abort -- and never a made-up hierarchy."""
+    from video_segment_amd._lib import VsgError, VSG_ERR_INVALID
+    W, H, N, chunk = 96, 64, 16, 8
+    fl = synth.const_flow(W, H)
+    d = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=True)
+    o = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
+    r = vsg.RegionSegmentation(W, H, vsg.default_region_options(min_region_num=3))
+    ro = ol.OracleRegionSegmentation(W, H, ol.region_options(min_region_num=3))
+    frames = [synth.bench_frame(W, H, k) for k in range(N)]
+    fed, aborted = 0, False
+    for k in range(N):
+        n = d.process_frame(frames[k], fl if k > 0 else None, flush=(k == N - 1))
+        assert n == o.process_frame(frames[k], fl if k > 0 else None, flush=(k == N - 1))
+        for i in range(n):
+            seg = d.result_bytes(i)
+            assert seg == o.result_bytes(i)
+            last = k == N - 1 and i == n - 1
+            code = ro.process_frame(seg, frames[fed], fl if fed > 0 else None, flush=last)
+            if code == -2:
+                with pytest.raises(VsgError, match="the reference aborts") as e:
+                    r.process_frame(seg, frames[fed], fl if fed > 0 else None, flush=last)
+                assert e.value.code == VSG_ERR_INVALID
+                aborted = True
+                break
+            assert r.process_frame(seg, frames[fed], fl if fed > 0 else None, flush=last) == code
+            fed += 1
+        if aborted:
+            break
+    assert aborted
+    d.close()
+    o.close()
+
+
+@pytest.mark.skipif(not os.environ.get("VSG_SLOW"), reason="minutes of CPU oracle at 3840x2160 (VSG_SLOW=1)")
+def test_config4_first_chunk_set_against_oracle(vsg):
+    """configs[4] at its own size against the oracle running BOTH stages: 3840x2160 + flow, one
+    over-segmentation chunk = one flushed chunk set, every hierarchical SegmentationDesc byte for
+    byte.  (Run by hand on a GPU box with VSG_SLOW=1; the result is recorded in DESIGN.md.)"""
+    import torch
+    W, H, N, chunk = 3840, 2160, 12, 20
+    want = oracle_pipeline(W, H, N, chunk, dict(min_region_num=5))
+    dev = torch.device("cuda", 0)
+    fl_h = synth.const_flow(W, H)
+    fl = torch.from_numpy(fl_h).to(dev)
+    frames_h = [synth.soft_frame(W, H, k) for k in range(N)]
+    d = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=True)
+    r = vsg.RegionSegmentation(W, H, vsg.default_region_options(min_region_num=5))
+    segs = []
+    for k in range(N):
+        n = d.process_frame(torch.from_numpy(frames_h[k]).to(dev), fl if k > 0 else None, flush=(k == N - 1))
+        segs += [d.result_bytes(i) for i in range(n)]
+    d.close()
+    got = []
+    for k, seg in enumerate(segs):
+        m = r.process_frame(seg, frames_h[k], fl_h if k > 0 else None, flush=(k == N - 1))
+        got += [r.result_bytes(i) for i in range(m)]
+    r.close()
+    assert len(got) == N == len(want)
+    for k in range(N):
+        assert got[k] == want[k], "hierarchical SegmentationDesc %d differs at 3840x2160" % k

@@ -44,7 +44,14 @@ def test_chain_self_check_is_silent(vsg, monkeypatch, capfd):
                                  {"VSG_SPINE_MIN": "32", "VSG_SPINE_CHECK": "1", "VSG_WINDOWS": "1",
                                   "VSG_GROUP_BUCKETS": "0"},
                                  {"VSG_SPINE_MIN": "48", "VSG_FORCE_ROLLBACK": "1"},
-                                 {"VSG_SPINE_MIN": "32", "VSG_SPINE_MAX_EDGES": "4096"}])
+                                 {"VSG_SPINE_MIN": "32", "VSG_SPINE_MAX_EDGES": "4096"},
+                                 # the streamed spine (prep / scan / chain / verify; two passes with one
+                                 # batch of k_spine between them) on every tree replay, however small
+                                 {"VSG_SPINE_MIN": "32", "VSG_SPINE_FAST_MIN": "0", "VSG_SPINE_CHECK": "1"},
+                                 {"VSG_SPINE_MIN": "64", "VSG_SPINE_FAST_MIN": "0", "VSG_SPINE_FAST": "1"},
+                                 {"VSG_SPINE_MIN": "32", "VSG_SPINE_FAST_MIN": "0", "VSG_SPINE_FAST": "3",
+                                  "VSG_WINDOWS": "1", "VSG_GROUP_BUCKETS": "0"},
+                                 {"VSG_SPINE_MIN": "48", "VSG_SPINE_FAST": "0"}])
 def test_stage_decomposition_variants(vsg, monkeypatch, env):
     """The stage driver's two decompositions are exact whatever their parameters: a bucket split
     into consecutive rank windows (each its own filter -> components -> replay), runs of equal
@@ -138,3 +145,19 @@ def test_randomised_streams_against_oracle(vsg):
     sp.one_case(np.random.default_rng([11, 30]), 30)
     for idx in range(40):
         sp.one_case(np.random.default_rng([5, idx]), idx)
+
+
+def test_randomised_streams_larger_sizes(vsg):
+    """The same differential sweep at sizes up to about 600 x 390 (components large enough for the
+    wave worker's chains, the Kruskal-tree replay and its streamed spine with the default
+    thresholds), with two_stage_oversegment in a third of the cases: presmoothing on / off, L1 / L2,
+    random / constant / no flow, chunk sizes 8 - 20.  Streams are cut to 2.5 M pixel-frames so that
+    the oracle's share stays around a second per case."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_parity as sp
+    seen = set()
+    for idx in range(44):
+        desc = sp.one_case(np.random.default_rng([2024, idx]), idx, scale=3.0, max_px_frames=2.5e6, two_stage=True)
+        seen.add((desc[4], desc[5], tuple(sorted(desc[6].items()))))
+    assert len(seen) >= 25, "the sweep is supposed to cover many option combinations"

@@ -7,7 +7,7 @@
 # MI355X_MICROARCH.md), summarised per kernel -- every kernel -- by tools/pmc_summary.py together
 # with the average launch durations of step 2.
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -22,6 +22,9 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   timeout 900 rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$N -o cc -- $CMD > "$OUT/pmc_$N.log" 2>&1
   cp /tmp/prof_$N/cc_counter_collection.csv "$OUT/cc_$N.csv" 2>/dev/null
 done
-python "$ROOT/tools/pmc_summary.py" "$OUT"/cc_*.csv --stats "$OUT/kernel_stats.csv" --wave-json "$OUT/pmc_wave.json" > "$OUT/pmc_summary.json"
+python "$ROOT/tools/pmc_summary.py" "$OUT"/cc_*.csv --stats "$OUT/kernel_stats.csv" --wave-json "$OUT/pmc_wave.json" --bench-log "$OUT/pmc_FETCH_SIZE.log" > "$OUT/pmc_summary.json"
+# 4. the compact per-kernel table bench.py embeds (4 chunk boundaries: 1 warm-up + 3 timed)
+python "$ROOT/tools/kernel_table.py" "$OUT/kernel_stats.csv" "$OUT/pmc_summary.json" 4 > "$OUT/kernel_table.json"
+python "$ROOT/tools/show_stats.py" "$OUT/kernel_stats.csv" 12
 rm -f "$OUT"/cc_*.csv      # several MB each; the summaries are what is kept
 head -c 1500 "$OUT/bench.json"

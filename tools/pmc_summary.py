@@ -7,7 +7,9 @@ statistics of the same command:
 Per kernel: launches, every counter (sum and per launch), and with --stats the average launch
 duration and the HBM rate (FETCH_SIZE + WRITE_SIZE) / duration against the 8 TB/s peak.
 --wave-json OUT writes the per-launch bytes of vsg::k_merge_wave to OUT and those of k_spine to OUT
-with "wave" replaced by "spine", in the form bench.py reads from profiles/r3_pmc_{wave,spine}.json.
+with "wave" replaced by "spine", in the form bench.py reads from profiles/r4_pmc_{wave,spine}.json;
+--bench-log LOG: the output of the counter pass (bench.py's own JSON line), whose algorithmic bytes
+per launch are stored next to the counters of that same run.
 
 FETCH_SIZE / WRITE_SIZE are in KB (rocprofv3 derived metrics), raw: on gfx950 FETCH_SIZE counts a
 wide (16 B/lane) streaming read at half its bytes (MI355X_MICROARCH.md), other widths are
@@ -49,11 +51,14 @@ def main():
     out = {}
     argv = sys.argv[1:]
     wave_json = stats = None
-    for flag in ("--wave-json", "--stats"):
+    bench_log = None
+    for flag in ("--wave-json", "--stats", "--bench-log"):
         if flag in argv:
             i = argv.index(flag)
             if flag == "--wave-json":
                 wave_json = argv[i + 1]
+            elif flag == "--bench-log":
+                bench_log = argv[i + 1]
             else:
                 stats = argv[i + 1]
             del argv[i:i + 2]
@@ -88,6 +93,15 @@ def main():
     rows = sorted(out.items(), key=lambda kv: -kv[1].get("total_ms", sum(
         v for k, v in kv[1].items() if k.endswith("_sum"))))
     print(json.dumps(dict(rows), indent=1))
+    # The bench line the counter pass itself printed: its algorithmic bytes per launch are the ones
+    # the pass's traffic is to be compared with (another run has another number of launches).
+    same_run = {}
+    if bench_log:
+        for line in open(bench_log, errors="replace"):
+            if line.startswith("{") and '"roofline"' in line:
+                r = json.loads(line)["roofline"]
+                tag = "spine" if "k_spine" in r["kernel"] else "wave"
+                same_run[tag] = r["bytes_per_launch"]
     if wave_json:
         for name, e in out.items():
             for kern, tag in (("k_merge_wave", "wave"), ("k_spine", "spine")):
@@ -97,6 +111,7 @@ def main():
                     "kernel": name, "launches": e["launches"],
                     "fetch_bytes_per_launch_raw": e.get("FETCH_SIZE_KB_per_launch", 0.0) * 1e3,
                     "write_bytes_per_launch_raw": e.get("WRITE_SIZE_KB_per_launch", 0.0) * 1e3,
+                    "algorithmic_bytes_per_launch_same_run": same_run.get(tag),
                     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
                               "'bench.py --no-cpu-baseline --no-pcie-leg --no-extras', tools/measure_round.sh; "
                               "raw counters (gfx950: FETCH_SIZE may under-count wide streaming "

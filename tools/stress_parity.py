@@ -43,12 +43,18 @@ def make_frame(rng, W, H, kind, k):
     return synth.bench_frame(W, H, k)
 
 
-def one_case(rng, idx):
-    scale = float(os.environ.get("STRESS_SCALE", "1"))
+def one_case(rng, idx, scale=None, max_px_frames=None, two_stage=False):
+    """scale: sizes up to 200 x 130 times this; max_px_frames: the stream is cut to this many
+    pixel-frames (the CPU oracle does about 3 M per second); two_stage: a third of the cases run
+    with two_stage_oversegment."""
+    if scale is None:
+        scale = float(os.environ.get("STRESS_SCALE", "1"))
     W = int(rng.integers(24, int(200 * scale)))
     H = int(rng.integers(16, int(130 * scale)))
     chunk = int(rng.choice([8, 9, 10, 13, 20]))
     N = int(rng.integers(1, 3 * chunk + 3))
+    if max_px_frames:
+        N = max(1, min(N, int(max_px_frames // (W * H))))
     kind = str(rng.choice(["noise", "smooth", "blocks", "twotone", "bench"]))
     flow_kind = str(rng.choice(["none", "const", "random"]))
     has_flow = flow_kind != "none"
@@ -60,6 +66,8 @@ def one_case(rng, idx):
             extra["presmoothing"] = 0          # unfiltered features: many failed tests, finalized regions
         if orng.random() < 0.25:
             extra["color_distance"] = 0        # L1
+        if two_stage and orng.random() < 0.34:
+            extra["two_stage_oversegment"] = 1
     go = vsg.default_options(chunk_size=chunk, **extra)
     oo = ol.default_options(chunk_size=chunk, **extra)
     gs = vsg.DenseSegmentation(W, H, go, has_flow=has_flow)

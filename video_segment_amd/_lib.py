@@ -13,6 +13,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "lib", "libvsg_hip.so")
 
 VSG_OK = 0
+VSG_ERR_INVALID, VSG_ERR_DEVICE, VSG_ERR_STATE, VSG_ERR_INTERNAL = -1, -2, -3, -4   # include/vsg.h
 VSG_MEM_HOST = 0
 VSG_MEM_DEVICE = 1
 
@@ -182,9 +183,13 @@ def lib():
 
 
 class VsgError(RuntimeError):
-    pass
+    """A negative status of the C ABI; `code` is the status (VSG_ERR_*)."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 def check(rc):
     if rc != VSG_OK:
-        raise VsgError("vsg error %d: %s" % (rc, lib().vsg_last_error().decode()))
+        raise VsgError("vsg error %d: %s" % (rc, lib().vsg_last_error().decode()), rc)
