@@ -456,6 +456,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.spine_nested_factor = getenv("VSG_SPINE_NESTED") ? std::max(1, atoi(getenv("VSG_SPINE_NESTED"))) : 2;
   S.spine_debug = getenv("VSG_SPINE_DEBUG") ? 1 : 0;
   S.spine_check = getenv("VSG_SPINE_CHECK") ? 1 : 0;
+  S.rank_split_min = getenv("VSG_RANK_SPLIT_MIN") ? atoi(getenv("VSG_RANK_SPLIT_MIN")) : (1 << 20);
   S.spine_fast = getenv("VSG_SPINE_FAST") ? atoi(getenv("VSG_SPINE_FAST")) : 2;   // streamed passes
   S.spine_fast_min = getenv("VSG_SPINE_FAST_MIN") ? atoi(getenv("VSG_SPINE_FAST_MIN")) : 32768;
   if (S.spine_min > 0) {
@@ -1119,14 +1120,16 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
   const int nf = (int)frames.size();
   small_i32_a_.ensure((size_t)std::max(nf, 1));
   H2D(small_i32_a_.get(), frames.data(), (size_t)nf, stream_);
-  if (enforce_n4) {
-    LaunchEnforceN4(label_img_.get(), W_, H_, small_i32_a_.get(), nf, adjust_.get(), stream_);
-  }
-
-  // 3. run-length intervals in (slice, y, x) order.
   const int rows = nf * H_;
   row_counts_.ensure((size_t)rows + 1);
   row_offsets_.ensure((size_t)rows + 1);
+  if (enforce_n4 && nf > 0) {
+    // (the row flags of the sweep live in the array the run counts of step 3 are written to next)
+    VSG_HIP(hipMemsetAsync(row_counts_.get(), 0, (size_t)rows * sizeof(int32_t), stream_));
+    LaunchEnforceN4(label_img_.get(), W_, H_, small_i32_a_.get(), nf, row_counts_.get(), adjust_.get(), stream_);
+  }
+
+  // 3. run-length intervals in (slice, y, x) order.
   for (int i = 0; i < nf; ++i) {
     LaunchRowRunCounts(label_img_.get(), W_, H_, frames[i], row_counts_.get() + (size_t)i * H_,
                        stream_);

@@ -202,6 +202,7 @@ struct MergeScratch {
   int spine_nested_factor;   // side clusters go one level down from spine_min * this many edges
   int spine_max_edges;   // at most this many edges per stage (scratch pool)
   int spine_debug, spine_check;
+  int rank_split_min;    // Euler tours of at least this many arcs are ranked by sampling (k_rank_walk)
   int spine_fast;        // the plain steps of a spine through the streamed chain (k_spine_chain)
   int spine_fast_min;    // ... from this many tree edges on (seven more launches)
   int32_t* spine_pool;   // scratch, SpinePoolInts(spine_max_edges) ints
@@ -268,7 +269,8 @@ void LaunchFlatten(NodeArrays nodes, size_t n, int32_t* label_uf, hipStream_t s)
 // N4 sweep on the listed slices of label_img (one workgroup per slice); adjust[key] receives the
 // per-region size change.
 void LaunchEnforceN4(int32_t* label_img, int W, int H, const int32_t* frames_dev, int num_frames,
-                     int32_t* adjust /* [N] */, hipStream_t s);
+                     int32_t* row_flags /* [num_frames * H] scratch, zeroed */, int32_t* adjust /* [N] */,
+                     hipStream_t s);
 // Run-length encoding of one slice: counts per row, then intervals.
 void LaunchRowRunCounts(const int32_t* label_img, int W, int H, int frame, int32_t* row_counts,
                         hipStream_t s);

@@ -39,10 +39,38 @@ void LaunchFlatten(NodeArrays nodes, size_t n, int32_t* label_uf, hipStream_t s)
 // rows; inside a row all columns are evaluated in parallel from the previous iterate and
 // re-evaluated until nothing changes.  The system is triangular (column j only depends on
 // column j-1), so the fixed point is unique and equals the sequential result.
+//
+// Rewrites are rare (a pixel that hangs on its region by a diagonal only), and a row whose upper
+// row was not rewritten and in which no pixel changes when evaluated on the original values stays
+// as it is -- so k_n4_row_flags first marks, for all rows of all slices at once, the rows in which
+// something would change given the ORIGINAL upper row, and the sweep only works on those rows and
+// on the rows below a rewritten one; everything else it skips without touching the image (the
+// sweep over all 1079 row pairs of a 1080p slice was 2.2 ms per chunk, one workgroup per slice).
 constexpr int kN4Threads = 1024;
+
+__global__ __launch_bounds__(256) void k_n4_row_flags(const int32_t* __restrict__ label_img, int W, int H,
+                                                       const int32_t* __restrict__ frames,
+                                                       int32_t* __restrict__ row_flags /* [slices][H] */) {
+  const int i = blockIdx.x;       // upper row; the flag belongs to row i + 1
+  const int32_t* img = label_img + (size_t)frames[blockIdx.y] * W * H;
+  const int32_t* cur = img + (size_t)i * W;
+  const int32_t* bel = cur + W;
+  int changed = 0;
+  for (int j = threadIdx.x; j < W; j += 256) {
+    const int id = cur[j];
+    const int left = (j > 0) ? cur[j - 1] : -1;
+    const int right = (j < W - 1) ? cur[j + 1] : -1;
+    const int bl = (j > 0) ? bel[j - 1] : -1;
+    const int br = (j < W - 1) ? bel[j + 1] : -1;
+    const int v = bel[j];
+    changed |= (bl == id && left != id && v != id) || (br == id && right != id && v != id);
+  }
+  if (__syncthreads_or(changed) && threadIdx.x == 0) row_flags[(size_t)blockIdx.y * H + i + 1] = 1;
+}
 
 __global__ __launch_bounds__(kN4Threads) void k_enforce_n4(int32_t* __restrict__ label_img, int W,
                                                             int H, const int32_t* __restrict__ frames,
+                                                            const int32_t* __restrict__ row_flags,
                                                             int32_t* __restrict__ adjust) {
   extern __shared__ int32_t srow[];   // cur[W], bel[W], it0[W], it1[W]
   int32_t* cur = srow;
@@ -51,11 +79,17 @@ __global__ __launch_bounds__(kN4Threads) void k_enforce_n4(int32_t* __restrict__
   int32_t* xb = srow + 3 * W;
   const int tid = threadIdx.x;
   int32_t* img = label_img + (size_t)frames[blockIdx.x] * W * H;
-  for (int j = tid; j < W; j += kN4Threads) cur[j] = img[j];
-  __syncthreads();
+  const int32_t* flags = row_flags + (size_t)blockIdx.x * H;
+  bool have_cur = false;      // cur[] holds the (final) row i
+  bool prev_rewritten = false;
   for (int i = 0; i < H - 1; ++i) {
+    if (!prev_rewritten && !flags[i + 1]) {   // (uniform) nothing can change in row i + 1
+      have_cur = false;
+      continue;
+    }
     int32_t* below = img + (size_t)(i + 1) * W;
     for (int j = tid; j < W; j += kN4Threads) {
+      if (!have_cur) cur[j] = img[(size_t)i * W + j];
       const int v = below[j];
       bel[j] = v;
       xa[j] = v;
@@ -83,6 +117,7 @@ __global__ __launch_bounds__(kN4Threads) void k_enforce_n4(int32_t* __restrict__
       x_new = t;
       if (!any) break;
     }
+    int rewritten = 0;
     for (int j = tid; j < W; j += kN4Threads) {
       const int v = x_old[j];
       const int o = bel[j];
@@ -90,18 +125,22 @@ __global__ __launch_bounds__(kN4Threads) void k_enforce_n4(int32_t* __restrict__
         below[j] = v;
         atomicSub(&adjust[o], 1);
         atomicAdd(&adjust[v], 1);
+        rewritten = 1;
       }
       cur[j] = v;
     }
-    __syncthreads();
+    prev_rewritten = __syncthreads_or(rewritten) != 0;
+    have_cur = true;
   }
 }
 
 void LaunchEnforceN4(int32_t* label_img, int W, int H, const int32_t* frames_dev, int num_frames,
-                     int32_t* adjust, hipStream_t s) {
-  if (num_frames <= 0) return;
+                     int32_t* row_flags /* [num_frames * H], zeroed */, int32_t* adjust, hipStream_t s) {
+  if (num_frames <= 0 || H < 2) return;
+  hipLaunchKernelGGL(k_n4_row_flags, dim3(H - 1, num_frames), dim3(256), 0, s, label_img, W, H, frames_dev,
+                     row_flags);
   hipLaunchKernelGGL(k_enforce_n4, dim3(num_frames), dim3(kN4Threads),
-                     (size_t)4 * W * sizeof(int32_t), s, label_img, W, H, frames_dev, adjust);
+                     (size_t)4 * W * sizeof(int32_t), s, label_img, W, H, frames_dev, row_flags, adjust);
   VSG_HIP(hipGetLastError());
 }
 
