@@ -572,6 +572,29 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   // window tells which case it is: average component size below `bushy` -> keep splitting.
   S.bucket_prefix = bucket_prefix_dev_.get();
   S.bucket_prefix_host = bucket_prefix.data();
+  {
+    // start of every bucket inside every list's sorted slots (= the list's offsets array), from the
+    // host copy of the bucket table
+    list_off_host_.assign((size_t)L * (kNumBuckets + 2), 0);
+    for (int l = 0; l < L; ++l) {
+      int32_t* off = list_off_host_.data() + (size_t)l * (kNumBuckets + 2);
+      int acc_l = 0;
+      for (int b = 0; b <= kNumBuckets; ++b) {
+        off[b] = acc_l;
+        const int32_t* row = bucket_base_host_.data() + (size_t)b * (L + 1);
+        acc_l += row[l + 1] - row[l];
+      }
+      off[kNumBuckets + 1] = acc_l;
+    }
+    const size_t cap = (size_t)3 * 65536;
+    if (seg_table_dev_.size() < cap) seg_table_dev_.alloc(cap);
+    S.bucket_base_host = getenv("VSG_FILTER_SEGS") && atoi(getenv("VSG_FILTER_SEGS")) == 0 ? nullptr
+                                                                                          : bucket_base_host_.data();
+    S.list_off_host = list_off_host_.data();
+    S.seg_dev = seg_table_dev_.get();
+    S.seg_cap = seg_table_dev_.size();
+    S.seg_host = &seg_table_host_;
+  }
   if (++window_target_age_ > 8) {
     window_target_age_ = 0;
     for (auto& t : window_target_) {

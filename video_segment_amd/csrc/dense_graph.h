@@ -154,6 +154,8 @@ class DenseGraphHip {
   DevBuf<int32_t> bk_cons_;
   int64_t optimistic_stages_ = 0, rollbacks_ = 0;
   DevBuf<int32_t> scalars_;   // num_active, num_segs, misc
+  DevBuf<int32_t> seg_table_dev_;   // k_filter: the segments of the current stage
+  std::vector<int32_t> seg_table_host_, list_off_host_;
   Mailbox mail_;              // host-visible scalars (device_graph.h); mapped host memory
   void* mail_mem_ = nullptr;
   DevBuf<int32_t> zero_pool_mem_;

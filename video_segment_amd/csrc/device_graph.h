@@ -158,6 +158,14 @@ struct FilterMasks {
   unsigned long long* tentative;   // settled under an assumption (inert_mode 2)
   int32_t* block_cnt;
 };
+// The non-empty (bucket, list) segments of a stage's edge range (k_filter): start inside the stage,
+// list index, position of the segment's first edge in the list's sorted slots.
+struct FilterSegs {
+  const int32_t* start;
+  const int32_t* list;
+  const int32_t* pos0;
+  int n;
+};
 struct MergeScratch {
   // sized for the largest bucket (n_max edges)
   int32_t* e_ra;         // root of node a at filter time (per bucket edge)
@@ -193,6 +201,11 @@ struct MergeScratch {
   int group_hi;
   const int32_t* bucket_prefix;
   const int32_t* bucket_prefix_host;   // the same table on the host
+  const int32_t* bucket_base_host;     // host copy of the bucket table [(kNumBuckets + 1) x (L + 1)]
+  const int32_t* list_off_host;        // [L][kNumBuckets + 2]: start of every bucket in every list's slots
+  int32_t* seg_dev;                    // device buffer of the stage's segment table (FilterSegs)
+  size_t seg_cap;                      // ... its capacity in ints
+  std::vector<int32_t>* seg_host;      // staging
   // Kruskal-tree replay of the large components (merge_spine.hip)
   int spine_min;         // components of at least this many replayed edges; 0: never
   int spine_off;             // the current stage is a replay without the tree replay

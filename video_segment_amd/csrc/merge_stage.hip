@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <vector>
 
 #include "merge_common.h"
 
@@ -158,29 +159,67 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
                                                  int32_t* __restrict__ e_rb,
                                                  uint32_t* __restrict__ e_gpos,
                                                  FilterMasks M,
-                                                 int32_t* __restrict__ num_ti) {
+                                                 int32_t* __restrict__ num_ti, FilterSegs segs) {
   __shared__ int wave_cnt[4], wave_kept[4];
+  __shared__ int s_start[257], s_list[256], s_pos0[256];
   const int j = blockIdx.x * 256 + threadIdx.x;   // index inside the stage's window
+  // Where edge j lives: the host lists the stage's non-empty (bucket, list) segments (start inside
+  // the stage, list, position of the segment's first edge in the list's sorted slots).  A
+  // workgroup's 256 edges touch at most 256 of them, found by the workgroup together and kept in
+  // LDS -- the two binary searches per thread over tables in global memory (up to fifteen
+  // dependent loads before the first byte of the edge itself) made the kernel latency bound.
+  int m_segs = 0;
+  if (segs.start) {
+    const int jf = blockIdx.x * 256;
+    int first = 0;
+    if (segs.n > 256) {   // the last segment that starts at or before the workgroup's first edge
+      const int stride = (segs.n + 255) / 256;
+      const int t1 = threadIdx.x * stride;
+      const int c1 = __syncthreads_count(t1 < segs.n && segs.start[t1] <= jf);
+      const int base = (c1 - 1) * stride;
+      const int t2 = base + threadIdx.x;
+      const int c2 = __syncthreads_count(threadIdx.x < stride && t2 < segs.n && segs.start[t2] <= jf);
+      first = base + c2 - 1;
+    }
+    m_segs = min(256, segs.n - first);
+    if (threadIdx.x < m_segs) {
+      s_start[threadIdx.x] = segs.start[first + threadIdx.x];
+      s_list[threadIdx.x] = segs.list[first + threadIdx.x];
+      s_pos0[threadIdx.x] = segs.pos0[first + threadIdx.x];
+    }
+    __syncthreads();
+  }
   int ti = 0, active = 0, settled = 0;
   int ra = 0, rb = 0;
   uint32_t gpos = 0;
   if (j < n_b) {
-    int bk = bucket;
-    int jb = j0 + j;                               // index inside the bucket
-    if (bucket_hi > bucket + 1) {                  // several buckets: the last b with prefix[b] <= position
-      const int jg = bucket_prefix[bucket] + jb;
-      int lo = bucket, hi = bucket_hi;
+    int l, pos;
+    if (segs.start) {
+      int lo = 0, hi = m_segs;   // the last loaded segment with start <= j
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (bucket_prefix[mid] <= jg) lo = mid; else hi = mid;
+        if (s_start[mid] <= j) lo = mid; else hi = mid;
       }
-      bk = lo;
-      jb = jg - bucket_prefix[bk];
+      l = s_list[lo];
+      pos = s_pos0[lo] + (j - s_start[lo]);
+    } else {
+      int bk = bucket;
+      int jb = j0 + j;                               // index inside the bucket
+      if (bucket_hi > bucket + 1) {                  // several buckets: the last b with prefix[b] <= position
+        const int jg = bucket_prefix[bucket] + jb;
+        int lo = bucket, hi = bucket_hi;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (bucket_prefix[mid] <= jg) lo = mid; else hi = mid;
+        }
+        bk = lo;
+        jb = jg - bucket_prefix[bk];
+      }
+      const int32_t* base_row = bucket_base + (size_t)bk * (P.num_lists + 1);
+      l = LocateList(base_row, P.num_lists, jb);
+      pos = lists[l].offsets[bk] + (jb - base_row[l]);
     }
-    const int32_t* base_row = bucket_base + (size_t)bk * (P.num_lists + 1);
-    const int l = LocateList(base_row, P.num_lists, jb);
     const ListDesc L = lists[l];
-    const int pos = L.offsets[bk] + (jb - base_row[l]);
     int a, b;
     DecodeEdge(L, L.slots[pos], P.W, a, b);
     ra = FindCompress(nodes.parent, a);
@@ -577,11 +616,48 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   int32_t* d_num_ti = TakeZeroed(S, 2);   // fresh counters per stage: nothing to clear
   int32_t* d_violation = d_num_ti + 1;
   int32_t* d_num_leaders = S.num_active + 5;
+  // The stage's non-empty (bucket, list) segments, from the host copy of the bucket table.
+  FilterSegs segs = {nullptr, nullptr, nullptr, 0};
+  if (S.bucket_base_host && S.list_off_host && S.seg_dev) {
+    const int L = P.num_lists;
+    std::vector<int32_t>& h = *S.seg_host;
+    h.clear();
+    const int64_t g0 = (int64_t)S.bucket_prefix_host[bucket] + j0, g1 = g0 + n_b;
+    std::vector<int32_t> st, li, po;
+    for (int b = bucket; b < bucket_hi; ++b) {
+      const int32_t* row = S.bucket_base_host + (size_t)b * (L + 1);
+      const int64_t bstart = S.bucket_prefix_host[b];
+      if (bstart + row[L] <= g0) continue;
+      if (bstart >= g1) break;
+      for (int l = 0; l < L; ++l) {
+        const int cnt = row[l + 1] - row[l];
+        if (cnt == 0) continue;
+        const int64_t s0 = bstart + row[l], s1 = s0 + cnt;
+        if (s1 <= g0 || s0 >= g1) continue;
+        const int64_t first = std::max(s0, g0);
+        st.push_back((int32_t)(first - g0));
+        li.push_back(l);
+        po.push_back(S.list_off_host[(size_t)l * (kNumBuckets + 2) + b] + (int32_t)(first - s0));
+      }
+    }
+    const int nseg = (int)st.size();
+    if (nseg > 0 && nseg <= 65536 && (size_t)3 * nseg <= S.seg_cap) {
+      h.reserve((size_t)3 * nseg);
+      h.insert(h.end(), st.begin(), st.end());
+      h.insert(h.end(), li.begin(), li.end());
+      h.insert(h.end(), po.begin(), po.end());
+      VSG_HIP(hipMemcpyAsync(S.seg_dev, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      segs.start = S.seg_dev;
+      segs.list = S.seg_dev + nseg;
+      segs.pos0 = S.seg_dev + 2 * (size_t)nseg;
+      segs.n = nseg;
+    }
+  }
   const int ef0 = NextEvent(S);
   if (ef0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ef0], s));
   hipLaunchKernelGGL(k_filter, dim3(Blocks(n_b)), dim3(256), 0, s, bucket, bucket_hi, j0, n_b, lists,
                      bucket_base, S.bucket_prefix, list_slot_base, kept_all, nodes, P, inert_mode, S.cc, S.e_ra, S.e_rb, S.e_gpos,
-                     S.masks, d_num_ti);
+                     S.masks, d_num_ti, segs);
   const int ef1 = NextEvent(S);
   if (ef1 >= 0) {
     VSG_HIP(hipEventRecord((*S.ev_pool)[ef1], s));
