@@ -162,6 +162,12 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
                                                  int32_t* __restrict__ num_ti, FilterSegs segs) {
   __shared__ int wave_cnt[4], wave_kept[4];
   __shared__ int s_start[257], s_list[256], s_pos0[256];
+  // ... with what the edges of a segment need from its list (a 48-byte descriptor per thread
+  // otherwise: six loads of the 22 a wavefront issued)
+  __shared__ const uint32_t* s_slots[256];
+  __shared__ const int32_t* s_prev[256];
+  __shared__ int s_type[256], s_base_a[256], s_base_b[256];
+  __shared__ uint32_t s_slot_base[256];
   const int j = blockIdx.x * 256 + threadIdx.x;   // index inside the stage's window
   // Where edge j lives: the host lists the stage's non-empty (bucket, list) segments (start inside
   // the stage, list, position of the segment's first edge in the list's sorted slots).  A
@@ -184,8 +190,16 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
     m_segs = min(256, segs.n - first);
     if (threadIdx.x < m_segs) {
       s_start[threadIdx.x] = segs.start[first + threadIdx.x];
-      s_list[threadIdx.x] = segs.list[first + threadIdx.x];
+      const int l = segs.list[first + threadIdx.x];
+      s_list[threadIdx.x] = l;
       s_pos0[threadIdx.x] = segs.pos0[first + threadIdx.x];
+      const ListDesc L = lists[l];
+      s_slots[threadIdx.x] = L.slots;
+      s_prev[threadIdx.x] = L.prev_idx;
+      s_type[threadIdx.x] = L.type;
+      s_base_a[threadIdx.x] = L.base_a;
+      s_base_b[threadIdx.x] = L.base_b;
+      s_slot_base[threadIdx.x] = list_slot_base[l];
     }
     __syncthreads();
   }
@@ -194,6 +208,7 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
   uint32_t gpos = 0;
   if (j < n_b) {
     int l, pos;
+    int a, b, l_type;
     if (segs.start) {
       int lo = 0, hi = m_segs;   // the last loaded segment with start <= j
       while (hi - lo > 1) {
@@ -202,6 +217,14 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
       }
       l = s_list[lo];
       pos = s_pos0[lo] + (j - s_start[lo]);
+      ListDesc L;
+      L.slots = s_slots[lo];
+      L.prev_idx = s_prev[lo];
+      L.type = l_type = s_type[lo];
+      L.base_a = s_base_a[lo];
+      L.base_b = s_base_b[lo];
+      DecodeEdge(L, L.slots[pos], P.W, a, b);
+      gpos = s_slot_base[lo] + (uint32_t)pos;
     } else {
       int bk = bucket;
       int jb = j0 + j;                               // index inside the bucket
@@ -218,14 +241,14 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
       const int32_t* base_row = bucket_base + (size_t)bk * (P.num_lists + 1);
       l = LocateList(base_row, P.num_lists, jb);
       pos = lists[l].offsets[bk] + (jb - base_row[l]);
+      const ListDesc L = lists[l];
+      l_type = L.type;
+      DecodeEdge(L, L.slots[pos], P.W, a, b);
+      gpos = list_slot_base[l] + (uint32_t)pos;
     }
-    const ListDesc L = lists[l];
-    int a, b;
-    DecodeEdge(L, L.slots[pos], P.W, a, b);
     ra = FindCompress(nodes.parent, a);
     rb = FindCompress(nodes.parent, b);
-    gpos = list_slot_base[l] + (uint32_t)pos;
-    const bool gone = P.spatial_survivors && L.type == 0 && !P.spatial_survivors[gpos];
+    const bool gone = P.spatial_survivors && l_type == 0 && !P.spatial_survivors[gpos];
     if (ra != rb && !gone) {
       bool inert = false;
       if (inert_mode != 0) {
