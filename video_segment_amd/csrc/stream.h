@@ -140,6 +140,7 @@ class DenseSegmentationHip {
   DevBuf<uint8_t> staging_bgr_;
   DevBuf<float> staging_flow_;
   DevBuf<int32_t> halo_ids_dev_[2];
+  int32_t* halo_ids_host_ = nullptr;   // pinned staging of the two planes
   bool halo_valid_ = false;
   // pending import (multi-GPU chunk chain)
   bool pending_import_ = false;
