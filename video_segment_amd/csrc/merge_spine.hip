@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void k_spine_gather(int mE, int K, const int32
 // best[c] holds the smallest rank among the edges that leave component c, stamped with the round
 // ((31 - round) << 27 | rank, unsigned): a later round's entry is smaller than anything an
 // earlier round left behind, so the table never has to be cleared.
+constexpr int kAliveSlots = 64;   // counters of the live edges of a round, one cache line apart
 __device__ __forceinline__ uint32_t BorKey(int round, int e) { return ((uint32_t)(31 - round) << 27) | (uint32_t)e; }
 
 // The kernels of a round run over all edges (list == null) or over the list of the edges that were
@@ -128,8 +129,11 @@ __global__ __launch_bounds__(256) void k_bor_min(int n, const int32_t* __restric
     if (!(has_prev && (cu == pu || cu == pv)) && key < best[cu]) atomicMin(&best[cu], key);
     if (!(has_prev && (cv == pu || cv == pv)) && key < best[cv]) atomicMin(&best[cv], key);
   }
-  const unsigned long long m = __ballot(live);
-  if (m && (threadIdx.x & 63) == 0) atomicAdd(alive, (int)__popcll(m));
+  // One addition per workgroup, spread over kAliveSlots cache lines: an atomic per wavefront on ONE
+  // word was the kernel's bottleneck (625 K same-address atomics for 40 M edges: 3 ms a round,
+  // whatever the tables cost).
+  const int cnt = __syncthreads_count(live);
+  if (cnt && threadIdx.x == 0) atomicAdd(&alive[(blockIdx.x % kAliveSlots) * 16], cnt);
 }
 
 // The edges that are the minimum of one of their two components join them (tree edges); the first
@@ -143,7 +147,11 @@ __global__ __launch_bounds__(256) void k_bor_hook(int n, const int32_t* __restri
                                                    const int32_t* __restrict__ alive,
                                                    unsigned long long* __restrict__ mail, unsigned mail_seq) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) MailPost(mail, mail_seq, 0, *alive);
+  if (blockIdx.x == 0) {   // (k_bor_min is complete: its counters are final)
+    int v = threadIdx.x < kAliveSlots ? alive[threadIdx.x * 16] : 0;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (threadIdx.x == 0) MailPost(mail, mail_seq, 0, v);
+  }
   if (list_len) n = min(n, *list_len);
   if (i >= n) return;
   const int e = list ? list[i] : i;
@@ -1075,27 +1083,44 @@ __global__ __launch_bounds__(256) void k_spine_verify(int K, const int32_t* __re
   if (bad >= 0) atomicMin(&F.fail[k], bad);
 }
 
+constexpr int kCommitPer = 4;
 __global__ __launch_bounds__(256) void k_spine_commit(int mt, int K, const int32_t* __restrict__ comp_spine,
                                                        const int32_t* __restrict__ root_vertex, NodeArrays nodes,
                                                        SpineFastArrays F, unsigned long long* __restrict__ stats) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  bool forced = false, small = false, regular = false;
-  if (i < mt && i < comp_spine[K]) {
-    const int k = CompOf(comp_spine, K, i);
-    const int local = i - comp_spine[k];
-    if (local >= F.start_pos[k] && local < min(F.stop[k], F.fail[k])) {
-      nodes.parent[F.p[i]] = root_vertex[k];
-      const int meta = F.meta[i];
-      forced = (meta & 1) != 0;
-      small = !forced && (meta & 4);
-      regular = !forced && !small;
+  __shared__ int red[3][4];
+  int forced = 0, small = 0, regular = 0;
+  const int mS = comp_spine[K];
+#pragma unroll
+  for (int q = 0; q < kCommitPer; ++q) {
+    const int i = (blockIdx.x * kCommitPer + q) * 256 + threadIdx.x;
+    if (i < mt && i < mS) {
+      const int k = CompOf(comp_spine, K, i);
+      const int local = i - comp_spine[k];
+      if (local >= F.start_pos[k] && local < min(F.stop[k], F.fail[k])) {
+        nodes.parent[F.p[i]] = root_vertex[k];
+        const int meta = F.meta[i];
+        const bool f = (meta & 1) != 0, sm = !f && (meta & 4);
+        forced += f;
+        small += sm;
+        regular += !f && !sm;
+      }
     }
   }
-  const unsigned long long mf = __ballot(forced), ms = __ballot(small), mr = __ballot(regular);
+  // (one set of additions per workgroup: the three counters are single words)
+  for (int off = 32; off > 0; off >>= 1) {
+    forced += __shfl_down(forced, off);
+    small += __shfl_down(small, off);
+    regular += __shfl_down(regular, off);
+  }
   if ((threadIdx.x & 63) == 0) {
-    if (mf) atomicAdd(&stats[0], (unsigned long long)__popcll(mf));
-    if (mr) atomicAdd(&stats[1], (unsigned long long)__popcll(mr));
-    if (ms) atomicAdd(&stats[2], (unsigned long long)__popcll(ms));
+    red[0][threadIdx.x >> 6] = forced;
+    red[1][threadIdx.x >> 6] = regular;
+    red[2][threadIdx.x >> 6] = small;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    if (v) atomicAdd(&stats[threadIdx.x], (unsigned long long)v);
   }
 }
 
@@ -1372,7 +1397,7 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
     for (int round = 0;; ++round) {
       dbg_rounds = round;
       VSG_REQUIRE(round < 32, -4, "spine: the spanning forest did not converge");
-      int32_t* d_ctr = TakeZeroed(S, 2);   // [0] edges alive in this round, [1] length of the next list
+      int32_t* d_ctr = TakeZeroed(S, 16 * kAliveSlots + 4);   // edges alive in this round (spread), then the length of the next list
       // ecu / ecv (the components of the round) live in the side_key / spine_flag arrays, which are
       // only written once the forest is done
       hipLaunchKernelGGL(k_bor_min, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, list_len, round, eu, ev,
@@ -1399,9 +1424,9 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
         if (lists[0]) {
           // (at most `alive` edges are left: the ones this round hooked are gone as well)
           hipLaunchKernelGGL(k_bor_compact, dim3(Blocks(((size_t)n_list + kBorCompactPer - 1) / kBorCompactPer)),
-                             dim3(256), 0, s, n_list, list, list_len, estate, lists[which], d_ctr + 1);
+                             dim3(256), 0, s, n_list, list, list_len, estate, lists[which], d_ctr + 16 * kAliveSlots);
           list = lists[which];
-          list_len = d_ctr + 1;
+          list_len = d_ctr + 16 * kAliveSlots;
           which ^= 1;
           n_list = alive;
         }
@@ -1625,7 +1650,7 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
                            wa.nodes, F);
         hipLaunchKernelGGL(k_spine_verify, dim3(Blocks((size_t)F.ck_stride)), dim3(256), 0, s, K, comp_spine,
                            root_vertex, wa.nodes, wa.T, F);
-        hipLaunchKernelGGL(k_spine_commit, dim3(Blocks(mt)), dim3(256), 0, s, mt, K, comp_spine, root_vertex,
+        hipLaunchKernelGGL(k_spine_commit, dim3(Blocks(((size_t)mt + kCommitPer - 1) / kCommitPer)), dim3(256), 0, s, mt, K, comp_spine, root_vertex,
                            wa.nodes, F, wa.stats);
         hipLaunchKernelGGL(k_spine_finish, dim3((K + 63) / 64), dim3(64), 0, s, K, comp_spine, root_vertex,
                            wa.nodes, wa.T, F, wa.stats);

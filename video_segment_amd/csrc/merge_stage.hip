@@ -935,7 +935,7 @@ __global__ __launch_bounds__(256) void k_max_segment(int max_segs, const int32_t
     if (v >= below) v = 0;
   }
   for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(out, v);
+  if ((threadIdx.x & 63) == 0 && v > *out) atomicMax(out, v);   // (a stale read only costs an atomic)
 }
 
 __global__ __launch_bounds__(256) void k_keep_virtual_bucket(const ListDesc* __restrict__ lists,
