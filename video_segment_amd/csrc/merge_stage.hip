@@ -299,7 +299,9 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
     M.tentative[gw] = mt;
     wave_cnt[w] = (int)__popcll(ma);
     wave_kept[w] = (int)__popcll(ma | ms);
-    if (mt != 0) atomicAdd(num_ti, (int)__popcll(mt));
+    // (only "any" is read back; an atomic per wavefront on this one word would serialise the
+    // kernel wherever constrained regions meet)
+    if (mt != 0 && *num_ti == 0) *num_ti = 1;
   }
   __syncthreads();
   // Roots and position only where something reads them back (the compaction: active; the
@@ -492,15 +494,23 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
                                                       int work_cap, int32_t* __restrict__ work_ctl) {
   const int seg = blockIdx.x * 256 + threadIdx.x;
   unsigned n_forced = 0, n_regular = 0, n_small = 0;
-  if (seg < *num_segs) {
-    const int cnt = seg_cnt[seg];
-    if (cnt > small_seg && cnt < wave_max && work_list) {
-      // the wave worker's: filed under its size class (the order inside a class is arbitrary --
-      // components are independent)
-      const int cls = cnt >= kWaveClassMin0 ? 0 : (cnt >= kWaveClassMin1 ? 1 : 2);
-      const int at = atomicAdd(&work_ctl[cls], 1);
-      work_list[(size_t)cls * work_cap + at] = (uint32_t)seg;
+  const int cnt = seg < *num_segs ? seg_cnt[seg] : 0;
+  if (work_list) {
+    // the wave worker's: filed under its size class (the order inside a class is arbitrary --
+    // components are independent); one reservation per wavefront and class
+    const int cls = (cnt > small_seg && cnt < wave_max) ? (cnt >= kWaveClassMin0 ? 0 : (cnt >= kWaveClassMin1 ? 1 : 2)) : -1;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < kWaveClasses; ++c) {
+      const unsigned long long m = __ballot(cls == c);
+      if (!m) continue;
+      int base = 0;
+      if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&work_ctl[c], (int)__popcll(m));
+      base = __shfl(base, (int)__builtin_ctzll(m));
+      if (cls == c) work_list[(size_t)c * work_cap + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)seg;
     }
+  }
+  if (seg < *num_segs) {
     if (cnt <= small_seg) {
       const int beg = seg_off[seg];
       for (int p = beg; p < beg + cnt; ++p) {

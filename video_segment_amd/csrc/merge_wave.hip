@@ -659,6 +659,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
   unsigned dbg_batches = 0;
   unsigned long long dbg_taken = 0, dbg_live = 0;
   unsigned long long cyc_load = 0, cyc_loop = 0, cyc_wait = 0;
+  unsigned long long edges_taken = 0;
   __shared__ int next_seg;
   // With a work list (filed by k_merge_small, three size classes, largest first) the workgroups
   // draw tickets; without one they stride over all segments.
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
     }
 
     // ---- consumer --------------------------------------------------------------------------------
-    if (lane == 0) atomicAdd(&stats[3], (unsigned long long)cnt);
+    edges_taken += (unsigned long long)cnt;   // (added to stats[3] once, at the end)
     const unsigned long long seg_t0 = Clock();
     const unsigned seg_cut0 = C.dbg_cut, seg_kept0 = C.dbg_kept;
     const unsigned long long seg_c0[12] = {dbg_batches, C.dbg_rounds, dbg_live, cyc_wait, cyc_load, cyc_loop,
@@ -957,6 +958,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
     C.n_small += __shfl_down(C.n_small, off);
   }
   if (lane == 0) {
+    if (edges_taken) atomicAdd(&stats[3], edges_taken);
     if (C.n_forced) atomicAdd(&stats[0], (unsigned long long)C.n_forced);
     if (C.n_regular) atomicAdd(&stats[1], (unsigned long long)C.n_regular);
     if (C.n_small) atomicAdd(&stats[2], (unsigned long long)C.n_small);
