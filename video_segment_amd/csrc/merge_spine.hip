@@ -823,7 +823,7 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
 constexpr int kChRing = 4096;   // ring positions (a multiple of the fill)
 constexpr int kChFill = 256;    // positions per producer fill
 constexpr int kChFills = kChRing / kChFill;
-constexpr int kChProducers = 4;
+constexpr int kChProducers = 3;    // wavefronts 1-3: the chain wavefront (0) keeps its SIMD to itself
 constexpr int kChBlock = 16;    // steps per block = lanes of a DPP row
 
 struct SpineFastArrays {
@@ -968,6 +968,7 @@ __global__ __launch_bounds__(64 * (1 + kChProducers)) void k_spine_chain(int K, 
   // (Coefficients through DPP row shifts -- one lane per row, the 16 steps of a block in the lanes
   // of the row -- need no LDS reads at all, but a dependent DPP operation has three times the
   // latency of a plain one: 12 ns per step instead of 5.)
+  __builtin_amdgcn_s_setprio(3);
   const int ch = lane % 3;
   float h = ch == 0 ? H.d0 : (ch == 1 ? H.d1 : H.d2);
   float* ckout = F.ck + (size_t)ch * F.ck_stride + SpineCkOfs(comp_spine, k);
