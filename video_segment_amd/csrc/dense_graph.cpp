@@ -1207,30 +1207,113 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
   VSG_HIP(hipStreamSynchronize(stream_));
   const double t_dev1 = NowMs();
 
+  double th[6] = {t_dev1, t_dev1, t_dev1, t_dev1, t_dev1, t_dev1};   // debug: phases of the host part
   // 5. regions in first-appearance order of their intervals (GetCreateRegionInformation via
   //    AddIntervalToRasterization, dense_segmentation_graph.h:432-466).
   regions_.clear();
   key_to_region_.clear();
   next_region_index_ = 0;
   std::vector<int32_t> region_keys;
-  for (int i = 0; i < num_iv; ++i) {
-    const int key = h_label[i];
-    auto it = key_to_region_.find(key);
-    int idx;
-    if (it == key_to_region_.end()) {
-      idx = next_region_index_++;
-      key_to_region_.emplace(key, idx);
-      regions_.emplace_back();
-      regions_.back().index = idx;
-      regions_.back().has_raster = true;
-      region_keys.push_back(key);
-    } else {
-      idx = it->second;
+  {
+    // The intervals arrive in (slice, y, x) order.  One host thread per slice collects the slice's
+    // regions in order of first appearance with their rasters (a small open-addressing map: a
+    // std::unordered_map lookup per interval was 15 ms for 0.9 M intervals); the slices are then
+    // merged in order, which gives the same region numbering as one pass over all intervals.
+    struct SliceTable {
+      int frame = 0;
+      std::vector<int32_t> keys;       // first-appearance order within the slice
+      std::vector<Raster> rasters;     // parallel to keys
+    };
+    struct FlatMap {   // key -> value, keys >= 0
+      std::vector<int32_t> k, v;
+      uint32_t mask = 0;
+      size_t used = 0;
+      explicit FlatMap(size_t cap_pow2) : k(cap_pow2, -1), v(cap_pow2, 0), mask((uint32_t)cap_pow2 - 1) {}
+      int32_t* find_or_insert(int32_t key, int32_t value_if_new, bool* inserted) {
+        if (2 * (used + 1) > k.size()) grow();
+        uint32_t h = ((uint32_t)key * 2654435761u) & mask;
+        for (;; h = (h + 1) & mask) {
+          if (k[h] == key) {
+            *inserted = false;
+            return &v[h];
+          }
+          if (k[h] < 0) {
+            k[h] = key;
+            v[h] = value_if_new;
+            ++used;
+            *inserted = true;
+            return &v[h];
+          }
+        }
+      }
+      void grow() {
+        FlatMap bigger(k.size() * 2);
+        bool ins;
+        for (size_t i = 0; i < k.size(); ++i) {
+          if (k[i] >= 0) bigger.find_or_insert(k[i], v[i], &ins);
+        }
+        *this = std::move(bigger);
+      }
+    };
+    std::vector<int> slice_begin;   // interval index where every slice starts
+    for (int i = 0; i < num_iv; ++i) {
+      if (i == 0 || (h_ty[i] >> 16) != (h_ty[i - 1] >> 16)) slice_begin.push_back(i);
     }
-    RegionInfo& ri = regions_[idx];
-    const int t = (int)(h_ty[i] >> 16), y = (int)(h_ty[i] & 0xFFFFu);
-    if (ri.raster.empty() || ri.raster.back().frame < t) ri.raster.push_back(RasterSlice{t, Raster()});
-    ri.raster.back().raster.push_back(Interval{y, h_lx[i], h_rx[i]});
+    const int ns = (int)slice_begin.size();
+    slice_begin.push_back(num_iv);
+    std::vector<SliceTable> tables((size_t)ns);
+    {
+      std::atomic<int> next(0);
+      auto work = [&]() {
+        for (int sidx = next.fetch_add(1); sidx < ns; sidx = next.fetch_add(1)) {
+          SliceTable& st = tables[(size_t)sidx];
+          const int b = slice_begin[(size_t)sidx], e = slice_begin[(size_t)sidx + 1];
+          st.frame = (int)(h_ty[b] >> 16);
+          FlatMap local(1024);
+          int last_key = -1, last_idx = -1;
+          for (int i = b; i < e; ++i) {
+            const int key = h_label[i];
+            int idx;
+            if (key == last_key) {
+              idx = last_idx;
+            } else {
+              bool ins;
+              idx = *local.find_or_insert(key, (int32_t)st.keys.size(), &ins);
+              if (ins) {
+                st.keys.push_back(key);
+                st.rasters.emplace_back();
+              }
+              last_key = key;
+              last_idx = idx;
+            }
+            st.rasters[(size_t)idx].push_back(Interval{(int)(h_ty[i] & 0xFFFFu), h_lx[i], h_rx[i]});
+          }
+        }
+      };
+      const int hw = (int)std::thread::hardware_concurrency();
+      const int nt = std::max(1, std::min({ns, hw > 0 ? hw : 1, 16}));
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+      work();
+      for (std::thread& t : pool) t.join();
+    }
+    FlatMap global(4096);
+    for (SliceTable& st : tables) {
+      for (size_t j = 0; j < st.keys.size(); ++j) {
+        bool ins;
+        const int idx = *global.find_or_insert(st.keys[j], next_region_index_, &ins);
+        if (ins) {
+          ++next_region_index_;
+          regions_.emplace_back();
+          regions_.back().index = idx;
+          regions_.back().has_raster = true;
+          region_keys.push_back(st.keys[j]);
+        }
+        regions_[(size_t)idx].raster.push_back(RasterSlice{st.frame, std::move(st.rasters[j])});
+      }
+    }
+    key_to_region_.reserve(region_keys.size() * 2);
+    for (size_t i = 0; i < region_keys.size(); ++i) key_to_region_.emplace(region_keys[i], (int)i);
   }
   // sizes / constraints of the representatives
   auto fetch_states = [&](const std::vector<int32_t>& keys, std::vector<int32_t>* sz,
@@ -1263,6 +1346,7 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
 
   std::unordered_map<int, int> size_adjust;
   for (size_t i = 0; i < adj_keys.size(); ++i) size_adjust[adj_keys[i]] = adj_vals[i];
+  th[0] = NowMs();
 
   // 6. EnforceSpatialConnectedness (dense_segmentation_graph.h:666-904).
   std::vector<uint32_t> rl_ty;
@@ -1295,6 +1379,7 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
       parallel_regions([&](int r) {
         if (regions_[r].has_raster) splitters[r].Prepare(regions_[r].raster, have_flows ? &reqs[r] : nullptr);
       });
+      th[1] = NowMs();
       std::vector<size_t> req_off((size_t)num_regions + 1, 0);
       for (int r = 0; r < num_regions; ++r) req_off[r + 1] = req_off[r] + reqs[r].size();
       std::vector<float> samples;
@@ -1304,11 +1389,13 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
         for (int r = 0; r < num_regions; ++r) all.insert(all.end(), reqs[r].begin(), reqs[r].end());
         SampleFlows(all, *dev_flows, &samples);
       }
+      th[2] = NowMs();
       std::vector<TubeResult> results((size_t)num_regions);
       parallel_regions([&](int r) {
         if (!regions_[r].has_raster || !splitters[r].MaySplit()) return;
         splitters[r].Finish(W_, H_, have_flows ? samples.data() + 2 * req_off[r] : nullptr, &results[r]);
       });
+      th[3] = NowMs();
       for (int r = 0; r < num_regions; ++r) {
         if (results[r].tubes.size() <= 1) continue;
         split.emplace_back(r, TubeResult());
@@ -1448,7 +1535,29 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
   const int L = (int)lists_.size();
   int capacity = (int)std::max<size_t>(pairs_.size(), (size_t)1 << 20);
   int count = 0;
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  // The pairs through a hash table first (what is left to sort is the distinct pairs); a chunk with
+  // more distinct pairs than half the table lists all of them, as before.
+  bool hashed = false;
+  if (!getenv("VSG_PAIR_TABLE") || atoi(getenv("VSG_PAIR_TABLE")) != 0) {
+    const size_t cap = (size_t)1 << 21;
+    pairs_sorted_.ensure(cap);
+    pairs_unique_.ensure(cap);
+    pairs_.ensure((size_t)capacity);
+    order_keys_.ensure((size_t)capacity);
+    PairTable table{pairs_sorted_.get(), pairs_unique_.get(), (unsigned)(cap - 1)};
+    LaunchNeighborPairsHashed(list_desc_dev_.get(), L, label_uf_.get(), W_, table, scalars_.get() + 3, stream_);
+    int distinct = 0;
+    D2H(&distinct, scalars_.get() + 3, 1, stream_);
+    VSG_HIP(hipStreamSynchronize(stream_));
+    if (distinct <= (int)(cap / 2) && distinct <= capacity) {
+      LaunchPairTableCompact(table, pairs_.get(), order_keys_.get(), scalars_.get() + 3, stream_);
+      D2H(&count, scalars_.get() + 3, 1, stream_);
+      VSG_HIP(hipStreamSynchronize(stream_));
+      VSG_REQUIRE(count == distinct, -4, "pair table: entries lost");
+      hashed = true;
+    }
+  }
+  for (int attempt = 0; attempt < 2 && !hashed; ++attempt) {
     pairs_.ensure((size_t)capacity);
     order_keys_.ensure((size_t)capacity);
     LaunchNeighborPairs(list_desc_dev_.get(), L, label_uf_.get(), W_, pairs_.get(),
@@ -1531,6 +1640,9 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
     std::fprintf(stderr, "[vsg] readout: device1 %.1f host1 %.1f device2 %.1f host2 %.1f ms (intervals %d, pairs %d, unique %zu)\n",
                  t_dev1 - t_start, t_host1 - t_dev1, t_dev2 - t_host1, t_end - t_dev2, num_iv, count,
                  uniq.size());
+    std::fprintf(stderr, "[vsg]   host1: region table %.1f, tube prepare %.1f, flow samples %.1f, tube finish %.1f, "
+                 "bookkeeping %.1f ms (%zu regions)\n", th[0] - t_dev1, th[1] - th[0], th[2] - th[1], th[3] - th[2],
+                 t_host1 - th[3], regions_.size());
   }
   timings_.readout_ms = (float)((t_dev1 - t_start) + (t_dev2 - t_host1));
   timings_.host_post_ms = (float)((t_host1 - t_dev1) + (t_end - t_dev2));

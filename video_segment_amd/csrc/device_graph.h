@@ -300,6 +300,18 @@ void LaunchWriteIntervals(const int32_t* label_img, int W, int H, int frame,
 void LaunchRelabelIntervals(const uint32_t* ty, const int32_t* lx, const int32_t* rx,
                             const int32_t* new_label, int n, int W, int H, int32_t* label_uf,
                             hipStream_t s);
+// Hash table of the region pairs of a chunk: pair -> smallest order key (readout_kernels.hip).
+struct PairTable {
+  unsigned long long* key;     // [mask + 1], all ones = empty
+  unsigned long long* order;   // [mask + 1]
+  unsigned mask;               // capacity - 1 (a power of two)
+};
+// The pairs go into the table instead of a list (*distinct = pairs entered); LaunchPairTableCompact
+// then lists the table's entries as (pairs, order_keys), *out_count of them.
+void LaunchNeighborPairsHashed(const ListDesc* lists, int num_lists, const int32_t* label_uf, int W,
+                               PairTable table, int32_t* distinct, hipStream_t s);
+void LaunchPairTableCompact(PairTable table, unsigned long long* pairs, unsigned long long* order_keys,
+                            int32_t* out_count, hipStream_t s);
 // Emits (ka << 32 | kb) for every kept edge whose end labels differ.  count is a device scalar.
 void LaunchNeighborPairs(const ListDesc* lists, int num_lists, const int32_t* label_uf, int W,
                          unsigned long long* pairs, unsigned long long* order_keys,

@@ -235,6 +235,47 @@ void LaunchRelabelIntervals(const uint32_t* ty, const int32_t* lx, const int32_t
   VSG_HIP(hipGetLastError());
 }
 
+// Open-addressing table of (pair -> smallest order key); empty = all ones.  *distinct counts the
+// pairs entered (the caller falls back to listing every pair when the table gets too full).
+__device__ __forceinline__ void PairTableInsert(const PairTable& t, unsigned long long pair,
+                                                unsigned long long order, int32_t* distinct) {
+  unsigned long long x = pair * 0x9E3779B97F4A7C15ull;
+  unsigned h = (unsigned)(x >> 40) & t.mask;
+  for (unsigned probe = 0; probe <= t.mask; ++probe) {
+    unsigned long long k = t.key[h];
+    if (k == ~0ull) {
+      k = atomicCAS(&t.key[h], ~0ull, pair);
+      if (k == ~0ull) {
+        atomicAdd(distinct, 1);
+        k = pair;
+      }
+    }
+    if (k == pair) {
+      if (order < t.order[h]) atomicMin(&t.order[h], order);
+      return;
+    }
+    h = (h + 1) & t.mask;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pair_table_compact(PairTable t, unsigned long long* __restrict__ pairs,
+                                                             unsigned long long* __restrict__ order_keys,
+                                                             int32_t* __restrict__ out_count) {
+  const unsigned h = blockIdx.x * 256 + threadIdx.x;
+  const bool full = h <= t.mask && t.key[h] != ~0ull;
+  const unsigned long long m = __ballot(full);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(out_count, (int)__popcll(m));
+  base = __shfl(base, (int)__builtin_ctzll(m));
+  if (full) {
+    const int idx = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+    pairs[idx] = t.key[h];
+    order_keys[idx] = t.order[h];
+  }
+}
+
 // K9: every kept edge whose end points carry different region keys yields one ordered pair
 // (ka << 32 | kb) and an order key (bucket, list, position) for the first-appearance order that
 // DetermineNeighborIdsImpl uses when it creates RegionInformation for unseen representatives.
@@ -242,7 +283,8 @@ __global__ __launch_bounds__(256) void k_neighbor_pairs(const ListDesc* __restri
                                                          const int32_t* __restrict__ label_uf, int W,
                                                          unsigned long long* __restrict__ pairs,
                                                          unsigned long long* __restrict__ order_keys,
-                                                         int32_t* __restrict__ count, int capacity) {
+                                                         int32_t* __restrict__ count, int capacity,
+                                                         PairTable table) {
   const int l = blockIdx.y;
   const ListDesc L = lists[l];
   if (!L.offsets) return;
@@ -281,6 +323,23 @@ __global__ __launch_bounds__(256) void k_neighbor_pairs(const ListDesc* __restri
     if (lane > 0 && emit && prev_emit && prev_pair == pair) emit = false;
     const unsigned long long m = __ballot(emit);
     if (m == 0) continue;
+    if (table.key) {
+      // Into the hash table: the pair with the smallest order key it has been seen with.  (Two large
+      // regions meet along millions of kept edges: 43 M emitted pairs for 7 K distinct ones on a noisy
+      // chunk, all of them sorted afterwards.)  The first look is a plain read: a pair that is there
+      // already with a smaller order key costs no atomic.
+      if (emit) {
+        int lo = 0, hi = kNumBuckets + 1;   // bucket of position p
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (L.offsets[mid] <= p) lo = mid; else hi = mid;
+        }
+        const unsigned long long order = ((unsigned long long)lo << 48) | ((unsigned long long)l << 36) |
+                                         (unsigned long long)(uint32_t)p;
+        PairTableInsert(table, pair, order, count);
+      }
+      continue;
+    }
     int base = 0;
     if (lane == 0) base = atomicAdd(count, (int)__popcll(m));
     base = __shfl(base, 0);
@@ -305,7 +364,26 @@ void LaunchNeighborPairs(const ListDesc* lists, int num_lists, const int32_t* la
                          int capacity, hipStream_t s) {
   VSG_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
   hipLaunchKernelGGL(k_neighbor_pairs, dim3(256, num_lists), dim3(256), 0, s, lists, label_uf, W,
-                     pairs, order_keys, count, capacity);
+                     pairs, order_keys, count, capacity, PairTable{nullptr, nullptr, 0});
+  VSG_HIP(hipGetLastError());
+}
+
+void LaunchNeighborPairsHashed(const ListDesc* lists, int num_lists, const int32_t* label_uf, int W,
+                               PairTable table, int32_t* distinct, hipStream_t s) {
+  const size_t cap = (size_t)table.mask + 1;
+  VSG_HIP(hipMemsetAsync(table.key, 0xFF, cap * sizeof(unsigned long long), s));
+  VSG_HIP(hipMemsetAsync(table.order, 0xFF, cap * sizeof(unsigned long long), s));
+  VSG_HIP(hipMemsetAsync(distinct, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_neighbor_pairs, dim3(256, num_lists), dim3(256), 0, s, lists, label_uf, W,
+                     nullptr, nullptr, distinct, 0, table);
+  VSG_HIP(hipGetLastError());
+}
+
+void LaunchPairTableCompact(PairTable table, unsigned long long* pairs, unsigned long long* order_keys,
+                            int32_t* out_count, hipStream_t s) {
+  VSG_HIP(hipMemsetAsync(out_count, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_pair_table_compact, dim3(((size_t)table.mask + 256) / 256), dim3(256), 0, s, table, pairs,
+                     order_keys, out_count);
   VSG_HIP(hipGetLastError());
 }
 
