@@ -428,7 +428,9 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   // graph (1.15 N edges: 48 M at 1080p x 21 slices; the stamped ranks of the spanning forest allow
   // 2^27); a component is worth the tree replay from a fixed number of edges on (what one
   // wavefront replays in about a millisecond), whatever the frame size.
-  S.spine_min = getenv("VSG_SPINE_MIN") ? atoi(getenv("VSG_SPINE_MIN")) : 4096;
+  // (re-tuned in round 4, once the tree machinery had got cheaper: 4096 -> 2048, nested levels from
+  // the same size on)
+  S.spine_min = getenv("VSG_SPINE_MIN") ? atoi(getenv("VSG_SPINE_MIN")) : 2048;
   {
     const double want = 1.15 * (double)wh_ * (double)capacity_frames_;   // (the handle's capacity, not this chunk's N)
     const int by_graph = (int)std::min<double>(std::max<double>(want, 1 << 20), 120 << 20);
@@ -453,7 +455,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   }
   S.spine_low_failed = spine_low_failed;
   S.spine_low_skip = spine_low_skip;
-  S.spine_nested_factor = getenv("VSG_SPINE_NESTED") ? std::max(1, atoi(getenv("VSG_SPINE_NESTED"))) : 2;
+  S.spine_nested_factor = getenv("VSG_SPINE_NESTED") ? std::max(1, atoi(getenv("VSG_SPINE_NESTED"))) : 1;
   S.spine_debug = getenv("VSG_SPINE_DEBUG") ? 1 : 0;
   S.spine_check = getenv("VSG_SPINE_CHECK") ? 1 : 0;
   S.rank_split_min = getenv("VSG_RANK_SPLIT_MIN") ? atoi(getenv("VSG_RANK_SPLIT_MIN")) : (1 << 20);
