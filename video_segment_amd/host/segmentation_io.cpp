@@ -7,66 +7,71 @@
 namespace segmentation {
 
 namespace {
+// Little-endian POD records, appended to a byte string that goes out in one write per section.
 template <class T>
-void Put(std::ofstream& o, const T& v) {
-  o.write(reinterpret_cast<const char*>(&v), sizeof(T));
+void Append(std::string* bytes, const T& v) {
+  bytes->append(reinterpret_cast<const char*>(&v), sizeof(T));
 }
 }  // namespace
 
+// Layout: see the header.  Every section is assembled in memory and written in one go; the file
+// position is tracked here (file_pos_) because the chunk header stores absolute offsets of the
+// frames that follow it and of the next header.
 bool SegmentationWriter::OpenFile(const std::vector<int>& header_entries) {
-  header_entries_ = header_entries;
-  ofs_.open(filename_.c_str(), std::ios_base::out | std::ios_base::binary | std::ios_base::trunc);
-  if (!ofs_) {
+  out_.open(filename_.c_str(), std::ios_base::out | std::ios_base::binary | std::ios_base::trunc);
+  if (!out_) {
     std::fprintf(stderr, "ERROR: Could not open %s to write!\n", filename_.c_str());
     return false;
   }
-  num_chunks_ = 0;
-  ofs_.write("HEAD", 4);
-  const int32_t num_entries = (int32_t)header_entries_.size();
-  Put(ofs_, num_entries);
-  for (int e : header_entries_) Put(ofs_, (int32_t)e);
-  curr_offset_ = 4 + 4 + (int64_t)num_entries * 4;
+  std::string head("HEAD");
+  Append(&head, (int32_t)header_entries.size());
+  for (int flag : header_entries) Append(&head, (int32_t)flag);
+  out_.write(head.data(), (std::streamsize)head.size());
+  file_pos_ = (int64_t)head.size();
+  chunks_written_ = 0;
+  frames_written_ = 0;
+  pending_.clear();
   return true;
 }
 
 void SegmentationWriter::AddSegmentationDataToChunk(const std::string& data, int64_t pts) {
-  file_offsets_.push_back(curr_offset_);
-  chunk_buffer_.push_back(data);
-  curr_offset_ += (int64_t)data.size() + 4 + (int64_t)sizeof(int32_t);
-  time_stamps_.push_back(pts);
+  pending_.push_back(Pending{data, pts});
 }
 
 void SegmentationWriter::WriteChunk() {
-  const int32_t num_frames = (int32_t)file_offsets_.size();
-  const int32_t chunk_id = num_chunks_++;
-  ofs_.write("CHNK", 4);
-  Put(ofs_, chunk_id);
-  Put(ofs_, num_frames);
-  const int64_t size_of_header = 4 + 2 * (int64_t)sizeof(int32_t) +
-                                 (int64_t)num_frames * 2 * (int64_t)sizeof(int64_t) +
-                                 (int64_t)sizeof(int64_t);
-  curr_offset_ += size_of_header;
-  for (int64_t& o : file_offsets_) o += size_of_header;
-  for (int64_t o : file_offsets_) Put(ofs_, o);
-  for (int64_t t : time_stamps_) Put(ofs_, t);
-  Put(ofs_, curr_offset_);
-  for (const std::string& frame : chunk_buffer_) {
-    ofs_.write("SEGD", 4);
-    Put(ofs_, (int32_t)frame.size());
-    ofs_.write(frame.data(), (std::streamsize)frame.size());
+  const int64_t n = (int64_t)pending_.size();
+  // absolute offset of every frame record (tag + size + payload) behind the header, and of what
+  // follows the chunk
+  int64_t at = file_pos_ + ChunkHeaderBytes(n);
+  std::string header("CHNK");
+  Append(&header, (int32_t)chunks_written_);
+  Append(&header, (int32_t)n);
+  for (const Pending& f : pending_) {
+    Append(&header, at);
+    at += 4 + (int64_t)sizeof(int32_t) + (int64_t)f.wire.size();
   }
-  total_frames_ += (int)chunk_buffer_.size();
-  chunk_buffer_.clear();
-  file_offsets_.clear();
-  time_stamps_.clear();
+  for (const Pending& f : pending_) Append(&header, f.pts);
+  Append(&header, at);   // where the next chunk header (or TERM) starts
+  out_.write(header.data(), (std::streamsize)header.size());
+  for (const Pending& f : pending_) {
+    std::string rec("SEGD");
+    Append(&rec, (int32_t)f.wire.size());
+    out_.write(rec.data(), (std::streamsize)rec.size());
+    out_.write(f.wire.data(), (std::streamsize)f.wire.size());
+  }
+  file_pos_ = at;
+  frames_written_ += (int)n;
+  ++chunks_written_;
+  pending_.clear();
 }
 
 void SegmentationWriter::WriteTermHeaderAndClose() {
-  if (!chunk_buffer_.empty()) WriteChunk();
-  ofs_.write("TERM", 4);
-  Put(ofs_, num_chunks_);
-  ofs_.close();
-  std::fprintf(stderr, "Wrote a total of %d frames.\n", total_frames_);
+  if (!pending_.empty()) WriteChunk();
+  std::string term("TERM");
+  Append(&term, (int32_t)chunks_written_);
+  out_.write(term.data(), (std::streamsize)term.size());
+  out_.close();
+  std::fprintf(stderr, "Wrote a total of %d frames.\n", frames_written_);
 }
 
 bool SegmentationWriterUnit::OpenStreams(StreamSet* set) {

@@ -28,14 +28,20 @@ class SegmentationWriter {
   void WriteTermHeaderAndClose();
 
  private:
+  // A frame waiting for its chunk: the serialized message and its time stamp.
+  struct Pending {
+    std::string wire;
+    int64_t pts;
+  };
+  // Bytes a chunk header with n frames occupies: tag, id, n, n offsets, n time stamps, link.
+  static int64_t ChunkHeaderBytes(int64_t n) { return 4 + 4 + 4 + 16 * n + 8; }
+
   std::string filename_;
-  std::ofstream ofs_;
-  std::vector<int> header_entries_;
-  int32_t num_chunks_ = 0;
-  int64_t curr_offset_ = 0;
-  int total_frames_ = 0;
-  std::vector<int64_t> file_offsets_, time_stamps_;
-  std::vector<std::string> chunk_buffer_;
+  std::ofstream out_;
+  std::vector<Pending> pending_;
+  int64_t file_pos_ = 0;        // bytes written so far (the stream is append-only)
+  int32_t chunks_written_ = 0;
+  int frames_written_ = 0;
 };
 
 // Reader of the same container (segment_util/segmentation_io.h:117-170, segmentation_io.cpp:168-300):
