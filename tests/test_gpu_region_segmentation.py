@@ -178,11 +178,10 @@ def test_bench_checker_through_both_stages_reports_invalid(vsg):
     o.close()
 
 
-@pytest.mark.skipif(not os.environ.get("VSG_SLOW"), reason="minutes of CPU oracle at 3840x2160 (VSG_SLOW=1)")
 def test_config4_first_chunk_set_against_oracle(vsg):
-    """configs[4] at its own size against the oracle running BOTH stages: 3840x2160 + flow, one
-    over-segmentation chunk = one flushed chunk set, every hierarchical SegmentationDesc byte for
-    byte.  (Run by hand on a GPU box with VSG_SLOW=1; the result is recorded in DESIGN.md.)"""
+    """configs[4] at its own size against the oracle running BOTH stages: 3840x2160 + flow, twelve
+    frames = one flushed over-segmentation chunk = one chunk set, every hierarchical
+    SegmentationDesc byte for byte (40 s, most of it the CPU oracle)."""
     import torch
     W, H, N, chunk = 3840, 2160, 12, 20
     want = oracle_pipeline(W, H, N, chunk, dict(min_region_num=5))
