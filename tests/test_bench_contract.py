@@ -67,8 +67,8 @@ def test_committed_round_line_carries_every_key():
     tools/measure_round.sh): the contract keys plus what the headline depends on -- the other
     single-GPU configs, the other inputs, the streams sweep."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r3_*_bench_1080p.json")))
-    assert paths, "no round-3 bench line under profiles/"
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r4_*_bench_1080p.json")))
+    assert paths, "no round-4 bench line under profiles/"
     out = last_json_line(open(paths[-1]).read())
     check(out, 1, out["steps"], out["warmup"])
     assert out["vs_baseline"] is None and out["parity_checked"] is True
@@ -81,3 +81,9 @@ def test_committed_round_line_carries_every_key():
     assert set(out["workloads"]) >= {"checker (headline input)", "blobs", "noise"}
     assert [s["streams"] for s in out["streams_sweep"]] == [1, 2, 4, 8]
     assert out["pipelined"]["value"] > 0
+    # round 4: a measured denominator, the per-kernel table and the memory a stream holds
+    r = out["roofline"]
+    assert r["peak_measured"] > 1000 and 0 < r["frac_of_measured"] < 1
+    assert len(r["kernels"]["top"]) == 8 and all(k["ms_per_step"] > 0 for k in r["kernels"]["top"])
+    assert 0.9 < r["traffic_vs_algorithmic_same_run"] < 1.5
+    assert out["device_bytes_per_stream"] > (1 << 30)
