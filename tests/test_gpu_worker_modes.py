@@ -52,6 +52,8 @@ def test_chain_self_check_is_silent(vsg, monkeypatch, capfd):
                                  {"VSG_SPINE_MIN": "32", "VSG_SPINE_FAST_MIN": "0", "VSG_SPINE_FAST": "3",
                                   "VSG_WINDOWS": "1", "VSG_GROUP_BUCKETS": "0"},
                                  {"VSG_SPINE_MIN": "48", "VSG_SPINE_FAST": "0"},
+                                 # a pool of zeroed counters so small that it changes halves within a chunk
+                                 {"VSG_SPINE_MIN": "32", "VSG_ZERO_POOL": "4096", "VSG_SPINE_CHECK": "1"},
                                  # Euler tours ranked by sampling (every 64th arc) whatever their length
                                  {"VSG_SPINE_MIN": "32", "VSG_RANK_SPLIT_MIN": "0", "VSG_SPINE_CHECK": "1"}])
 def test_stage_decomposition_variants(vsg, monkeypatch, env):

@@ -85,10 +85,12 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
     mail_.list_dev = reinterpret_cast<int32_t*>(static_cast<char*>(dev) +
                                                 (size_t)slots * kMailValues * sizeof(unsigned long long));
     mail_.list_cap = (int)list_cap;
-    zero_pool_mem_.alloc(1 << 18);
+    zero_pool_mem_.alloc(1 << 20);
     zero_pool_.base = zero_pool_mem_.get();
     zero_pool_.cap = zero_pool_mem_.size();
-    zero_pool_.used = zero_pool_.cap;   // cleared before its first use
+    if (const char* e = getenv("VSG_ZERO_POOL")) {   // test hook: a small pool changes halves all the time
+      zero_pool_.cap = std::min<size_t>(zero_pool_.cap, std::max<size_t>((size_t)atoll(e), 4096));
+    }
   }
   VSG_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
   VSG_HIP(hipStreamCreateWithFlags(&aux2_stream_, hipStreamNonBlocking));
@@ -356,6 +358,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   // (the counters of the last chunk's stages: nothing is in flight on the other streams here)
   VSG_HIP(hipMemsetAsync(zero_pool_.base, 0, zero_pool_.cap * sizeof(int32_t), stream_));
   zero_pool_.used = 0;
+  zero_pool_.second_half = false;
   LaunchInitIdentity(cc_.get(), N, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
 

@@ -146,7 +146,8 @@ void LaunchMailPost(const MailSlot& slot, const int32_t* p0, const int32_t* p1, 
 // counter per stage was 450 launches per chunk).
 struct ZeroPool {
   int32_t* base = nullptr;
-  size_t cap = 0, used = 0;
+  size_t cap = 0, used = 0;     // `used` counts inside the current half (TakeZeroed)
+  bool second_half = false;
 };
 
 // ---- merge_stage.hip (worker: merge_wave.hip) ----------------------------------------------------------------

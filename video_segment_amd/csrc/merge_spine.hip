@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_spine_gather(int mE, int K, const int32
 // best[c] holds the smallest rank among the edges that leave component c, stamped with the round
 // ((31 - round) << 27 | rank, unsigned): a later round's entry is smaller than anything an
 // earlier round left behind, so the table never has to be cleared.
-constexpr int kAliveSlots = 64;   // counters of the live edges of a round, one cache line apart
+constexpr int kAliveSlots = 32;   // counters of the live edges of a round, one cache line apart
 __device__ __forceinline__ uint32_t BorKey(int round, int e) { return ((uint32_t)(31 - round) << 27) | (uint32_t)e; }
 
 // The kernels of a round run over all edges (list == null) or over the list of the edges that were

@@ -117,17 +117,25 @@ void MailWait(const MailSlot& slot, int count, int* values, hipStream_t s) {
 }
 
 int32_t* TakeZeroed(MergeScratch& S, size_t n) {
+  // The pool is used in two halves.  Counters live for a stage at most (a few thousand ints), so
+  // when one half is used up the OTHER one holds nothing anybody still reads: it is cleared (after
+  // the streams have drained: kernels of older stages may still be adding to it) and taken over,
+  // while the counters of the stage in flight stay where they are.
   ZeroPool& z = *S.zeros;
   n = (n + 3) & ~(size_t)3;
-  VSG_REQUIRE(n <= z.cap, -4, "zero pool: request too large");
-  if (z.used + n > z.cap) {
+  const size_t half = z.cap / 2;
+  VSG_REQUIRE(n <= half, -4, "zero pool: request too large");
+  const size_t begin = z.second_half ? half : 0;
+  if (z.used + n > half) {
     VSG_HIP(hipStreamSynchronize(S.main_stream));
     if (S.aux_stream) VSG_HIP(hipStreamSynchronize(S.aux_stream));
     if (S.aux2_stream) VSG_HIP(hipStreamSynchronize(S.aux2_stream));
-    VSG_HIP(hipMemsetAsync(z.base, 0, z.cap * sizeof(int32_t), S.main_stream));
+    z.second_half = !z.second_half;
     z.used = 0;
+    VSG_HIP(hipMemsetAsync(z.base + (z.second_half ? half : 0), 0, half * sizeof(int32_t), S.main_stream));
+    return TakeZeroed(S, n);
   }
-  int32_t* p = z.base + z.used;
+  int32_t* p = z.base + begin + z.used;
   z.used += n;
   return p;
 }
