@@ -94,6 +94,7 @@ class PinnedBuf {
   void ensure(size_t n) {
     if (n <= n_) return;
     release();
+    n = n + n / 4 + 256;   // (with slack: sizes that drift from chunk to chunk)
     VSG_HIP(hipHostMalloc(reinterpret_cast<void**>(&p_), n * sizeof(T), hipHostMallocDefault));
     n_ = n;
   }

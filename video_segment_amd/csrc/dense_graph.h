@@ -155,6 +155,7 @@ class DenseGraphHip {
   int64_t optimistic_stages_ = 0, rollbacks_ = 0;
   DevBuf<int32_t> scalars_;   // num_active, num_segs, misc
   DevBuf<int32_t> seg_table_dev_;   // k_filter: the segments of the current stage
+  PinnedBuf<int32_t> iv_host_;      // read-out: the scan intervals on the host (label, frame|y, lx, rx)
   std::vector<int32_t> seg_table_host_, list_off_host_;
   Mailbox mail_;              // host-visible scalars (device_graph.h); mapped host memory
   void* mail_mem_ = nullptr;
