@@ -1218,6 +1218,8 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
   const double t_dev1 = NowMs();
 
   double th[6] = {t_dev1, t_dev1, t_dev1, t_dev1, t_dev1, t_dev1};   // debug: phases of the host part
+  long long sum_tubes = 0;
+  int most_tubes = 0;
   // 5. regions in first-appearance order of their intervals (GetCreateRegionInformation via
   //    AddIntervalToRasterization, dense_segmentation_graph.h:432-466).
   regions_.clear();
@@ -1374,13 +1376,25 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
     {
       std::vector<TubeSplitter> splitters((size_t)num_regions);
       std::vector<std::vector<FlowRequest>> reqs((size_t)num_regions);
+      // One task per region, the regions with the most scan intervals first (a region's analysis
+      // grows faster than its size); the number of threads follows the number of intervals.
+      std::vector<int> by_work((size_t)num_regions);
+      std::vector<long long> work_of((size_t)num_regions, 0);
+      long long total_work = 0;
+      for (int r = 0; r < num_regions; ++r) {
+        by_work[r] = r;
+        if (!regions_[r].has_raster) continue;
+        for (const RasterSlice& sl : regions_[r].raster) work_of[r] += (long long)sl.raster.size();
+        total_work += work_of[r];
+      }
+      std::stable_sort(by_work.begin(), by_work.end(), [&](int a, int b) { return work_of[a] > work_of[b]; });
       auto parallel_regions = [&](const std::function<void(int)>& fn) {
         std::atomic<int> next(0);
         auto work = [&]() {
-          for (int r = next.fetch_add(1); r < num_regions; r = next.fetch_add(1)) fn(r);
+          for (int i = next.fetch_add(1); i < num_regions; i = next.fetch_add(1)) fn(by_work[i]);
         };
         const int hw = (int)std::thread::hardware_concurrency();
-        const int nt = std::max(1, std::min({num_regions / 64, hw > 0 ? hw : 1, 16}));
+        const int nt = std::max(1, std::min({(int)(total_work / 16384), num_regions, hw > 0 ? hw : 1, 16}));
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; ++t) pool.emplace_back(work);
         work();
@@ -1400,12 +1414,34 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
         SampleFlows(all, *dev_flows, &samples);
       }
       th[2] = NowMs();
+      if (const char* dump = getenv("VSG_DUMP_TUBES")) {
+        // debug: the input of the tube analysis of this chunk (tools/tube_harness.cpp reads it)
+        if (FILE* f = std::fopen(dump, "wb")) {
+          auto put = [&](int v) { std::fwrite(&v, 4, 1, f); };
+          put(W_); put(H_); put(num_regions); put(have_flows ? 1 : 0);
+          for (int r = 0; r < num_regions; ++r) {
+            put(regions_[r].has_raster ? (int)regions_[r].raster.size() : -1);
+            if (!regions_[r].has_raster) continue;
+            for (const RasterSlice& sl : regions_[r].raster) {
+              put(sl.frame); put((int)sl.raster.size());
+              std::fwrite(sl.raster.data(), sizeof(Interval), sl.raster.size(), f);
+            }
+            put((int)reqs[r].size());
+            if (have_flows) std::fwrite(samples.data() + 2 * req_off[r], 8, reqs[r].size(), f);
+          }
+          std::fclose(f);
+        }
+      }
       std::vector<TubeResult> results((size_t)num_regions);
       parallel_regions([&](int r) {
         if (!regions_[r].has_raster || !splitters[r].MaySplit()) return;
         splitters[r].Finish(W_, H_, have_flows ? samples.data() + 2 * req_off[r] : nullptr, &results[r]);
       });
       th[3] = NowMs();
+      for (int r = 0; r < num_regions; ++r) {
+        most_tubes = std::max(most_tubes, results[r].tubes_matched);
+        sum_tubes += results[r].tubes_matched;
+      }
       for (int r = 0; r < num_regions; ++r) {
         if (results[r].tubes.size() <= 1) continue;
         split.emplace_back(r, TubeResult());
@@ -1651,8 +1687,8 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
                  t_dev1 - t_start, t_host1 - t_dev1, t_dev2 - t_host1, t_end - t_dev2, num_iv, count,
                  uniq.size());
     std::fprintf(stderr, "[vsg]   host1: region table %.1f, tube prepare %.1f, flow samples %.1f, tube finish %.1f, "
-                 "bookkeeping %.1f ms (%zu regions)\n", th[0] - t_dev1, th[1] - th[0], th[2] - th[1], th[3] - th[2],
-                 t_host1 - th[3], regions_.size());
+                 "bookkeeping %.1f ms (%zu regions, %lld matched tubes, at most %d in a region)\n", th[0] - t_dev1,
+                 th[1] - th[0], th[2] - th[1], th[3] - th[2], t_host1 - th[3], regions_.size(), sum_tubes, most_tubes);
   }
   timings_.readout_ms = (float)((t_dev1 - t_start) + (t_dev2 - t_host1));
   timings_.host_post_ms = (float)((t_host1 - t_dev1) + (t_end - t_dev2));

@@ -95,6 +95,7 @@ struct TubeResult {
   std::vector<Raster3D> tubes;
   std::vector<float> areas;
   int tube_to_keep = -1;
+  int tubes_matched = 0;   // tubes after the temporal matching, before the joins (statistics)
 };
 // One point where the matching reads the backward flow: flow[frame](y, x).
 struct FlowRequest {
@@ -110,6 +111,9 @@ class TubeSplitter {
   void Prepare(const Raster3D& raster, std::vector<FlowRequest>* requests);
   bool MaySplit() const;
   void Finish(int W, int H, const float* flow_xy, TubeResult* out);
+#ifdef VSG_TEST_MODELS
+  void FinishPlain(int W, int H, const float* flow_xy, TubeResult* out);   // tests/host/tube_plain_model.inc
+#endif
 
  private:
   struct Impl;

@@ -113,20 +113,23 @@ void SplitComponentsN4(const Raster& r, std::vector<Raster>* comps) {
     }
     return i;
   };
-  int row_start = -1, prev_y = -2, first_test = 0;
+  // Intervals of one row are disjoint and ordered by lx, so the intervals of the row above that
+  // overlap interval i in x are consecutive and the first of them never moves left as i advances
+  // (which pairs are united first does not matter: the components come out the same).
+  int row_start = 0, prev_start = 0, prev_end = 0, cursor = 0;
   for (int i = 0; i < n; ++i) {
     uf[i] = i;
-    if (r[i].y != prev_y) {
-      first_test = (prev_y + 1 == r[i].y) ? row_start : i;
-      prev_y = r[i].y;
+    if (i == 0 || r[i].y != r[i - 1].y) {
+      const bool adjacent = i > 0 && r[i - 1].y + 1 == r[i].y;
+      prev_start = adjacent ? row_start : i;
+      prev_end = i;
       row_start = i;
+      cursor = prev_start;
     }
-    for (int k = first_test; k < i; ++k) {
-      if (std::abs(r[i].y - r[k].y) <= 1 &&
-          std::max(r[i].lx, r[k].lx) <= std::min(r[i].rx, r[k].rx)) {
-        const int a = root(i), b = root(k);
-        if (a != b) uf[a] = b;
-      }
+    while (cursor < prev_end && r[cursor].rx < r[i].lx) ++cursor;
+    for (int k = cursor; k < prev_end && r[k].lx <= r[i].rx; ++k) {
+      const int a = root(i), b = root(k);
+      if (a != b) uf[a] = b;
     }
   }
   int num = 0;
@@ -270,32 +273,39 @@ float MeanSliceSize(const Tube& t) {   // dense_segmentation_graph.cpp:35-45
   return s / (float)t.size();
 }
 
-void JoinTubes(const Tube& a, const Tube& b, Tube* out) {   // .cpp:47-88
-  if (a.empty()) {
-    *out = b;
-    return;
-  }
-  if (b.empty()) {
-    *out = a;
-    return;
-  }
+// Joins b into a; where both have a slice of a frame, a's slice is the base (its axes stay when the
+// joined shape is unreliable).  The slices are moved, not copied: a and b are left empty.  Frames
+// that only b had are appended to *gained (may be null).
+void JoinTubes(Tube* a, Tube* b, Tube* out, std::vector<int>* gained) {   // .cpp:47-88
+  out->clear();
+  out->reserve(a->size() + b->size());
+  const bool a_empty = a->empty();
   size_t i = 0, j = 0;
-  while (i < a.size() && j < b.size()) {
-    if (a[i].frame < b[j].frame) {
-      out->push_back(a[i++]);
-    } else if (a[i].frame > b[j].frame) {
-      out->push_back(b[j++]);
+  while (i < a->size() && j < b->size()) {
+    if ((*a)[i].frame < (*b)[j].frame) {
+      out->push_back(std::move((*a)[i++]));
+    } else if ((*a)[i].frame > (*b)[j].frame) {
+      if (gained) gained->push_back((*b)[j].frame);
+      out->push_back(std::move((*b)[j++]));
     } else {
-      TSlice m = a[i];
-      MergeRasters(m.raster, b[j].raster, &m.raster);
+      TSlice& m = (*a)[i];
+      MergeRasters(m.raster, (*b)[j].raster, &m.raster);
       m.Recompute();
-      out->push_back(m);
+      out->push_back(std::move(m));
       ++i;
       ++j;
     }
   }
-  while (i < a.size()) out->push_back(a[i++]);
-  while (j < b.size()) out->push_back(b[j++]);
+  while (i < a->size()) out->push_back(std::move((*a)[i++]));
+  while (j < b->size()) {
+    if (gained && !a_empty) gained->push_back((*b)[j].frame);
+    out->push_back(std::move((*b)[j++]));
+  }
+  if (gained && a_empty) {
+    for (const TSlice& sl : *out) gained->push_back(sl.frame);
+  }
+  a->clear();
+  b->clear();
 }
 
 bool TemporalNeighbors(const Tube& a, const Tube& b) {   // .cpp:90-110
@@ -315,23 +325,6 @@ bool TemporalNeighbors(const Tube& a, const Tube& b) {   // .cpp:90-110
   return (double)ratio > 0.9 && std::hypot((double)d.y, (double)d.x) < 20;
 }
 
-float MeanCentreDistance(const Tube& a, const Tube& b) {   // .cpp:112-148
-  if (a.empty() || b.empty()) return std::numeric_limits<float>::max();
-  const int f0 = std::max(a[0].frame, b[0].frame);
-  const int f1 = std::min(a.back().frame, b.back().frame);
-  int i = 0, j = 0, w = 0;
-  float sum = 0;
-  for (int f = f0; f <= f1; ++f) {
-    while (a[i].frame < f) ++i;
-    while (b[j].frame < f) ++j;
-    if (a[i].frame != f || b[j].frame != f) continue;
-    const V2 d = Sub(a[i].shape.center, b[j].shape.center);
-    sum = (float)((double)sum + std::hypot((double)d.y, (double)d.x));
-    ++w;
-  }
-  return w > 0 ? sum / (float)w : std::numeric_limits<float>::max();
-}
-
 float BoxOverlapFraction(const Tube& a, const Tube& b) {   // .cpp:150-191
   if (a.empty() || b.empty()) return std::numeric_limits<float>::max();
   const int f0 = std::max(a[0].frame, b[0].frame);
@@ -348,20 +341,6 @@ float BoxOverlapFraction(const Tube& a, const Tube& b) {   // .cpp:150-191
     ++w;
   }
   return w > 0 ? (float)hits * (1.0f / (float)w) : std::numeric_limits<float>::max();
-}
-
-int ClosestTube(const Tube& t, const std::vector<Tube>& all, int skip) {   // .cpp:193-210
-  float best = std::numeric_limits<float>::max();
-  int best_idx = -1;
-  for (int k = 0; k < (int)all.size(); ++k) {
-    if (k == skip) continue;
-    const float d = MeanCentreDistance(t, all[k]);
-    if (d < best) {
-      best = d;
-      best_idx = k;
-    }
-  }
-  return best_idx;
 }
 
 }  // namespace
@@ -411,6 +390,8 @@ void TubeSplitter::Finish(int W, int H, const float* flow_xy, TubeResult* out) {
   out->areas.clear();
   out->tube_to_keep = -1;
   std::vector<Tube> done, active;
+  std::vector<float> last_x, last_y;
+  std::vector<char> candidate;
   const float inv_diam = (float)(1.0f / std::hypot((double)W, (double)H));
   size_t sample = 0;
 
@@ -423,11 +404,27 @@ void TubeSplitter::Finish(int W, int H, const float* flow_xy, TubeResult* out) {
     first_slice = false;
     if (active.empty()) {
       if (had_requests) sample += slices.size();
-      for (TSlice& s : slices) active.push_back(Tube{std::move(s)});
+      for (TSlice& s : slices) {
+        active.emplace_back();
+        active.back().push_back(std::move(s));
+      }
       continue;
     }
     std::vector<Tube> next;
     std::vector<char> continued(active.size(), 0);
+    // centre of every active tube's last slice (NaN frame marker: tubes already continued or
+    // ending in this frame are not candidates)
+    const int num_active = (int)active.size();
+    last_x.resize((size_t)num_active);
+    last_y.resize((size_t)num_active);
+    candidate.resize((size_t)num_active);
+    for (int k = 0; k < num_active; ++k) {
+      candidate[k] = !active[k].empty() && active[k].back().frame < frame;
+      if (candidate[k]) {
+        last_x[k] = active[k].back().shape.center.x;
+        last_y[k] = active[k].back().shape.center.y;
+      }
+    }
     for (TSlice& s : slices) {
       // FindPreviousTube, dense_segmentation_graph.h:601-629
       V2 c = s.shape.center;
@@ -438,29 +435,36 @@ void TubeSplitter::Finish(int W, int H, const float* flow_xy, TubeResult* out) {
       ++sample;
       float best = std::numeric_limits<float>::max();
       float best_idx = -1;   // float in the reference
-      for (int k = 0; k < (int)active.size(); ++k) {
-        if (active[k].empty() || active[k].back().frame >= frame) continue;
-        const V2 d = Sub(active[k].back().shape.center, c);
-        const float dist = HypotYX(d.y, d.x);
+      double skip_above = std::numeric_limits<double>::infinity();
+      for (int k = 0; k < num_active; ++k) {
+        if (!candidate[k]) continue;
+        const float dx = last_x[k] - c.x, dy = last_y[k] - c.y;
+        // the distance is only evaluated where it can be below the best one so far
+        if ((double)dx * (double)dx + (double)dy * (double)dy > skip_above) continue;
+        const float dist = HypotYX(dy, dx);
         if (dist < best) {
           best = dist;
           best_idx = (float)k;
+          skip_above = (double)best * (double)best * (1.0 + 1e-6);
         }
       }
       const int prev = (int)best_idx;
       if (prev < 0) {
-        next.push_back(Tube{std::move(s)});
+        next.emplace_back();
+        next.back().push_back(std::move(s));
         continue;
       }
       const int sa = active[prev].back().shape.size, sb = s.shape.size;
       const float ratio = (float)((double)std::min(sa, sb) / ((double)std::max(sa, sb) + 1e-6));
       if ((double)ratio > 0.75 && best * inv_diam < 0.04f) {
         continued[prev] = 1;
+        candidate[prev] = 0;
         active[prev].push_back(std::move(s));
         next.emplace_back();
         next.back().swap(active[prev]);
       } else {
-        next.push_back(Tube{std::move(s)});
+        next.emplace_back();
+        next.back().push_back(std::move(s));
       }
     }
     for (size_t k = 0; k < active.size(); ++k) {
@@ -469,48 +473,147 @@ void TubeSplitter::Finish(int W, int H, const float* flow_xy, TubeResult* out) {
     next.swap(active);
   }
   for (Tube& t : active) done.push_back(std::move(t));
+  out->tubes_matched = (int)done.size();
 
   if (done.size() > 1) {
+    // The reference keeps the tubes in a vector, erases the joined one and puts the join in the
+    // other one's place, so the order of the survivors never changes.  Here the tubes keep their
+    // index: a doubly linked list of the live ones gives the reference's order, and the tubes
+    // that have a slice in a frame are listed per frame (the only ones at a finite distance).
+    const int T = (int)done.size();
+    std::vector<int> nxt((size_t)T + 1), prv((size_t)T + 1);   // T = list head
+    for (int k = 0; k <= T; ++k) {
+      nxt[k] = k == T ? 0 : k + 1;
+      prv[k] = k == 0 ? T : k - 1;
+    }
+    std::vector<char> live((size_t)T, 1);
+    auto unlink = [&](int k) {
+      live[k] = 0;
+      nxt[prv[k]] = nxt[k];
+      prv[nxt[k]] = prv[k];
+    };
+    int frame_lo = std::numeric_limits<int>::max(), frame_hi = -1;
+    for (const Tube& t : done) {
+      if (t.empty()) continue;
+      frame_lo = std::min(frame_lo, t[0].frame);
+      frame_hi = std::max(frame_hi, t.back().frame);
+    }
+    std::vector<std::vector<int>> in_frame(frame_hi >= frame_lo ? (size_t)(frame_hi - frame_lo + 1) : 0);
+    for (int k = 0; k < T; ++k) {
+      for (const TSlice& sl : done[k]) in_frame[(size_t)(sl.frame - frame_lo)].push_back(k);
+    }
+    std::vector<int> seen((size_t)T, -1), gained;
+    // centre of tube l's slice of frame f (x = NaN: l has no slice there), so that a distance
+    // is evaluated without visiting the other tube
+    const size_t num_frames = in_frame.size();
+    const float kNone = std::numeric_limits<float>::quiet_NaN();
+    std::vector<V2> centre_at(num_frames * (size_t)T, V2{kNone, kNone});
+    auto note_centres = [&](int k) {
+      for (const TSlice& sl : done[k]) centre_at[(size_t)(sl.frame - frame_lo) * T + k] = sl.shape.center;
+    };
+    for (int k = 0; k < T; ++k) note_centres(k);
+    // ClosestTube (.cpp:193-210): the first tube, in order, at the smallest mean centre distance
+    // (MeanCentreDistance, .cpp:112-148: over the common frames, in frame order, summed in float); tubes without a common frame
+    // are at distance max and never chosen.  The exact distance is only evaluated where a bound
+    // computed with plain square roots says it can be below the best one so far.
+    auto closest = [&](int k) {
+      float best = std::numeric_limits<float>::max();
+      int best_idx = -1;
+      const Tube& tk = done[k];
+      double skip_above = std::numeric_limits<double>::infinity();
+      for (const TSlice& sl : tk) {
+        std::vector<int>& ids = in_frame[(size_t)(sl.frame - frame_lo)];
+        size_t w = 0;
+        for (size_t q = 0; q < ids.size(); ++q) {
+          const int l = ids[q];
+          if (!live[l]) continue;          // joined away: drop the entry
+          ids[w++] = l;
+          if (l == k || seen[l] == k) continue;
+          seen[l] = k;
+          double bound = 0;
+          int common = 0;
+          for (const TSlice& a : tk) {
+            const V2 cl = centre_at[(size_t)(a.frame - frame_lo) * T + l];
+            if (cl.x != cl.x) continue;
+            const V2 dc = Sub(a.shape.center, cl);
+            bound += std::sqrt((double)dc.x * (double)dc.x + (double)dc.y * (double)dc.y);
+            ++common;
+          }
+          if (bound > skip_above * (double)common) continue;
+          float sum = 0;
+          for (const TSlice& a : tk) {
+            const V2 cl = centre_at[(size_t)(a.frame - frame_lo) * T + l];
+            if (cl.x != cl.x) continue;
+            const V2 dc = Sub(a.shape.center, cl);
+            sum = (float)((double)sum + std::hypot((double)dc.y, (double)dc.x));
+          }
+          const float d = sum / (float)common;
+          if (d < best || (d == best && best_idx >= 0 && l < best_idx)) {
+            best = d;
+            best_idx = l;
+            // the float sums round at every frame: 1e-4 covers more frames than a chunk has
+            skip_above = (double)best * (1.0 + 1e-4);
+          }
+        }
+        ids.resize(w);
+      }
+      return best_idx;
+    };
     // pass 1: small or overlapping tubes join their closest tube (:795-816)
-    for (int k = 0; k < (int)done.size();) {
+    for (int k = nxt[T]; k != T;) {
       bool merge = MeanSliceSize(done[k]) < 20;
       if (!merge) {
-        for (int l = 0; l < (int)done.size(); ++l) {
+        // a tube without a common frame counts as overlapping (the fraction of no frames is
+        // max): look for one whose frames lie before or after this tube's first
+        const int k0 = done[k][0].frame, k1 = done[k].back().frame;
+        for (int l = nxt[T]; l != T && !merge; l = nxt[l]) {
+          merge = l != k && (done[l].back().frame < k0 || done[l][0].frame > k1);
+        }
+      }
+      if (!merge) {
+        for (int l = nxt[T]; l != T; l = nxt[l]) {
           if (l != k && (double)BoxOverlapFraction(done[k], done[l]) > 0.8) {
             merge = true;
             break;
           }
         }
       }
-      bool merged = false;
+      const int after = nxt[k];
       if (merge) {
-        const int idx = ClosestTube(done[k], done, k);
+        const int idx = closest(k);
         if (idx >= 0) {
           Tube j;
-          JoinTubes(done[idx], done[k], &j);
+          gained.clear();
+          JoinTubes(&done[idx], &done[k], &j, &gained);
           done[idx].swap(j);
-          done.erase(done.begin() + k);
-          merged = true;
+          for (int f : gained) in_frame[(size_t)(f - frame_lo)].push_back(idx);
+          note_centres(idx);
+          unlink(k);
         }
       }
-      if (!merged) ++k;
+      k = after;
     }
     // pass 2: tubes abutting in time (:819-839)
-    for (int k = 0; k < (int)done.size();) {
-      bool merged = false;
-      for (int l = 0; l < (int)done.size(); ++l) {
+    for (int k = nxt[T]; k != T;) {
+      const int after = nxt[k];
+      for (int l = nxt[T]; l != T; l = nxt[l]) {
         if (l == k) continue;
         if (TemporalNeighbors(done[k], done[l])) {
           Tube j;
-          JoinTubes(done[k], done[l], &j);
+          JoinTubes(&done[k], &done[l], &j, nullptr);
           done[l].swap(j);
-          done.erase(done.begin() + k);
-          merged = true;
+          unlink(k);
           break;
         }
       }
-      if (!merged) ++k;
+      k = after;
     }
+    size_t w = 0;
+    for (int k = nxt[T]; k != T; k = nxt[k]) {
+      if ((size_t)k != w) done[w].swap(done[k]);
+      ++w;
+    }
+    done.resize(w);
   }
 
   // largest tube keeps the region (:841-861)
@@ -819,3 +922,8 @@ void RenderIdImage(const SegDesc& d, int W, int32_t* out) {
 }
 
 }  // namespace vsg
+
+#ifdef VSG_TEST_MODELS
+// tests/test_tube_analysis.py compiles this file with the plain restatement of Finish beside it
+#include "../../tests/host/tube_plain_model.inc"
+#endif
