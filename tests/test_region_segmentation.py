@@ -206,3 +206,57 @@ def test_foreign_or_corrupt_oversegmentation_is_rejected(vsg):
     with pytest.raises(VsgError, match="outside the frame"):
         vsg.RegionSegmentation(W, H).process_frame(inverted.SerializeToString(), frame)
     assert vsg.RegionSegmentation(W, H).process_frame(good, frame, flush=True) == 1   # the intact one is fine
+
+
+def _descriptor_stress_frame(W, H, k):
+    """Low-contrast blocks (neighbouring regions have to share histogram bins, or the reference
+    aborts) around a grey whose 8-bit L is exactly on a luminance bin (L = 85: the weight of the upper
+    bin is 0 and both weights go to one bin), one block of that exact grey without noise, a noisy
+    gradient; intervals longer than one accumulation batch (128 px)."""
+    rng = np.random.default_rng(100 + k)
+    ramp = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)
+    L = ol.bgr_to_lab(ramp)[0, :, 0]
+    grey = int(np.argmin(np.abs(L.astype(int) - 85)))
+    assert L[grey] == 85
+    img = np.empty((H, W, 3), np.int64)
+    x = np.arange(W)[None, :]
+    y = np.arange(H)[:, None]
+    img[..., 0] = grey - 6 + (x * 12) // W
+    img[..., 1] = grey - 4 + (y * 8) // H
+    img[..., 2] = grey + 5 * (((x + 3 * k) // (W // 3)) % 2)
+    img += rng.integers(-1, 2, (H, W, 3))
+    img[: H // 4, : W // 2] = grey                      # exact grey, no noise: L on a bin
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _descriptor_stress_flow(W, H, k):
+    rng = np.random.default_rng(500 + k)
+    fl = rng.normal(0, 2.0, (H, W, 2)).astype(np.float32)
+    fl[: H // 5] = 0.0                                   # atan2(0, 0)
+    fl[H // 5: 2 * H // 5, :, 0] = -0.0
+    fl[H // 5: 2 * H // 5, :, 1] = np.where(rng.random((H // 5 * 1, W)) < 0.5, 0.0, -0.0)[: fl[H // 5: 2 * H // 5].shape[0]]
+    fl[2 * H // 5: 3 * H // 5, : W // 2] = (-2.0, 0.0)   # on the last bin's upper edge
+    fl[2 * H // 5: 3 * H // 5, W // 2:] = (0.0, 3.0)     # axis aligned
+    fl[3 * H // 5: 4 * H // 5, ::2] = (1.5, -1.5)        # diagonal, alternating with random vectors
+    return fl
+
+
+def test_descriptor_passes_on_varied_colours_and_flow(vsg, monkeypatch):
+    """The descriptor passes of AddOverSegmentation beyond what the small constant-flow cases reach:
+    per-pixel flow in every direction (zero vectors, negative zeros, axes, bin edges), colours on bin
+    positions, intervals longer than an accumulation batch, several host threads."""
+    monkeypatch.setenv("VSG_PARALLEL_MIN_WORK", "1")
+    W, H, N, chunk = 300, 100, 16, 8
+    o = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
+    frames = [_descriptor_stress_frame(W, H, k) for k in range(N)]
+    flows = [None] + [_descriptor_stress_flow(W, H, k) for k in range(1, N)]
+    segs = []
+    for k in range(N):
+        n = o.process_frame(frames[k], flows[k], flush=(k == N - 1))
+        segs += [o.result_bytes(i) for i in range(n)]
+    o.close()
+    feed = [(frames[k], flows[k], segs[k]) for k in range(N)]
+    got, want = run_both(vsg, W, H, feed, dict(chunk_set_size=2, chunk_set_overlap=1, min_region_num=3))
+    assert len(want) == N
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g == w, "hierarchical SegmentationDesc %d differs" % k

@@ -20,6 +20,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <exception>
+#include <ctime>
 #include <functional>
 #include <limits>
 #include <thread>
@@ -102,6 +104,16 @@ inline int DescaleBy(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 inline uint8_t ClampByte(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
 }  // namespace
+
+// VSG_DEBUG_STATS: CPU time of the descriptor passes summed over the host threads, and the longest
+// single region per frame (what bounds the frame when the regions are few and large)
+static std::atomic<long long> g_cpu_color_us(0), g_cpu_flow_us(0), g_longest_us(0);
+static bool g_debug_stats = getenv("VSG_DEBUG_STATS") != nullptr;
+static long long ThreadCpuUs() {
+  timespec ts;
+  clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+  return (long long)ts.tv_sec * 1000000 + ts.tv_nsec / 1000;
+}
 
 static double NowMs() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -221,43 +233,92 @@ struct ColorHist {
     const uint32_t epoch = sc->epoch;
     float* acc = sc->acc.data();
     uint32_t* stamp = sc->stamp.data();
-    const int sq = color_bins * color_bins;
+    const int sq = color_bins * color_bins, cb = color_bins;
     const float s0 = (float)(lum_bins - 1), s12 = (float)(color_bins - 1);
     size_t pixels = 0;
+    // In batches: first the bins and the eight weights of every pixel (no dependence between
+    // pixels: the compiler vectorizes these loops), then the sums, pixel by pixel and bin by bin in
+    // the order of AddLabPixel.  Neighbouring pixels mostly fall between the same bins: over such a
+    // run the eight sums stay in registers.
+    constexpr int kBatch = 128;
+    float pos[3][kBatch], frac[3][kBatch], value[8][kBatch];
+    int lo[3][kBatch], base[kBatch], steps[kBatch];
+    auto touch = [&](int k) {
+      if (stamp[k] != epoch) {
+        stamp[k] = epoch;
+        sc->touched.push_back(k);
+        auto it = bins.find(k);
+        acc[k] = it != bins.end() ? it->second : 0.0f;
+      }
+    };
     for (const Interval& iv : raster) {
-      const uint8_t* px = lab + ((size_t)iv.y * W + iv.lx) * 3;
-      for (int x = iv.lx; x <= iv.rx; ++x, px += 3) {
-        const float pos[3] = {(float)px[0] * (1.0f / 255.f) * s0, (float)px[1] * (1.0f / 255.f) * s12,
-                              (float)px[2] * (1.0f / 255.f) * s12};
-        int lo[3], hi[3];
-        float w_lo[3], w_hi[3];
-        for (int c = 0; c < 3; ++c) {
-          lo[c] = (int)pos[c];
-          const float frac = pos[c] - (float)lo[c];
-          hi[c] = lo[c] + (frac >= 1e-6f);
-          w_lo[c] = 1.0f - frac;
-          w_hi[c] = frac;
+      for (int x0 = iv.lx; x0 <= iv.rx; x0 += kBatch) {
+        const int m = std::min(kBatch, iv.rx - x0 + 1);
+        const uint8_t* px = lab + ((size_t)iv.y * W + x0) * 3;
+        for (int i = 0; i < m; ++i) {
+          pos[0][i] = (float)px[3 * i] * (1.0f / 255.f) * s0;
+          pos[1][i] = (float)px[3 * i + 1] * (1.0f / 255.f) * s12;
+          pos[2][i] = (float)px[3 * i + 2] * (1.0f / 255.f) * s12;
         }
-        for (int a = 0; a < 2; ++a) {
-          const int slice = (a ? hi[0] : lo[0]) * sq;
-          const float wa = a ? w_hi[0] : w_lo[0];
-          for (int b = 0; b < 2; ++b) {
-            const int row = slice + (b ? hi[1] : lo[1]) * color_bins;
-            const float wb = b ? w_hi[1] : w_lo[1];
-            for (int c = 0; c < 2; ++c) {
-              const float value = wa * wb * (c ? w_hi[2] : w_lo[2]) * 1.0f;
-              const int k = row + (c ? hi[2] : lo[2]);
-              if (stamp[k] != epoch) {
-                stamp[k] = epoch;
-                sc->touched.push_back(k);
-                auto it = bins.find(k);
-                acc[k] = it != bins.end() ? it->second : 0.0f;
-              }
-              acc[k] += value;
-            }
+        for (int c = 0; c < 3; ++c) {
+          for (int i = 0; i < m; ++i) {
+            const int l = (int)pos[c][i];
+            lo[c][i] = l;
+            frac[c][i] = pos[c][i] - (float)l;
           }
         }
-        ++pixels;
+        for (int i = 0; i < m; ++i) {
+          base[i] = lo[0][i] * sq + lo[1][i] * cb + lo[2][i];
+          // hi = lo + (frac >= 1e-6) per channel
+          steps[i] = (frac[0][i] >= 1e-6f ? 4 : 0) | (frac[1][i] >= 1e-6f ? 2 : 0) | (frac[2][i] >= 1e-6f ? 1 : 0);
+        }
+        for (int i = 0; i < m; ++i) {
+          const float wa[2] = {1.0f - frac[0][i], frac[0][i]};
+          const float wb[2] = {1.0f - frac[1][i], frac[1][i]};
+          const float wc[2] = {1.0f - frac[2][i], frac[2][i]};
+          for (int j = 0; j < 8; ++j) value[j][i] = wa[j >> 2] * wb[(j >> 1) & 1] * wc[j & 1] * 1.0f;
+        }
+        for (int i = 0; i < m;) {
+          int e = i + 1;
+          while (e < m && base[e] == base[i] && steps[e] == steps[i]) ++e;
+          const int st = steps[i];
+          int k[8];
+          for (int j = 0; j < 8; ++j) {
+            k[j] = base[i] + ((j & 4) && (st & 4) ? sq : 0) + ((j & 2) && (st & 2) ? cb : 0) + ((j & 1) && (st & 1) ? 1 : 0);
+          }
+          if (st == 7) {   // eight different bins
+            for (int j = 0; j < 8; ++j) touch(k[j]);
+            float a0 = acc[k[0]], a1 = acc[k[1]], a2 = acc[k[2]], a3 = acc[k[3]];
+            float a4 = acc[k[4]], a5 = acc[k[5]], a6 = acc[k[6]], a7 = acc[k[7]];
+            for (int q = i; q < e; ++q) {
+              a0 += value[0][q];
+              a1 += value[1][q];
+              a2 += value[2][q];
+              a3 += value[3][q];
+              a4 += value[4][q];
+              a5 += value[5][q];
+              a6 += value[6][q];
+              a7 += value[7][q];
+            }
+            acc[k[0]] = a0;
+            acc[k[1]] = a1;
+            acc[k[2]] = a2;
+            acc[k[3]] = a3;
+            acc[k[4]] = a4;
+            acc[k[5]] = a5;
+            acc[k[6]] = a6;
+            acc[k[7]] = a7;
+          } else {         // a channel exactly on a bin: two weights go to the same bin, one after the other
+            for (int q = i; q < e; ++q) {
+              for (int j = 0; j < 8; ++j) {
+                touch(k[j]);
+                acc[k[j]] += value[j][q];
+              }
+            }
+          }
+          i = e;
+        }
+        pixels += (size_t)m;
       }
     }
     for (int k : sc->touched) bins[k] = acc[k];   // (a new bin is inserted here: first-touch order)
@@ -357,6 +418,69 @@ struct FlowHist {
     return (float)(0.5 * sum);
   }
 };
+
+// What FlowHist::Add computes from a flow vector -- its bin and its magnitude -- for every pixel of
+// a frame, on all host threads: a region's histogram is a sequential float sum over its pixels, a
+// frame of a few very large regions would otherwise leave most threads idle while one of them
+// evaluates atan2 and hypot 700 K times.  The sums stay sequential, per region (ChunkSet::AddFrame).
+struct FlowSamples {
+  std::vector<uint16_t> bin;
+  std::vector<double> magnitude;
+  bool valid = false;
+  void Compute(const float* flow, int W, int H, int num_bins) {
+    bin.resize((size_t)W * H);
+    magnitude.resize((size_t)W * H);
+    const int band = 16;
+    ParallelItems((H + band - 1) / band, (size_t)W * H, [&](int item, int) {
+      uint32_t last_x = 0, last_y = 0;
+      uint16_t last_bin = 0;
+      double last_mag = 0;
+      bool have_last = false;
+      for (int y = item * band; y < std::min(H, (item + 1) * band); ++y) {
+        const float* p = flow + (size_t)y * W * 2;
+        uint16_t* b = bin.data() + (size_t)y * W;
+        double* m = magnitude.data() + (size_t)y * W;
+        for (int x = 0; x < W; ++x, p += 2) {
+          uint32_t ux, uy;
+          std::memcpy(&ux, p, 4);
+          std::memcpy(&uy, p + 1, 4);
+          if (!have_last || ux != last_x || uy != last_y) {   // (the same bits give the same values)
+            const float angle = (float)(std::atan2((double)p[1], (double)p[0]) / (2.0 * M_PI + 1e-4) + 0.5);
+            last_bin = (uint16_t)(size_t)(angle * num_bins);
+            last_mag = std::hypot((double)p[0], (double)p[1]);
+            last_x = ux;
+            last_y = uy;
+            have_last = true;
+          }
+          b[x] = last_bin;
+          m[x] = last_mag;
+        }
+      }
+    });
+    valid = true;
+  }
+};
+
+// FlowHist::Add for every pixel of a raster, in pixel order, from the samples of the frame; the sum
+// of a run of one bin stays in a register.
+void AccumulateFlow(const FlowSamples& samples, int W, const Raster& raster, FlowHist* F) {
+  for (const Interval& iv : raster) {
+    const size_t at = (size_t)iv.y * W + iv.lx;
+    const uint16_t* b = samples.bin.data() + at;
+    const double* m = samples.magnitude.data() + at;
+    const int len = iv.rx - iv.lx + 1;
+    for (int x = 0; x < len;) {
+      const int bin = b[x];
+      float sum = F->bins[(size_t)bin];
+      do {
+        sum = (float)((double)sum + m[x]);
+        ++x;
+      } while (x < len && b[x] == bin);
+      F->bins[(size_t)bin] = sum;
+    }
+    F->num_vectors += len;
+  }
+}
 
 struct Descriptors {
   bool present = false;                          // false: a fresh super-region before its first merge
@@ -804,7 +928,7 @@ class ChunkSet {
 
   // AddOverSegmentation: rasters and descriptor samples of one frame.  The regions of a frame are
   // independent (one node each): their pixels are visited on several host threads.
-  void AddFrame(const SegDesc& d, const uint8_t* lab, const float* flow) {
+  void AddFrame(const SegDesc& d, const uint8_t* lab, const float* flow, const FlowSamples* samples) {
     std::vector<Node*> nodes;
     nodes.reserve(d.regions.size());
     size_t pixels = 0;
@@ -826,18 +950,40 @@ class ChunkSet {
     }
     if (scratch_.size() < (size_t)ParallelSlots()) scratch_.resize((size_t)ParallelSlots());
     const int frame = frames_;
-    ParallelItems((int)nodes.size(), pixels, [&](int i, int t) {
-      const Region2DOut& r = d.regions[(size_t)i];
-      Node* n = nodes[(size_t)i];
-      if (S_.appearance) n->desc.color->AddLabPixels(lab, W_, r.raster, &scratch_[(size_t)t]);
-      if (S_.flow && flow) {
-        FlowHist& F = *n->desc.flow[(size_t)(frame - n->desc.flow_start)];
-        for (const Interval& iv : r.raster) {
-          const float* p = flow + ((size_t)iv.y * W_ + iv.lx) * 2;
-          for (int x = iv.lx; x <= iv.rx; ++x, p += 2) F.Add(p[0], p[1]);
-        }
+    std::atomic<long long> longest_us(0);
+    // One task per region and descriptor, the largest first: a frame of a few very large regions
+    // is bounded by its longest task.
+    struct Task {
+      int region;
+      bool flow;
+      size_t cost;
+    };
+    std::vector<Task> tasks;
+    for (int i = 0; i < (int)nodes.size(); ++i) {
+      size_t px = 0;
+      for (const Interval& iv : d.regions[(size_t)i].raster) px += (size_t)(iv.rx - iv.lx + 1);
+      if (S_.appearance) tasks.push_back(Task{i, false, 2 * px});
+      if (S_.flow && flow) tasks.push_back(Task{i, true, px});
+    }
+    std::stable_sort(tasks.begin(), tasks.end(), [](const Task& a, const Task& b) { return a.cost > b.cost; });
+    ParallelItems((int)tasks.size(), pixels, [&](int ti, int t) {
+      const Task& task = tasks[(size_t)ti];
+      const Region2DOut& r = d.regions[(size_t)task.region];
+      Node* n = nodes[(size_t)task.region];
+      const long long c0 = g_debug_stats ? ThreadCpuUs() : 0;
+      if (!task.flow) {
+        n->desc.color->AddLabPixels(lab, W_, r.raster, &scratch_[(size_t)t]);
+      } else {
+        AccumulateFlow(*samples, W_, r.raster, n->desc.flow[(size_t)(frame - n->desc.flow_start)].get());
+      }
+      if (g_debug_stats) {
+        const long long c2 = ThreadCpuUs();
+        (task.flow ? g_cpu_flow_us : g_cpu_color_us) += c2 - c0;
+        long long longest = longest_us.load();
+        while (c2 - c0 > longest && !longest_us.compare_exchange_weak(longest, c2 - c0)) {}
       }
     });
+    g_longest_us += longest_us.load();
     ++frames_;
   }
 
@@ -1091,6 +1237,7 @@ class ChunkSet {
 // ---------------------------------------------------------------------------------------------
 struct RegionSegmentationHost::Impl {
   double ms_lab = 0, ms_add = 0, ms_out = 0;   // VSG_DEBUG_STATS
+  double ms_build = 0, ms_ids = 0, ms_retrieve = 0;
   int frames_in = 0;
   RegionSegOptions o;
   Setup S;
@@ -1099,6 +1246,7 @@ struct RegionSegmentationHost::Impl {
   std::unique_ptr<ChunkSet> cur, next;
   std::vector<int> id_offsets;
   std::vector<uint8_t> lab;
+  FlowSamples flow_samples;   // of the frame being added
 
   void Output(bool flush, std::vector<std::unique_ptr<SegDesc>>* results) {   // ChunkBoundaryOutput
     if (!flush) {
@@ -1116,7 +1264,9 @@ struct RegionSegmentationHost::Impl {
   }
 
   void Segment(int overlap_at, int lookahead_at, std::vector<std::unique_ptr<SegDesc>>* results) {   // SegmentAndOutputChunk
+    const double t0 = NowMs();
     cur->BuildHierarchy();
+    const double t1 = NowMs();
     if (cur->levels() > (int)id_offsets.size()) id_offsets.resize((size_t)cur->levels(), 0);
     cur->ClipToFrames(lookahead_at, overlap_at);
     std::vector<int> next_offsets(id_offsets.size());
@@ -1124,16 +1274,33 @@ struct RegionSegmentationHost::Impl {
     id_offsets.swap(next_offsets);
     if (next) next->PullConstraints(*cur);
     cur->DropBaseLevel();
+    const double t2 = NowMs();
     const int first_frame = output_frames;
-    for (int f = 0; f < overlap_at; ++f) {
-      std::unique_ptr<SegDesc> d(new SegDesc());
-      cur->Retrieve(f, f == 0, d.get());
-      d->hierarchy_frame_idx = first_frame;
-      d->chunk_size = lookahead_at;
-      d->overlap_start = overlap_at;
+    // The frames of the chunk set are independent (rasters of the frame, moments, boundary
+    // vectorization): one task per frame.
+    std::vector<std::unique_ptr<SegDesc>> frames((size_t)std::max(overlap_at, 0));
+    std::exception_ptr failure;
+    std::atomic<bool> failed(false);
+    ParallelItems(overlap_at, (size_t)overlap_at * (size_t)W * H, [&](int f, int) {
+      try {
+        std::unique_ptr<SegDesc> d(new SegDesc());
+        cur->Retrieve(f, f == 0, d.get());
+        d->hierarchy_frame_idx = first_frame;
+        d->chunk_size = lookahead_at;
+        d->overlap_start = overlap_at;
+        frames[(size_t)f] = std::move(d);
+      } catch (...) {
+        if (!failed.exchange(true)) failure = std::current_exception();
+      }
+    });
+    if (failed) std::rethrow_exception(failure);
+    for (auto& d : frames) {
       results->push_back(std::move(d));
       ++output_frames;
     }
+    ms_build += t1 - t0;
+    ms_ids += t2 - t1;
+    ms_retrieve += NowMs() - t2;
     ++chunk_sets;
   }
 };
@@ -1159,6 +1326,11 @@ RegionSegmentationHost::~RegionSegmentationHost() {
   if (getenv("VSG_DEBUG_STATS") && impl_) {
     std::fprintf(stderr, "[vsg] region segmentation: lab %.1f ms, descriptors %.1f ms, hierarchy + output %.1f ms over %d frames\n",
                  impl_->ms_lab, impl_->ms_add, impl_->ms_out, impl_->frames_in);
+    std::fprintf(stderr, "[vsg]   hierarchy %.1f ms, clip + ids %.1f ms, retrieve %.1f ms\n", impl_->ms_build, impl_->ms_ids,
+                 impl_->ms_retrieve);
+    std::fprintf(stderr, "[vsg]   descriptor passes, CPU over all threads: colour %.1f ms, flow %.1f ms; longest region of every "
+                 "frame summed: %.1f ms\n", g_cpu_color_us.exchange(0) * 1e-3, g_cpu_flow_us.exchange(0) * 1e-3,
+                 g_longest_us.exchange(0) * 1e-3);
   }
 }
 
@@ -1179,6 +1351,7 @@ int RegionSegmentationHost::ProcessFrame(bool flush, const SegDesc* overseg, con
       I.lab.resize((size_t)I.W * I.H * 3);
       BgrToLab8(bgr, stride, I.W, I.H, I.lab.data());
     }
+    if (I.S.flow && flow) I.flow_samples.Compute(flow, I.W, I.H, I.S.flow_bins);
     I.ms_lab += NowMs() - t_lab;
     ++I.frames_in;
     const bool starts_chunk = overseg->has_hierarchy;
@@ -1199,11 +1372,11 @@ int RegionSegmentationHost::ProcessFrame(bool flush, const SegDesc* overseg, con
         I.cur->AddBaseLevel(overseg->hierarchy0, nullptr, shared);
         I.next->AddBaseLevel(overseg->hierarchy0, shared, nullptr);
       }
-      I.cur->AddFrame(*overseg, I.lab.data(), flow);
-      I.next->AddFrame(*overseg, I.lab.data(), flow);
+      I.cur->AddFrame(*overseg, I.lab.data(), flow, &I.flow_samples);
+      I.next->AddFrame(*overseg, I.lab.data(), flow, &I.flow_samples);
     } else {
       if (starts_chunk) I.cur->AddBaseLevel(overseg->hierarchy0, nullptr, nullptr);
-      I.cur->AddFrame(*overseg, I.lab.data(), flow);
+      I.cur->AddFrame(*overseg, I.lab.data(), flow, &I.flow_samples);
     }
     if (phase >= lookahead_from && I.lookahead_start < 0) I.lookahead_start = I.cur->frames();
     I.ms_add += NowMs() - t_add;
@@ -1225,3 +1398,9 @@ const std::string& RegionSegmentationHost::result_bytes(int i) {
 }
 
 }  // namespace vsg
+
+#ifdef VSG_TEST_MODELS
+// tests/test_descriptor_passes.py compiles this file with a test entry that compares the batched
+// passes above with the per-pixel ones (AddLabPixel, FlowHist::Add)
+#include "../../tests/host/descriptor_model.inc"
+#endif
