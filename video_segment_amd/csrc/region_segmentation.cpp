@@ -423,6 +423,36 @@ struct FlowHist {
 // a frame, on all host threads: a region's histogram is a sequential float sum over its pixels, a
 // frame of a few very large regions would otherwise leave most threads idle while one of them
 // evaluates atan2 and hypot 700 K times.  The sums stay sequential, per region (ChunkSet::AddFrame).
+// The bin FlowHist::Add puts a vector in -- (size_t)((float)(atan2(y, x) / (2 pi + 1e-4) + 0.5) * n)
+// -- from a polynomial arctangent (Abramowitz & Stegun 4.4.49, |error| <= 2e-8 rad) where that
+// cannot be wrong: the bin position it gives has to be at least 1e-4 of a bin away from a bin edge,
+// 25 times what the polynomial, the float rounding of the angle and of the product can move it
+// together.  Returns -1 otherwise (edges, axes, zero and non-finite vectors: the caller evaluates
+// atan2).
+inline int FastFlowBin(float x, float y, int num_bins) {
+  const double ax = std::fabs((double)x), ay = std::fabs((double)y);
+  const double mx = std::max(ax, ay), mn = std::min(ax, ay);
+  if (!(mx > 0) || !(mx <= std::numeric_limits<double>::max())) return -1;
+  const double z = mn / mx, z2 = z * z;
+  double p = 0.0028662257;
+  p = p * z2 - 0.0161657367;
+  p = p * z2 + 0.0429096138;
+  p = p * z2 - 0.0752896400;
+  p = p * z2 + 0.1065626393;
+  p = p * z2 - 0.1420889944;
+  p = p * z2 + 0.1999355085;
+  p = p * z2 - 0.3333314528;
+  p = p * z2 + 1.0;
+  double a = z * p;
+  if (ay > ax) a = M_PI / 2 - a;
+  if (x < 0) a = M_PI - a;
+  if (y < 0) a = -a;
+  const double t = (a / (2.0 * M_PI + 1e-4) + 0.5) * num_bins;
+  const double cell = std::floor(t), d = t - cell;
+  if (d < 1e-4 || d > 1.0 - 1e-4 || cell < 0 || cell >= num_bins) return -1;
+  return (int)cell;
+}
+
 struct FlowSamples {
   std::vector<uint16_t> bin;
   std::vector<double> magnitude;
@@ -445,8 +475,13 @@ struct FlowSamples {
           std::memcpy(&ux, p, 4);
           std::memcpy(&uy, p + 1, 4);
           if (!have_last || ux != last_x || uy != last_y) {   // (the same bits give the same values)
-            const float angle = (float)(std::atan2((double)p[1], (double)p[0]) / (2.0 * M_PI + 1e-4) + 0.5);
-            last_bin = (uint16_t)(size_t)(angle * num_bins);
+            const int fast = FastFlowBin(p[0], p[1], num_bins);
+            if (fast >= 0) {
+              last_bin = (uint16_t)fast;
+            } else {
+              const float angle = (float)(std::atan2((double)p[1], (double)p[0]) / (2.0 * M_PI + 1e-4) + 0.5);
+              last_bin = (uint16_t)(size_t)(angle * num_bins);
+            }
             last_mag = std::hypot((double)p[0], (double)p[1]);
             last_x = ux;
             last_y = uy;
