@@ -360,7 +360,9 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps, out):
     # RegionSegmentation (host) on top of it.  Input: the low-contrast variant of the generator --
     # on the bench input itself the reference's RegionAgglomerationGraph aborts (neighbouring
     # checker cells are at distance exactly 1.0, region_segmentation_graph.cpp:165).
-    nh = chunk + (chunk - 1)
+    # five chunks: with two the stream is all pipeline fill and drain (the hierarchical unit only
+    # starts when the dense one has finished its first chunk)
+    nh = chunk + 4 * (chunk - 1)
     fh = make_frames("soft", w4, h4, nh, dev)
     fh_host = [f.cpu().numpy() for f in fh]
     flh = synth.const_flow(w4, h4)

@@ -119,12 +119,15 @@ static double NowMs() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// fn(i) for i in [0, n), on up to 16 host threads (dynamic: the items are of very different sizes);
-// fn must not throw.
+// fn(i) for i in [0, n), on up to 16 host threads (32 on hosts with 64 or more: a 4K frame has 24
+// descriptor tasks); dynamic, the items are of very different sizes; fn must not throw.
+static int ParallelSlots(int hw) { return hw >= 64 ? 32 : 16; }
+static int ParallelSlots() { return ParallelSlots((int)std::thread::hardware_concurrency()); }
+
 static void ParallelItems(int n, size_t work, const std::function<void(int, int)>& fn) {
   const int hw = (int)std::thread::hardware_concurrency();
   const size_t min_work = getenv("VSG_PARALLEL_MIN_WORK") ? (size_t)atoll(getenv("VSG_PARALLEL_MIN_WORK")) : 65536;
-  const int threads = (int)std::min<size_t>((size_t)std::max(1, std::min(std::max(hw, 2), 16)),
+  const int threads = (int)std::min<size_t>((size_t)std::max(1, std::min(std::max(hw, 2), ParallelSlots(hw))),
                                             std::max<size_t>(1, work / std::max<size_t>(min_work, 1)));
   if (threads <= 1 || n <= 1) {
     for (int i = 0; i < n; ++i) fn(i, 0);
@@ -139,7 +142,7 @@ static void ParallelItems(int n, size_t work, const std::function<void(int, int)
   body(0);
   for (std::thread& t : pool) t.join();
 }
-static int ParallelSlots() { return 16; }
+
 
 void BgrToLab8(const uint8_t* src, size_t stride, int W, int H, uint8_t* dst) {
   static const LabTables T;
