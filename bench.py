@@ -636,6 +636,11 @@ def main():
             # (the counter passes are a run of their own, with their own number of launches: the
             # algorithmic bytes per launch OF THAT RUN are what the traffic is to be held against)
             traffic_same_run = pmc.get("algorithmic_bytes_per_launch_same_run")
+        # algorithmic bytes per launch of BOTH replay kernels in this run: under the counter passes
+        # the slower clock of the instrumented run can make the other kernel the dominant one
+        alg_by_kernel = {
+            "wave": WAVE_BYTES_PER_EDGE * acc["wave_edges"] / max(acc["wave_launches"], 1),
+            "spine": SPINE_BYTES_PER_EDGE * acc["spine_edges"] / max(acc["spine_launches"], 1)}
         copy_gbps = measured_copy_bandwidth(dev) if args.mode == "streams" else None
         out = {
             "metric": "over-segmented frames/sec at 1080p",
@@ -671,6 +676,7 @@ def main():
                 "traffic": traffic,
                 "traffic_unit": "B/launch",
                 "traffic_note": traffic_note,
+                "algorithmic_bytes_per_launch_by_kernel": alg_by_kernel,
                 "traffic_vs_algorithmic_same_run": (traffic / traffic_same_run) if (traffic and traffic_same_run)
                 else None,
                 "peak_measured": copy_gbps,

@@ -102,6 +102,7 @@ def main():
                 r = json.loads(line)["roofline"]
                 tag = "spine" if "k_spine" in r["kernel"] else "wave"
                 same_run[tag] = r["bytes_per_launch"]
+                same_run.update(r.get("algorithmic_bytes_per_launch_by_kernel", {}))
     if wave_json:
         for name, e in out.items():
             for kern, tag in (("k_merge_wave", "wave"), ("k_spine", "spine")):
