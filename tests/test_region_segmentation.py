@@ -260,3 +260,33 @@ def test_descriptor_passes_on_varied_colours_and_flow(vsg, monkeypatch):
     assert len(want) == N
     for k, (g, w) in enumerate(zip(got, want)):
         assert g == w, "hierarchical SegmentationDesc %d differs" % k
+
+
+def test_lab_conversion_against_opencv_when_present(vsg):
+    """BgrToLab8 restates cv::cvtColor(BGR2Lab) for 8-bit images (fixed-point RGB2Lab_b of the
+    OpenCV 2.4 line the reference links; un-vendored third-party arithmetic, parity unpinned in this
+    image: no cv2).  Where an OpenCV is importable this pins it: exhaustive over every value of each
+    channel against mid-grey partners, the grey ramp, and random colours.  OpenCV >= 3.3 changed the
+    coefficient rounding and the cube-root tables of this conversion (values may differ by 1 there);
+    the version the comparison ran against is part of the failure message."""
+    cv2 = pytest.importorskip("cv2")
+    rng = np.random.default_rng(11)
+    imgs = [rng.integers(0, 256, (64, 257, 3), dtype=np.uint8),
+            np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)]
+    for ch in range(3):
+        im = np.full((3, 256, 3), 128, np.uint8)
+        im[0, :, ch] = np.arange(256)
+        im[1, :, ch] = np.arange(256)
+        im[1, :, (ch + 1) % 3] = 30
+        im[2, :, ch] = np.arange(256)
+        im[2, :, (ch + 2) % 3] = 220
+        imgs.append(im)
+    for im in imgs:
+        want = cv2.cvtColor(im, cv2.COLOR_BGR2Lab)
+        got = vsg.bgr_to_lab(im)
+        diff = np.abs(got.astype(int) - want.astype(int))
+        major = int(cv2.__version__.split(".")[0])
+        if major < 3:
+            assert diff.max() == 0, "differs from cv2 %s (the 2.4 line is what the reference links)" % cv2.__version__
+        else:
+            assert diff.max() <= 1, "differs by more than 1 from cv2 %s" % cv2.__version__
