@@ -189,8 +189,7 @@ int vsg_chain_exchange_halo(vsg_chain* c, vsg_stream* from, int dst, vsg_stream*
  * the clustering works on a few thousand regions per chunk set (see region_segmentation.h); no HIP
  * device is needed for these entry points. */
 typedef struct vsg_regionseg vsg_regionseg;
-/* Mirrors segmentation::RegionSegmentationOptions (region_segmentation.h:41-83; save_descriptors
- * is not supported). */
+/* Mirrors segmentation::RegionSegmentationOptions (region_segmentation.h:41-83). */
 typedef struct vsg_regionseg_options {
   int min_region_num;             /* 10    */
   int max_region_num;             /* 10000 */
@@ -206,6 +205,9 @@ typedef struct vsg_regionseg_options {
   int use_flow;                   /* 1: RegionSegmentationUnit sets it to "a flow stream exists" */
   int use_size_penalizer;         /* 1 */
   int compute_vectorization;      /* 1 */
+  int save_descriptors;           /* 0; 1 = SegmentationDesc.features on hierarchy frames: one RegionFeatures
+                                   * { id } per region (segmentation.cpp:490-501; the descriptors of this
+                                   * path add no extension to it, region_descriptor.cpp:137-138) */
 } vsg_regionseg_options;
 void vsg_regionseg_default_options(vsg_regionseg_options* o);
 int vsg_regionseg_create(const vsg_regionseg_options* o, int width, int height, vsg_regionseg** out);

@@ -92,6 +92,7 @@ struct SegmentationDesc {
   int connectedness = 1;  // N4_CONNECT = 1, N8_CONNECT = 2
   bool has_vector_mesh = false;
   std::vector<float> vector_mesh;   // VectorMesh.coord: x, y pairs
+  std::vector<uint32_t> features;   // SegmentationDesc.features: RegionFeatures.id (save_descriptors)
 };
 
 // proto2 wire encoding of SegmentationDesc (field numbers from segmentation.proto:55-172;
@@ -177,6 +178,12 @@ static std::string Encode(const SegmentationDesc& d) {
   Int32(&out, 7, d.overlap_start);
   Int32(&out, 8, d.chunk_id);
   Int32(&out, 9, d.hierarchy_frame_idx);
+  for (uint32_t id : d.features) {   // SegmentationDesc.features = 10: RegionFeatures { required fixed32 id = 1 }
+    std::string fs;
+    Tag(&fs, 1, 5);
+    for (int i = 0; i < 4; ++i) fs.push_back(static_cast<char>((id >> (8 * i)) & 0xff));
+    Bytes(&out, 10, fs);
+  }
   if (d.has_vector_mesh) {   // SegmentationDesc.vector_mesh = 11
     std::string mesh;
     if (!d.vector_mesh.empty()) {   // coord = 1 [packed = true]
@@ -1990,6 +1997,7 @@ void vso_region_default_options(vso_region_options* o) {
   o->use_flow = d.use_flow;
   o->use_size_penalizer = d.use_size_penalizer;
   o->compute_vectorization = d.compute_vectorization;
+  o->save_descriptors = d.save_descriptors;
 }
 
 vso_region* vso_region_create(const vso_region_options* o, int width, int height) {
@@ -2008,6 +2016,7 @@ vso_region* vso_region_create(const vso_region_options* o, int width, int height
   d.use_flow = o->use_flow != 0;
   d.use_size_penalizer = o->use_size_penalizer != 0;
   d.compute_vectorization = o->compute_vectorization != 0;
+  d.save_descriptors = o->save_descriptors != 0;
   vso_region* r = new vso_region;
   r->rs.reset(new vso::RegionSegmentation(d, width, height));
   return r;

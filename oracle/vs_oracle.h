@@ -52,7 +52,7 @@ void vso_set_threads(int n);
 
 /* ---- hierarchical stage: RegionSegmentation::ProcessFrame (segmentation/region_segmentation.h) -- */
 typedef struct vso_region vso_region;
-/* Mirrors RegionSegmentationOptions (region_segmentation.h:41-83; save_descriptors not supported). */
+/* Mirrors RegionSegmentationOptions (region_segmentation.h:41-83). */
 typedef struct vso_region_options {
   int min_region_num;            /* 10 */
   int max_region_num;            /* 10000 */
@@ -62,6 +62,7 @@ typedef struct vso_region_options {
   int chunk_set_size, chunk_set_overlap, constraint_chunks;       /* 6, 2, 1 */
   int use_appearance, use_flow, use_size_penalizer;               /* 1, 1, 1 */
   int compute_vectorization;                                      /* 1 */
+  int save_descriptors;                                           /* 0: features { id } per region on hierarchy frames */
 } vso_region_options;
 void vso_region_default_options(vso_region_options* o);
 vso_region* vso_region_create(const vso_region_options* o, int width, int height);

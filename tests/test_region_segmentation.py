@@ -117,6 +117,9 @@ def test_lab_conversion_matches_oracle(vsg):
     (64, 48, 40, 8, True, dict(chunk_set_size=3, chunk_set_overlap=1, use_appearance=0, min_region_num=3)),
     # the first level has to be cut down to max_region_num
     (96, 64, 30, 10, True, dict(chunk_set_size=2, chunk_set_overlap=1, max_region_num=20, min_region_num=3)),
+    # save_descriptors: SegmentationDesc.features on the hierarchy frames
+    (96, 64, 60, 8, True, dict(chunk_set_size=3, chunk_set_overlap=1, constraint_chunks=1, min_region_num=3,
+                               save_descriptors=1)),
 ])
 def test_region_segmentation_bytes_match_oracle(vsg, W, H, N, chunk, flow, opts):
     fl = synth.const_flow(W, H) if flow else None
@@ -126,6 +129,18 @@ def test_region_segmentation_bytes_match_oracle(vsg, W, H, N, chunk, flow, opts)
     for k, (g, w) in enumerate(zip(got, want)):
         assert g == w, "hierarchical SegmentationDesc %d differs" % k
     assert check_structure(got, W, H) >= 1
+    Msg = build_schema()
+    with_features = 0
+    for g in got:
+        m = Msg()
+        m.ParseFromString(g)
+        if opts.get("save_descriptors") and len(m.hierarchy) > 0:
+            # one RegionFeatures { id } per region of the first level (segmentation.cpp:490-501)
+            assert sorted(f.id for f in m.features) == sorted(r.id for r in m.hierarchy[0].region)
+            with_features += 1
+        else:
+            assert len(m.features) == 0
+    assert with_features >= 2 if opts.get("save_descriptors") else with_features == 0
 
 
 def test_threaded_descriptor_accumulation_is_identical(vsg, monkeypatch):

@@ -65,7 +65,7 @@ class VsgRegionOptions(C.Structure):
         ("luminance_bins", C.c_int), ("color_bins", C.c_int), ("flow_bins", C.c_int),
         ("chunk_set_size", C.c_int), ("chunk_set_overlap", C.c_int), ("constraint_chunks", C.c_int),
         ("use_appearance", C.c_int), ("use_flow", C.c_int), ("use_size_penalizer", C.c_int),
-        ("compute_vectorization", C.c_int),
+        ("compute_vectorization", C.c_int), ("save_descriptors", C.c_int),
     ]
 
 

@@ -493,6 +493,7 @@ void vsg_regionseg_default_options(vsg_regionseg_options* o) {
   o->use_flow = d.use_flow;
   o->use_size_penalizer = d.use_size_penalizer;
   o->compute_vectorization = d.compute_vectorization;
+  o->save_descriptors = d.save_descriptors;
 }
 
 int vsg_regionseg_create(const vsg_regionseg_options* o, int width, int height, vsg_regionseg** out) {
@@ -513,6 +514,7 @@ int vsg_regionseg_create(const vsg_regionseg_options* o, int width, int height, 
     d.use_flow = o->use_flow != 0;
     d.use_size_penalizer = o->use_size_penalizer != 0;
     d.compute_vectorization = o->compute_vectorization != 0;
+    d.save_descriptors = o->save_descriptors != 0;
     std::unique_ptr<vsg_regionseg> r(new vsg_regionseg);
     r->impl.reset(new vsg::RegionSegmentationHost(d, width, height));
     r->W = width;

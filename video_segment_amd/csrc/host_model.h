@@ -75,6 +75,7 @@ struct SegDesc {
   int connectedness = 1;   // N4_CONNECT = 1, N8_CONNECT = 2
   bool has_vector_mesh = false;
   std::vector<float> vector_mesh;   // x, y pairs (SegmentationDesc.vector_mesh)
+  std::vector<uint32_t> feature_ids;   // SegmentationDesc.features: RegionFeatures.id (save_descriptors)
 };
 
 // Boundaries of all regions of a frame and their vectorization (boundary.cpp): fills

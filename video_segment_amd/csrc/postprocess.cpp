@@ -758,6 +758,12 @@ std::string EncodeSegDesc(const SegDesc& d) {
   PutInt(&out, 7, d.overlap_start);
   PutInt(&out, 8, d.chunk_id);
   PutInt(&out, 9, d.hierarchy_frame_idx);
+  for (uint32_t id : d.feature_ids) {               // SegmentationDesc.features = 10
+    std::string f;
+    PutVarint(&f, ((uint64_t)1 << 3) | 5);          // RegionFeatures.id = 1, fixed32
+    for (int i = 0; i < 4; ++i) f.push_back((char)((id >> (8 * i)) & 0xff));
+    PutMsg(&out, 10, f);
+  }
   if (d.has_vector_mesh) {                          // SegmentationDesc.vector_mesh = 11
     std::string mesh;
     if (!d.vector_mesh.empty()) {                   // VectorMesh.coord = 1 [packed]

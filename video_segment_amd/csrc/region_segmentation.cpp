@@ -1171,6 +1171,14 @@ class ChunkSet {
     }
     auto by_id = [](const auto& a, const auto& b) { return a.id < b.id; };
     if (sorted_output_) std::sort(d->regions.begin(), d->regions.end(), by_id);
+    if (with_hierarchy && o_.save_descriptors) {
+      // segmentation.cpp:490-501: one RegionFeatures per region that is not flagged for removal, in
+      // list order.  The descriptors of this path add no extension to it (AddToRegionFeatures is
+      // empty for the appearance and the flow descriptor, region_descriptor.cpp:137-138, .h:382).
+      for (const auto& n : *levels_[0]) {
+        if (!n->removed) d->feature_ids.push_back((uint32_t)n->region_id);
+      }
+    }
     if (with_hierarchy) {
       d->has_hierarchy = true;
       std::vector<std::pair<int, int>> span_below, span;

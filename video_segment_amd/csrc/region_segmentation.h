@@ -27,6 +27,7 @@ struct RegionSegOptions {
   int chunk_set_size = 6, chunk_set_overlap = 2, constraint_chunks = 1;
   bool use_appearance = true, use_flow = true, use_size_penalizer = true;
   bool compute_vectorization = true;
+  bool save_descriptors = false;
 };
 
 // cv::cvtColor(BGR -> Lab) for 8-bit frames (OpenCV's fixed-point algorithm restated; un-vendored

@@ -328,6 +328,7 @@ RegionSegmentation::RegionSegmentation(const RegionSegmentationOptions& options,
   o.use_flow = options.use_flow;
   o.use_size_penalizer = options.use_size_penalizer;
   o.compute_vectorization = options.compute_vectorization;
+  o.save_descriptors = options.save_descriptors;
   if (vsg_regionseg_create(&o, frame_width, frame_height, &handle_) != VSG_OK) handle_ = nullptr;
 }
 

@@ -148,8 +148,7 @@ class DenseSegmentationUnit : public VideoUnit {
 };
 
 // ---- hierarchical stage -----------------------------------------------------------------------
-// Same fields and defaults as the reference (region_segmentation.h:41-83; save_descriptors is not
-// supported by the library).
+// Same fields and defaults as the reference (region_segmentation.h:41-83).
 struct RegionSegmentationOptions {
   int min_region_num = 10;
   int max_region_num = 10000;
@@ -165,6 +164,7 @@ struct RegionSegmentationOptions {
   bool use_flow = true;
   bool use_size_penalizer = true;
   bool compute_vectorization = true;
+  bool save_descriptors = false;
 };
 
 // Host-side drop-in for segmentation::RegionSegmentation (region_segmentation.h:131-216) behind
