@@ -48,7 +48,8 @@ typedef struct vsg_graph vsg_graph;
 
 /* Mirrors segmentation::DenseSegmentationOptions (dense_segmentation.h:42-95). */
 typedef struct vsg_options {
-  int presmoothing;                   /* 0 PRESMOOTH_NONE, 2 PRESMOOTH_BILATERAL (default)  */
+  int presmoothing;                   /* 0 PRESMOOTH_NONE, 1 PRESMOOTH_GAUSSIAN (3x3, sigma 1.5),
+                                       * 2 PRESMOOTH_BILATERAL (default)  */
   float frac_min_region_size;         /* 0.01f                                              */
   int chunk_size;                     /* 20, must be >= 3                                   */
   float chunk_overlap_ratio;          /* 0.2f                                               */

@@ -594,6 +594,54 @@ static void BilateralFilter3(const float* image, int W, int H, float sigma_space
   });
 }
 
+// cv::GaussianBlur(src, dst, Size(3, 3), sigma) for CV_32FC3 -- OpenCV, un-vendored third-party
+// arithmetic: the published algorithm of the 2.4 line (imgproc/src/smooth.cpp getGaussianKernel,
+// filter.cpp SymmRowSmallFilter / SymmColumnSmallFilter for a symmetric 3-tap float kernel), restated;
+// PARITY UNPINNED (no OpenCV in this image).
+//   kernel: t_i = exp(-0.5 / sigma^2 * (i - 1)^2) in double, stored as float; normalised by the double
+//           sum of the stored floats: cf_i = float(cf_i * (1 / sum))
+//   rows:   r[x] = S[x] * k0 + (S[x - 1] + S[x + 1]) * k1          (k0 = cf[1], k1 = cf[0] = cf[2])
+//   cols:   d[y] = r[y] * k0 + (r[y - 1] + r[y + 1]) * k1          every operation rounded to f32
+//   border: BORDER_REFLECT_101 (-1 -> 1, n -> n - 2; a single row / column reflects onto itself)
+static void GaussianBlur3x3(const float* src, int W, int H, double sigma, float* dst) {
+  float cf[3];
+  double sum = 0;
+  const double scale2x = -0.5 / (sigma * sigma);
+  for (int i = 0; i < 3; ++i) {
+    const double x = i - 1.0;
+    cf[i] = (float)std::exp(scale2x * x * x);
+    sum += cf[i];
+  }
+  sum = 1.0 / sum;
+  for (int i = 0; i < 3; ++i) cf[i] = (float)(cf[i] * sum);
+  const float k0 = cf[1], k1 = cf[0];
+  std::vector<float> rows((size_t)W * H * 3);
+  for (int y = 0; y < H; ++y) {
+    const float* s = src + (size_t)y * W * 3;
+    float* r = rows.data() + (size_t)y * W * 3;
+    for (int x = 0; x < W; ++x) {
+      const int xl = x > 0 ? x - 1 : (W > 1 ? 1 : 0), xr = x + 1 < W ? x + 1 : (W > 1 ? W - 2 : 0);
+      for (int c = 0; c < 3; ++c) {
+        const float side = s[xl * 3 + c] + s[xr * 3 + c];
+        const float centre = s[x * 3 + c] * k0;
+        r[x * 3 + c] = centre + side * k1;
+      }
+    }
+  }
+  for (int y = 0; y < H; ++y) {
+    const int yu = y > 0 ? y - 1 : (H > 1 ? 1 : 0), yd = y + 1 < H ? y + 1 : (H > 1 ? H - 2 : 0);
+    const float* r0 = rows.data() + (size_t)yu * W * 3;
+    const float* r1 = rows.data() + (size_t)y * W * 3;
+    const float* r2 = rows.data() + (size_t)yd * W * 3;
+    float* d = dst + (size_t)y * W * 3;
+    for (int i = 0; i < W * 3; ++i) {
+      const float side = r0[i] + r2[i];
+      const float centre = r1[i] * k0;
+      d[i] = centre + side * k1;
+    }
+  }
+}
+
 // dense_segmentation.cpp:164-198.  convertTo(CV_32FC3, 1.0/255.0) is OpenCV (un-vendored);
 // assumed float(u8) * float(1.0/255.0)  -- parity unpinned for this one step.
 static void PreprocessFeatures(const uint8_t* bgr, size_t stride, int W, int H, int presmoothing,
@@ -607,8 +655,10 @@ static void PreprocessFeatures(const uint8_t* bgr, size_t stride, int W, int H, 
   }
   if (presmoothing == 2) {
     BilateralFilter3(tmp.data(), W, H, 3.0f, 0.25f, out);
+  } else if (presmoothing == 1) {
+    GaussianBlur3x3(tmp.data(), W, H, 1.5, out);   // dense_segmentation.cpp:186-188
   } else {
-    VSO_CHECK(presmoothing == 0);  // gaussian needs cv::GaussianBlur (not restated)
+    VSO_CHECK(presmoothing == 0);
     std::memcpy(out, tmp.data(), tmp.size() * sizeof(float));
   }
 }

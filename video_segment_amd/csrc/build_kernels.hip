@@ -3,6 +3,7 @@
 //   K0  k_minmax_u8          global min / max of the u8 frame (feeds the bilateral LUT scale)
 //   K1  k_bilateral          u8 BGR -> f32 * (1/255) -> 49-tap LUT bilateral -> planar f32
 //       k_convert_planar     PRESMOOTH_NONE variant
+//       k_gaussian3          PRESMOOTH_GAUSSIAN variant (3x3, sigma 1.5)
 //   K2  k_init_nodes / k_init_virtual_nodes
 //   (K3 / K4 / K5 -- edge keys and the stable bucket sort -- are in edge_sort.hip)
 //
@@ -231,6 +232,47 @@ void LaunchConvertPlanar(const uint8_t* bgr, size_t stride, int W, int H, float*
   const size_t n = (size_t)W * H;
   hipLaunchKernelGGL(k_convert_planar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, bgr,
                      stride, W, H, planes);
+  VSG_HIP(hipGetLastError());
+}
+
+// PRESMOOTH_GAUSSIAN: cv::GaussianBlur(f32 BGR, Size(3, 3), sigma 1.5), dense_segmentation.cpp:186-188.
+// OpenCV (2.4 line, un-vendored) filters separably with a symmetric 3-tap kernel {k1, k0, k1}: rows first,
+//   r(y, x) = S(y, x) * k0 + (S(y, x - 1) + S(y, x + 1)) * k1,
+// then columns with the same expression over r, every product and sum rounded to f32, border
+// BORDER_REFLECT_101 (-1 -> 1, n -> n - 2).  One thread per pixel evaluates the three row values it
+// needs itself: 27 bytes of input per pixel from L1/L2, no intermediate plane.  Parity unpinned.
+__global__ __launch_bounds__(256) void k_gaussian3(const uint8_t* __restrict__ bgr, size_t stride, int W,
+                                                    int H, float k0, float k1,
+                                                    float* __restrict__ planes) {
+  const size_t n = (size_t)W * H;
+  const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= n) return;
+  const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
+  const int xl = x > 0 ? x - 1 : (W > 1 ? 1 : 0), xr = x + 1 < W ? x + 1 : (W > 1 ? W - 2 : 0);
+  const int yu = y > 0 ? y - 1 : (H > 1 ? 1 : 0), yd = y + 1 < H ? y + 1 : (H > 1 ? H - 2 : 0);
+  const float c255 = (float)(1.0 / 255.0);
+  const int rows[3] = {yu, y, yd};
+  float r[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const uint8_t* p = bgr + (size_t)rows[k] * stride;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float sl = (float)p[(size_t)xl * 3 + c] * c255;
+      const float sc = (float)p[(size_t)x * 3 + c] * c255;
+      const float sr = (float)p[(size_t)xr * 3 + c] * c255;
+      r[k][c] = sc * k0 + (sl + sr) * k1;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) planes[(size_t)c * n + pix] = r[1][c] * k0 + (r[0][c] + r[2][c]) * k1;
+}
+
+void LaunchGaussian3(const uint8_t* bgr, size_t stride, int W, int H, float k0, float k1, float* planes,
+                     hipStream_t s) {
+  const size_t n = (size_t)W * H;
+  hipLaunchKernelGGL(k_gaussian3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, bgr, stride, W, H,
+                     k0, k1, planes);
   VSG_HIP(hipGetLastError());
 }
 

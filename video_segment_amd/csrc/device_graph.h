@@ -64,6 +64,9 @@ void UploadSpaceWeights(const float* w49, hipStream_t stream);
 void LaunchMinMax(const uint8_t* bgr, size_t stride, int W, int H, int* mm, hipStream_t s);
 void LaunchBilateral(const uint8_t* bgr, size_t stride, int W, int H, const float* lut,
                      float scale, float* planes, hipStream_t s);
+// cv::GaussianBlur 3x3 with the symmetric kernel {k1, k0, k1} (PRESMOOTH_GAUSSIAN).
+void LaunchGaussian3(const uint8_t* bgr, size_t stride, int W, int H, float k0, float k1, float* planes,
+                     hipStream_t s);
 void LaunchConvertPlanar(const uint8_t* bgr, size_t stride, int W, int H, float* planes,
                          hipStream_t s);
 void LaunchInterleavedToPlanar(const float* in, size_t n, float* planes, hipStream_t s);

@@ -68,10 +68,22 @@ void Preprocessor::Run(const uint8_t* bgr_dev, size_t stride, int presmoothing, 
   const double t0 = NowMs();
   if (presmoothing == 0) {
     LaunchConvertPlanar(bgr_dev, stride, W_, H_, out, stream_);
+  } else if (presmoothing == 1) {
+    // cv::getGaussianKernel(3, 1.5, CV_32F) (OpenCV 2.4 smooth.cpp; un-vendored, parity unpinned):
+    // exp in double, stored as float, normalised by the double sum of the floats
+    float cf[3];
+    double sum = 0;
+    const double scale2x = -0.5 / (1.5 * 1.5);
+    for (int i = 0; i < 3; ++i) {
+      const double x = i - 1.0;
+      cf[i] = (float)std::exp(scale2x * x * x);
+      sum += cf[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < 3; ++i) cf[i] = (float)(cf[i] * sum);
+    LaunchGaussian3(bgr_dev, stride, W_, H_, cf[1], cf[0], out, stream_);
   } else {
-    VSG_REQUIRE(presmoothing == 2, -1,
-                "only PRESMOOTH_NONE and PRESMOOTH_BILATERAL are supported (gaussian needs "
-                "cv::GaussianBlur)");
+    VSG_REQUIRE(presmoothing == 2, -1, "presmoothing has to be 0 (none), 1 (gaussian) or 2 (bilateral)");
     if (!space_uploaded_) {
       // space_weights, image_filter.cpp:216-225 (radius 4, sigma_space 3.0)
       float w[49];

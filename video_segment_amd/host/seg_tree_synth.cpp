@@ -348,8 +348,9 @@ int main(int argc, char** argv) {
   seg_options.frac_min_region_size = (float)FLAGS.dense_min_region_size;
   if (FLAGS.dense_smoothing == "none") seg_options.presmoothing = DenseSegmentationOptions::PRESMOOTH_NONE;
   else if (FLAGS.dense_smoothing == "bilateral") seg_options.presmoothing = DenseSegmentationOptions::PRESMOOTH_BILATERAL;
+  else if (FLAGS.dense_smoothing == "gaussian") seg_options.presmoothing = DenseSegmentationOptions::PRESMOOTH_GAUSSIAN;
   else {
-    std::fprintf(stderr, "ERROR: --dense_smoothing %s is not supported (none | bilateral)\n",
+    std::fprintf(stderr, "ERROR: --dense_smoothing %s is not supported (none | gaussian | bilateral)\n",
                  FLAGS.dense_smoothing.c_str());
     return 2;
   }
