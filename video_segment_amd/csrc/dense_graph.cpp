@@ -558,10 +558,11 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   if (const char* e = getenv("VSG_INERT_MODE")) inert_mode = std::min(inert_mode, atoi(e));
   const bool debug_stages = getenv("VSG_DEBUG_STAGES") != nullptr;
   // Rank windows of bucket 0: six up to 1080p, more on larger frames (the components of a window
-  // grow with the frame, the per-window chain of small launches does not): 12 at 3840x2160, where
-  // 10-12 measured 311-320 ms of merge per chunk against 342-371 with six (and 343 with 32).
+  // grow with the frame, the per-window chain of small launches does not), in proportion to the
+  // frame area up to 12.  Merge per chunk at 3840x2160: 342-371 ms with six, 311-320 with 10-12,
+  // 343 with 32; at 2560x1440: 149-151 with six, 143-147 with 10-12.
   const double frame_ratio = (double)W_ * (double)H_ / (1920.0 * 1080.0);
-  const int default_windows = std::max(6, std::min(12, (int)std::lround(6.0 * std::sqrt(frame_ratio))));
+  const int default_windows = std::max(6, std::min(12, (int)std::lround(6.0 * frame_ratio)));
   const int num_windows = getenv("VSG_WINDOWS") ? std::max(1, atoi(getenv("VSG_WINDOWS"))) : default_windows;
   const int window_bushy = getenv("VSG_WINDOW_BUSHY") ? atoi(getenv("VSG_WINDOW_BUSHY")) : 64;
   const bool adapt_windows = !getenv("VSG_ADAPT_WINDOWS") || atoi(getenv("VSG_ADAPT_WINDOWS")) != 0;
