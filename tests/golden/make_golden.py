@@ -5,7 +5,7 @@ these vectors are produced by oracle/libvs_oracle.so, which is itself pinned bit
 reference-derived values recorded in SURVEY.md App. B (tests/test_oracle_pins.py).  The vectors
 freeze the complete serialized output (every SegmentationDesc byte) for inputs that the survey's
 probe did not cover: noise, constant colour, single frame, the bench generator, L1 distance,
-no pre-smoothing, many short chunks; and, in their own files, for the two stages on the caller side
+no pre-smoothing, Gaussian pre-smoothing, many short chunks; and, in their own files, for the two stages on the caller side
 of the path -- the boundary vectorisation of the dense unit (vector_golden.json: every byte of
 Region2D.vectorization and vector_mesh) and the hierarchical RegionSegmentation behind it
 (hierarchy_golden.json: every hierarchy level, two and three chunk sets with overlap and
@@ -36,6 +36,7 @@ CASES = [
     ("single_frame_64x48", 64, 48, 1, "probe", False, 20, {}),
     ("bench_l1_64x48x12", 64, 48, 12, "bench", True, 8, {"color_distance": 0}),
     ("bench_nosmooth_64x48x12", 64, 48, 12, "bench", True, 8, {"presmoothing": 0}),
+    ("bench_gaussian_64x48x20", 64, 48, 20, "bench", True, 8, {"presmoothing": 1}),
 ]
 
 
@@ -82,6 +83,8 @@ HIERARCHY_CASES = [
     ("hier_soft_80x60x24_c8_noflow", 80, 60, 24, 8, False, dict(use_flow=0, min_region_num=4)),
     ("hier_soft_96x64x30_c10_cut", 96, 64, 30, 10, True,
      dict(chunk_set_size=2, chunk_set_overlap=1, max_region_num=20, min_region_num=3)),
+    ("hier_soft_96x64x40_c8_features", 96, 64, 40, 8, True,
+     dict(chunk_set_size=3, chunk_set_overlap=1, min_region_num=3, save_descriptors=1)),
 ]
 
 
