@@ -8,6 +8,7 @@
 //   tube_harness file <dump> [plain]     the input of one chunk, dumped by the library under
 //                                        VSG_DUMP_TUBES=<dump> (dense_graph.cpp): timing and a checksum
 //                                        of the result ("plain": of FinishPlain)
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +54,40 @@ static void MaskToRaster(const std::vector<char>& mask, int w, int h, int ox, in
   }
 }
 
+// N4 components of a raster by testing every pair of intervals (adjacent rows, overlapping in x),
+// ordered by first interval: what SplitComponentsN4 (a row sweep) has to return.
+static void ComponentsByAllPairs(const Raster& r, std::vector<Raster>* comps) {
+  const int n = (int)r.size();
+  std::vector<int> uf((size_t)n);
+  for (int i = 0; i < n; ++i) uf[i] = i;
+  auto root = [&](int i) { while (uf[i] != i) i = uf[i]; return i; };
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < i; ++k) {
+      if (std::abs(r[i].y - r[k].y) == 1 && std::max(r[i].lx, r[k].lx) <= std::min(r[i].rx, r[k].rx)) {
+        const int a = root(i), b = root(k);
+        if (a != b) uf[std::max(a, b)] = std::min(a, b);
+      }
+    }
+  }
+  std::vector<int> comp_of((size_t)n, -1);
+  for (int i = 0; i < n; ++i) {
+    const int rt = root(i);
+    if (comp_of[rt] < 0) {
+      comp_of[rt] = (int)comps->size();
+      comps->emplace_back();
+    }
+    (*comps)[(size_t)comp_of[rt]].push_back(r[i]);
+  }
+}
+
+static bool SameComponents(const std::vector<Raster>& a, const std::vector<Raster>& b) {
+  if (a.size() != b.size()) return false;
+  for (size_t k = 0; k < a.size(); ++k) {
+    if (a[k].size() != b[k].size() || std::memcmp(a[k].data(), b[k].data(), sizeof(Interval) * a[k].size()) != 0) return false;
+  }
+  return true;
+}
+
 static int RunRandom(int cases, unsigned seed) {
   const int W = 320, H = 200;
   int splits = 0, joins = 0;
@@ -93,6 +128,15 @@ static int RunRandom(int cases, unsigned seed) {
       if (kind == 4 && f + 1 == jump_at) bx += bx < w / 2 ? 17.5 : -17.5;
     }
     if (raster.empty()) continue;
+    for (const RasterSlice& sl : raster) {
+      std::vector<Raster> sweep, pairs;
+      SplitComponentsN4(sl.raster, &sweep);
+      ComponentsByAllPairs(sl.raster, &pairs);
+      if (!SameComponents(sweep, pairs)) {
+        std::printf("case %d: SplitComponentsN4 differs from the all-pairs components (%zu vs %zu)\n", c, sweep.size(), pairs.size());
+        return 1;
+      }
+    }
     TubeSplitter fast, plain;
     std::vector<FlowRequest> req, req2;
     fast.Prepare(raster, &req);

@@ -5,7 +5,9 @@ Finish keeps the live tubes in a linked list, finds a tube's closest tube throug
 evaluates a distance only where a bound says it can win; tests/host/tube_plain_model.inc is the same
 analysis with a vector, erase and every distance evaluated, in the order of
 segmentation/dense_segmentation_graph.h:666-861.  Both are compiled from postprocess.cpp with g++ (no
-HIP, no oracle) and have to return the same tubes, areas and kept tube on random regions."""
+HIP, no oracle) and have to return the same tubes, areas and kept tube on random regions.  The same
+run checks SplitComponentsN4 (a sweep over the previous row) against the components found by testing
+every pair of intervals."""
 import os
 import subprocess
 
