@@ -89,7 +89,7 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
     zero_pool_.base = zero_pool_mem_.get();
     zero_pool_.cap = zero_pool_mem_.size();
     if (const char* e = getenv("VSG_ZERO_POOL")) {   // test hook: a small pool changes halves all the time
-      zero_pool_.cap = std::min<size_t>(zero_pool_.cap, std::max<size_t>((size_t)atoll(e), 4096));
+      zero_pool_.cap = std::min<size_t>(zero_pool_.cap, std::max<size_t>((size_t)atoll(e), 4096) + kZeroArenaInts);
     }
   }
   VSG_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
@@ -100,9 +100,11 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   size_t temp = ScanTempBytes((int)N);
   cub_temp_.alloc(temp);
   Reset(max_frames);
+  MailRegisterGraph(1);
 }
 
 DenseGraphHip::~DenseGraphHip() {
+  MailRegisterGraph(-1);
   for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
   if (aux_fork_) (void)hipEventDestroy(aux_fork_);
   if (aux_join_) (void)hipEventDestroy(aux_join_);
@@ -359,6 +361,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   VSG_HIP(hipMemsetAsync(zero_pool_.base, 0, zero_pool_.cap * sizeof(int32_t), stream_));
   zero_pool_.used = 0;
   zero_pool_.second_half = false;
+  zero_pool_.arena_used = 0;
   LaunchInitIdentity(cc_.get(), N, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
 
@@ -462,6 +465,9 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.spine_debug = getenv("VSG_SPINE_DEBUG") ? 1 : 0;
   S.spine_check = getenv("VSG_SPINE_CHECK") ? 1 : 0;
   S.rank_split_min = getenv("VSG_RANK_SPLIT_MIN") ? atoi(getenv("VSG_RANK_SPLIT_MIN")) : (1 << 20);
+  // (a workgroup of 1024 threads walks 32 edges per thread and phase at 32 K edges: above that the
+  // loops of kernels over all CUs are the faster form again)
+  S.spine_block_max = getenv("VSG_SPINE_BLOCK_MAX") ? atoi(getenv("VSG_SPINE_BLOCK_MAX")) : 32768;
   S.spine_fast = getenv("VSG_SPINE_FAST") ? atoi(getenv("VSG_SPINE_FAST")) : 2;   // streamed passes
   S.spine_fast_min = getenv("VSG_SPINE_FAST_MIN") ? atoi(getenv("VSG_SPINE_FAST_MIN")) : 32768;
   if (S.spine_min > 0) {

@@ -140,6 +140,10 @@ inline MailSlot NextMail(Mailbox& m) {
 // Waits until the first `count` values of the slot have arrived (spins; looks at the stream for
 // errors now and then) and returns them.
 void MailWait(const MailSlot& slot, int count, int* values, hipStream_t s);
+// The waiting policy (merge_stage.hip: VSG_MAIL_YIELD): graphs register themselves so that a process
+// with more streams than cores stops spinning by itself.
+void MailRegisterGraph(int delta);
+int MailYieldMode();
 // Posts up to four device scalars from a one-thread kernel (where no kernel of the algorithm is at
 // hand to do it): values[i] = *ptrs[i].
 void LaunchMailPost(const MailSlot& slot, const int32_t* p0, const int32_t* p1, const int32_t* p2,
@@ -147,10 +151,12 @@ void LaunchMailPost(const MailSlot& slot, const int32_t* p0, const int32_t* p1, 
 
 // Zeroed device counters, handed out in order and cleared in one go per chunk (a hipMemsetAsync per
 // counter per stage was 450 launches per chunk).
+constexpr size_t kZeroArenaInts = 1024;   // head of the pool: scalars that live as long as a stage
 struct ZeroPool {
   int32_t* base = nullptr;
   size_t cap = 0, used = 0;     // `used` counts inside the current half (TakeZeroed)
   bool second_half = false;
+  size_t arena_used = 0;        // TakeStageScalars
 };
 
 // ---- merge_stage.hip (worker: merge_wave.hip) ----------------------------------------------------------------
@@ -220,6 +226,8 @@ struct MergeScratch {
   int spine_max_edges;   // at most this many edges per stage (scratch pool)
   int spine_debug, spine_check;
   int rank_split_min;    // Euler tours of at least this many arcs are ranked by sampling (k_rank_walk)
+  int spine_block_max;   // components of at most this many edges: one workgroup each runs the loops of
+                         // the tree machinery (forest rounds, list ranking, path maxima); 0: never
   int spine_fast;        // the plain steps of a spine through the streamed chain (k_spine_chain)
   int spine_fast_min;    // ... from this many tree edges on (seven more launches)
   int32_t* spine_pool;   // scratch, SpinePoolInts(spine_max_edges) ints
@@ -253,9 +261,11 @@ struct MergeScratch {
   ZeroPool* zeros;
   hipStream_t main_stream;
 };
-// n zeroed ints (see ZeroPool); when the pool is used up all three streams are drained and it is
-// cleared again.
+// n zeroed ints (see ZeroPool) for kernels that are launched right away; when the current half of
+// the pool is used up all three streams are drained and the other half is cleared and taken over.
 int32_t* TakeZeroed(MergeScratch& S, size_t n);
+// n zeroed ints that stay intact until the stage that took them (at its entry) has ended.
+int32_t* TakeStageScalars(MergeScratch& S, size_t n);
 
 // bucket_base[b * (L+1) + l] = number of bucket-b edges in lists < l; [.. + L] = total.
 void LaunchBuildBucketTable(const ListDesc* lists, int num_lists, int32_t* bucket_base,

@@ -26,7 +26,11 @@
 // This is memory-latency / dependency bound integer + scalar float work: no MFMA, no LDS tiling;
 // what matters is coalesced streaming in the filter and keeping the serial chains in registers.
 // Shared device helpers in merge_common.h.
+#include <sched.h>
+#include <time.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -84,10 +88,39 @@ void LaunchMailPost(const MailSlot& slot, const int32_t* p0, const int32_t* p1, 
   VSG_HIP(hipGetLastError());
 }
 
+// How a waiting host thread treats its core.  Every stream has one thread in MailWait for most of a
+// merge (about 150 waits per chunk); on a node with fewer free cores than streams (8 GPUs x S
+// streams) threads that only ever `pause` starve each other and the units feeding them.
+//   VSG_MAIL_YIELD=0  spin (lowest latency: about 14 us from the producing kernel to the next launch)
+//   VSG_MAIL_YIELD=1  spin briefly, then sched_yield between polls
+//   VSG_MAIL_YIELD=2  spin briefly, then sleep between polls (20 us, doubling up to 200 us)
+//   unset             0 while the process holds at most half as many graphs as it may use cores, 1 beyond
+static std::atomic<int> g_live_graphs{0};
+void MailRegisterGraph(int delta) { g_live_graphs.fetch_add(delta, std::memory_order_relaxed); }
+
+static int UsableCores() {
+  static const int n = [] {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) return (int)CPU_COUNT(&set);
+    const unsigned h = std::thread::hardware_concurrency();
+    return h ? (int)h : 1;
+  }();
+  return n;
+}
+
+int MailYieldMode() {
+  if (const char* e = getenv("VSG_MAIL_YIELD")) return std::max(0, std::min(2, atoi(e)));
+  return 2 * g_live_graphs.load(std::memory_order_relaxed) > UsableCores() ? 1 : 0;
+}
+
 void MailWait(const MailSlot& slot, int count, int* values, hipStream_t s) {
   using clk = std::chrono::steady_clock;
   clk::time_point t0;
   bool timed = false;
+  const int mode = MailYieldMode();
+  constexpr unsigned long long kBriefSpins = 512;   // a few microseconds: most values are there by then
+  long sleep_ns = 20000;
   for (int i = 0; i < count; ++i) {
     for (unsigned long long spins = 0;; ++spins) {
       const unsigned long long w = slot.host[i];
@@ -98,8 +131,18 @@ void MailWait(const MailSlot& slot, int count, int* values, hipStream_t s) {
 #if defined(__x86_64__)
       __builtin_ia32_pause();
 #endif
-      if ((spins & 0xffffull) == 0xffffull) {
-        // nothing for a while: a kernel that died would never post
+      if (mode != 0 && spins >= kBriefSpins) {
+        if (mode == 1) {
+          std::this_thread::yield();
+        } else {
+          const timespec ts = {0, sleep_ns};
+          nanosleep(&ts, nullptr);
+          sleep_ns = std::min(sleep_ns * 2, 200000l);
+        }
+      }
+      // nothing for a while (65536 spins, or about 10 ms of polite polls): a kernel that died
+      // would never post
+      if ((mode == 0 && (spins & 0xffffull) == 0xffffull) || (mode != 0 && (spins & 0x3ffull) == 0x3ffull)) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipSuccess && e != hipErrorNotReady) VSG_HIP(e);
         if (!timed) {
@@ -110,33 +153,56 @@ void MailWait(const MailSlot& slot, int count, int* values, hipStream_t s) {
           const unsigned long long w2 = slot.host[i];
           if ((unsigned)(w2 >> 32) != slot.seq) throw Error(-4 /* VSG_ERR_INTERNAL */, "mailbox: a value never arrived");
         }
-        std::this_thread::yield();
+        if (mode == 0) std::this_thread::yield();
       }
     }
   }
 }
 
+static void DrainStreams(MergeScratch& S) {
+  VSG_HIP(hipStreamSynchronize(S.main_stream));
+  if (S.aux_stream) VSG_HIP(hipStreamSynchronize(S.aux_stream));
+  if (S.aux2_stream) VSG_HIP(hipStreamSynchronize(S.aux2_stream));
+}
+
 int32_t* TakeZeroed(MergeScratch& S, size_t n) {
-  // The pool is used in two halves.  Counters live for a stage at most (a few thousand ints), so
-  // when one half is used up the OTHER one holds nothing anybody still reads: it is cleared (after
-  // the streams have drained: kernels of older stages may still be adding to it) and taken over,
-  // while the counters of the stage in flight stay where they are.
+  // Behind the stage arena (below) the pool is used in two halves, for counters that are consumed
+  // by kernels launched right after they are taken: when one half is used up all streams are drained
+  // -- so every kernel that was given a counter of either half is complete --, the OTHER half is
+  // cleared and taken over.  A counter that a kernel launched AFTER a later TakeZeroed still has to
+  // find intact (the stage's violation word) must not come from here: TakeStageScalars.
   ZeroPool& z = *S.zeros;
   n = (n + 3) & ~(size_t)3;
-  const size_t half = z.cap / 2;
+  VSG_REQUIRE(z.cap > 2 * kZeroArenaInts, -4, "zero pool: too small");
+  const size_t half = (z.cap - kZeroArenaInts) / 2;
   VSG_REQUIRE(n <= half, -4, "zero pool: request too large");
-  const size_t begin = z.second_half ? half : 0;
   if (z.used + n > half) {
-    VSG_HIP(hipStreamSynchronize(S.main_stream));
-    if (S.aux_stream) VSG_HIP(hipStreamSynchronize(S.aux_stream));
-    if (S.aux2_stream) VSG_HIP(hipStreamSynchronize(S.aux2_stream));
+    DrainStreams(S);
     z.second_half = !z.second_half;
     z.used = 0;
-    VSG_HIP(hipMemsetAsync(z.base + (z.second_half ? half : 0), 0, half * sizeof(int32_t), S.main_stream));
-    return TakeZeroed(S, n);
+    VSG_HIP(hipMemsetAsync(z.base + kZeroArenaInts + (z.second_half ? half : 0), 0, half * sizeof(int32_t),
+                           S.main_stream));
   }
-  int32_t* p = z.base + begin + z.used;
+  int32_t* p = z.base + kZeroArenaInts + (z.second_half ? half : 0) + z.used;
   z.used += n;
+  return p;
+}
+
+int32_t* TakeStageScalars(MergeScratch& S, size_t n) {
+  // The scalars a stage keeps from its first kernel to its last (tentative-edge flag, violation
+  // word) live in their own arena at the head of the pool, which the half swaps above never touch.
+  // It is only ever recycled here, at the entry of a stage, where no earlier stage's scalars are
+  // live any more (a stage reads its violation word back before it returns or replays itself).
+  ZeroPool& z = *S.zeros;
+  n = (n + 3) & ~(size_t)3;
+  VSG_REQUIRE(n <= kZeroArenaInts, -4, "zero pool: stage scalars too large");
+  if (z.arena_used + n > kZeroArenaInts) {
+    DrainStreams(S);
+    VSG_HIP(hipMemsetAsync(z.base, 0, kZeroArenaInts * sizeof(int32_t), S.main_stream));
+    z.arena_used = 0;
+  }
+  int32_t* p = z.base + z.arena_used;
+  z.arena_used += n;
   return p;
 }
 
@@ -155,6 +221,15 @@ int32_t* TakeZeroed(MergeScratch& S, size_t n) {
 //   rolls the stage back and replays it with inert_mode 0 (see RunBucketStage).
 // The stage covers the edges [j0, j0 + n_b) of the buckets [bucket, bucket_hi) (one after the
 // other; bucket_prefix[b] = edges in the buckets before b).
+// Every thread filters kFilterPer edges, 256 apart: the kernel is a chain of dependent loads per edge
+// (slot -> flow-displaced pixel -> parent -> parent of parent ..., 91 % of its wave cycles in
+// s_waitcnt at full occupancy), so the only parallelism left to add is inside the thread -- the
+// chains of a thread's edges advance together, every step one batch of independent loads.  The
+// bookkeeping downstream (masks, packed records, per-block counts) stays in units of 256 edges:
+// a workgroup simply covers kFilterPer such blocks.
+constexpr int kFilterPer = 2;
+constexpr int kFilterEdges = 256 * kFilterPer;   // edges per workgroup
+
 __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j0, int n_b,
                                                  const ListDesc* __restrict__ lists,
                                                  const int32_t* __restrict__ bucket_base,
@@ -168,25 +243,24 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
                                                  uint32_t* __restrict__ e_gpos,
                                                  FilterMasks M,
                                                  int32_t* __restrict__ num_ti, FilterSegs segs) {
-  __shared__ int wave_cnt[4], wave_kept[4];
-  __shared__ int s_start[257], s_list[256], s_pos0[256];
+  __shared__ int wave_cnt[kFilterPer][4], wave_kept[kFilterPer][4];
+  __shared__ int s_start[kFilterEdges], s_pos0[kFilterEdges];
   // ... with what the edges of a segment need from its list (a 48-byte descriptor per thread
   // otherwise: six loads of the 22 a wavefront issued)
-  __shared__ const uint32_t* s_slots[256];
-  __shared__ const int32_t* s_prev[256];
-  __shared__ int s_type[256], s_base_a[256], s_base_b[256];
-  __shared__ uint32_t s_slot_base[256];
-  const int j = blockIdx.x * 256 + threadIdx.x;   // index inside the stage's window
-  // Where edge j lives: the host lists the stage's non-empty (bucket, list) segments (start inside
+  __shared__ const uint32_t* s_slots[kFilterEdges];
+  __shared__ const int32_t* s_prev[kFilterEdges];
+  __shared__ int s_type[kFilterEdges], s_base_a[kFilterEdges], s_base_b[kFilterEdges];
+  __shared__ uint32_t s_slot_base[kFilterEdges];
+  const int jf = blockIdx.x * kFilterEdges;   // first edge of the workgroup inside the stage's window
+  // Where an edge lives: the host lists the stage's non-empty (bucket, list) segments (start inside
   // the stage, list, position of the segment's first edge in the list's sorted slots).  A
-  // workgroup's 256 edges touch at most 256 of them, found by the workgroup together and kept in
-  // LDS -- the two binary searches per thread over tables in global memory (up to fifteen
+  // workgroup's edges touch at most kFilterEdges of them, found by the workgroup together and kept
+  // in LDS -- the two binary searches per thread over tables in global memory (up to fifteen
   // dependent loads before the first byte of the edge itself) made the kernel latency bound.
   int m_segs = 0;
   if (segs.start) {
-    const int jf = blockIdx.x * 256;
     int first = 0;
-    if (segs.n > 256) {   // the last segment that starts at or before the workgroup's first edge
+    if (segs.n > kFilterEdges) {   // the last segment that starts at or before the workgroup's first edge
       const int stride = (segs.n + 255) / 256;
       const int t1 = threadIdx.x * stride;
       const int c1 = __syncthreads_count(t1 < segs.n && segs.start[t1] <= jf);
@@ -195,47 +269,80 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
       const int c2 = __syncthreads_count(threadIdx.x < stride && t2 < segs.n && segs.start[t2] <= jf);
       first = base + c2 - 1;
     }
-    m_segs = min(256, segs.n - first);
-    if (threadIdx.x < m_segs) {
-      s_start[threadIdx.x] = segs.start[first + threadIdx.x];
-      const int l = segs.list[first + threadIdx.x];
-      s_list[threadIdx.x] = l;
-      s_pos0[threadIdx.x] = segs.pos0[first + threadIdx.x];
+    m_segs = min(kFilterEdges, segs.n - first);
+    for (int i = threadIdx.x; i < m_segs; i += 256) {
+      s_start[i] = segs.start[first + i];
+      const int l = segs.list[first + i];
+      s_pos0[i] = segs.pos0[first + i];
       const ListDesc L = lists[l];
-      s_slots[threadIdx.x] = L.slots;
-      s_prev[threadIdx.x] = L.prev_idx;
-      s_type[threadIdx.x] = L.type;
-      s_base_a[threadIdx.x] = L.base_a;
-      s_base_b[threadIdx.x] = L.base_b;
-      s_slot_base[threadIdx.x] = list_slot_base[l];
+      s_slots[i] = L.slots;
+      // (a spatial list has no displaced pixels: the unconditional load below reads its slots instead)
+      s_prev[i] = L.type != 0 ? L.prev_idx : reinterpret_cast<const int32_t*>(L.slots);
+      s_type[i] = L.type;
+      s_base_a[i] = L.base_a;
+      s_base_b[i] = L.base_b;
+      s_slot_base[i] = list_slot_base[l];
     }
     __syncthreads();
   }
-  int ti = 0, active = 0, settled = 0;
-  int ra = 0, rb = 0;
-  uint32_t gpos = 0;
-  if (j < n_b) {
-    int l, pos;
-    int a, b, l_type;
-    if (segs.start) {
-      int lo = 0, hi = m_segs;   // the last loaded segment with start <= j
+  bool valid[kFilterPer];
+  int a[kFilterPer], b[kFilterPer], l_type[kFilterPer];
+  uint32_t gpos[kFilterPer];
+  if (segs.start) {
+    // ---- decode: every step is one batch of independent loads over the thread's edges ------------------------
+    const uint32_t* slots_p[kFilterPer];
+    const int32_t* prev_p[kFilterPer];
+    int pos[kFilterPer], base_a[kFilterPer], base_b[kFilterPer];
+#pragma unroll
+    for (int e = 0; e < kFilterPer; ++e) {
+      const int j = jf + e * 256 + threadIdx.x;
+      valid[e] = j < n_b;
+      const int jc = valid[e] ? j : n_b - 1;   // (an edge past the end repeats the last one, without effects)
+      int lo = 0, hi = m_segs;   // the last loaded segment with start <= jc
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (s_start[mid] <= j) lo = mid; else hi = mid;
+        if (s_start[mid] <= jc) lo = mid; else hi = mid;
       }
-      l = s_list[lo];
-      pos = s_pos0[lo] + (j - s_start[lo]);
-      ListDesc L;
-      L.slots = s_slots[lo];
-      L.prev_idx = s_prev[lo];
-      L.type = l_type = s_type[lo];
-      L.base_a = s_base_a[lo];
-      L.base_b = s_base_b[lo];
-      DecodeEdge(L, L.slots[pos], P.W, a, b);
-      gpos = s_slot_base[lo] + (uint32_t)pos;
-    } else {
+      pos[e] = s_pos0[lo] + (jc - s_start[lo]);
+      slots_p[e] = s_slots[lo];
+      prev_p[e] = s_prev[lo];
+      l_type[e] = s_type[lo];
+      base_a[e] = s_base_a[lo];
+      base_b[e] = s_base_b[lo];
+      gpos[e] = s_slot_base[lo] + (uint32_t)pos[e];
+    }
+    uint32_t slot[kFilterPer];
+#pragma unroll
+    for (int e = 0; e < kFilterPer; ++e) slot[e] = slots_p[e][pos[e]];
+    uint32_t pix[kFilterPer];
+    int pv[kFilterPer];
+#pragma unroll
+    for (int e = 0; e < kFilterPer; ++e) {
+      // (selected with a mask: as a conditional the compiler branches, and waits for edge 0's
+      // displaced pixel before it issues the load of edge 1's)
+      const uint32_t tm = (uint32_t)-(int)(l_type[e] != 0);
+      pix[e] = ((slot[e] / 9u) & tm) | ((slot[e] >> 2) & ~tm);
+      pv[e] = prev_p[e][pix[e]];
+    }
+#pragma unroll
+    for (int e = 0; e < kFilterPer; ++e) {   // DecodeEdge, without branches (a branch per edge would
+      a[e] = base_a[e] + (int)pix[e];        // put a wait for its loads between the edges)
+      const int kt = (int)(slot[e] - pix[e] * 9u);
+      const int dy = kt / 3 - 1, dx = kt - (kt / 3) * 3 - 1;
+      const int bt = base_b[e] + pv[e] + dy * P.W + dx;
+      const int ks = (int)(slot[e] & 3u);   // 0 right, 1 bottom, 2 bottom-left, 3 bottom-right
+      const int bs = a[e] + (ks != 0 ? P.W : 0) + (ks == 0 || ks == 3 ? 1 : 0) - (ks == 2 ? 1 : 0);
+      const int tm = -(int)(l_type[e] != 0);
+      b[e] = (bt & tm) | (bs & ~tm);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < kFilterPer; ++e) {
+      const int j = jf + e * 256 + threadIdx.x;
+      valid[e] = j < n_b;
+      const int jc = valid[e] ? j : n_b - 1;
       int bk = bucket;
-      int jb = j0 + j;                               // index inside the bucket
+      int jb = j0 + jc;                              // index inside the bucket
       if (bucket_hi > bucket + 1) {                  // several buckets: the last b with prefix[b] <= position
         const int jg = bucket_prefix[bucket] + jb;
         int lo = bucket, hi = bucket_hi;
@@ -247,85 +354,145 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
         jb = jg - bucket_prefix[bk];
       }
       const int32_t* base_row = bucket_base + (size_t)bk * (P.num_lists + 1);
-      l = LocateList(base_row, P.num_lists, jb);
-      pos = lists[l].offsets[bk] + (jb - base_row[l]);
+      const int l = LocateList(base_row, P.num_lists, jb);
+      const int pos = lists[l].offsets[bk] + (jb - base_row[l]);
       const ListDesc L = lists[l];
-      l_type = L.type;
-      DecodeEdge(L, L.slots[pos], P.W, a, b);
-      gpos = list_slot_base[l] + (uint32_t)pos;
+      l_type[e] = L.type;
+      DecodeEdge(L, L.slots[pos], P.W, a[e], b[e]);
+      gpos[e] = list_slot_base[l] + (uint32_t)pos;
     }
-    ra = FindCompress(nodes.parent, a);
-    rb = FindCompress(nodes.parent, b);
-    const bool gone = P.spatial_survivors && l_type == 0 && !P.spatial_survivors[gpos];
-    if (ra != rb && !gone) {
-      bool inert = false;
-      if (inert_mode != 0) {
-        const int f1 = nodes.flags[ra], f2 = nodes.flags[rb];
-        bool both_final_large = false;
-        if ((f1 & kFlagFinalized) && (f2 & kFlagFinalized)) {
-          const int s1 = __float_as_int(nodes.desc_sz[ra].w);
-          const int s2 = __float_as_int(nodes.desc_sz[rb].w);
-          both_final_large = (s1 >= P.min_region_size) && (s2 >= P.min_region_size);
-        }
-        if (inert_mode == 1) {
-          inert = both_final_large;
-        } else {
-          const int c1 = nodes.cons[ra], c2 = nodes.cons[rb];
-          if (c1 >= 0 && c2 >= 0) {
-            inert = (c1 != c2);            // different constraints: never merged
-          } else {
-            inert = both_final_large;      // at least one unconstrained
-          }
-          if (inert) {
-            ti = 1;
-            if (!(f1 & kFlagTentative)) nodes.flags[ra] = (uint8_t)(f1 | kFlagTentative);
-            if (!(f2 & kFlagTentative)) nodes.flags[rb] = (uint8_t)(f2 | kFlagTentative);
-          }
+  }
+  // ---- both roots of every edge (GetRegion with path compression), all chains of the thread together -------
+  constexpr int kChains = 2 * kFilterPer;
+  int x0[kChains], root[kChains];
+#pragma unroll
+  for (int e = 0; e < kFilterPer; ++e) {
+    x0[2 * e] = a[e];
+    x0[2 * e + 1] = b[e];
+  }
+#pragma unroll
+  for (int c = 0; c < kChains; ++c) root[c] = x0[c];
+  for (bool any = true; any;) {
+    int p[kChains];
+#pragma unroll
+    for (int c = 0; c < kChains; ++c) p[c] = nodes.parent[root[c]];
+    any = false;
+#pragma unroll
+    for (int c = 0; c < kChains; ++c) {
+      if (p[c] != root[c]) {
+        root[c] = p[c];
+        any = true;
+      }
+    }
+  }
+  {
+    // compression: every node on the path that does not point at the root yet (concurrent callers
+    // may race on parent[] writes; every value ever written is an ancestor of the node, so any
+    // interleaving leaves a valid forest with the same roots -- FindCompress, merge_common.h)
+    int cur[kChains];
+#pragma unroll
+    for (int c = 0; c < kChains; ++c) cur[c] = x0[c];
+    for (bool any = true; any;) {
+      int nx[kChains];
+#pragma unroll
+      for (int c = 0; c < kChains; ++c) nx[c] = cur[c] != root[c] ? nodes.parent[cur[c]] : root[c];
+      any = false;
+#pragma unroll
+      for (int c = 0; c < kChains; ++c) {
+        if (cur[c] != root[c]) {
+          if (nx[c] != root[c]) nodes.parent[cur[c]] = root[c];
+          cur[c] = nx[c];
+          any = any || (cur[c] != root[c]);
         }
       }
-      if (inert) {
-        kept_all[gpos] = 1;
-        settled = 1;
+    }
+  }
+  int ti[kFilterPer], active[kFilterPer], settled[kFilterPer];
+#pragma unroll
+  for (int e = 0; e < kFilterPer; ++e) {
+    ti[e] = active[e] = settled[e] = 0;
+    const int ra = root[2 * e], rb = root[2 * e + 1];
+    if (!valid[e] || ra == rb) continue;
+    if (P.spatial_survivors && l_type[e] == 0 && !P.spatial_survivors[gpos[e]]) continue;   // the edge is gone
+    bool inert = false;
+    if (inert_mode != 0) {
+      const int f1 = nodes.flags[ra], f2 = nodes.flags[rb];
+      bool both_final_large = false;
+      if ((f1 & kFlagFinalized) && (f2 & kFlagFinalized)) {
+        const int s1 = __float_as_int(nodes.desc_sz[ra].w);
+        const int s2 = __float_as_int(nodes.desc_sz[rb].w);
+        both_final_large = (s1 >= P.min_region_size) && (s2 >= P.min_region_size);
+      }
+      if (inert_mode == 1) {
+        inert = both_final_large;
       } else {
-        active = 1;
-        CcUnion(cc, ra, rb);
+        const int c1 = nodes.cons[ra], c2 = nodes.cons[rb];
+        if (c1 >= 0 && c2 >= 0) {
+          inert = (c1 != c2);            // different constraints: never merged
+        } else {
+          inert = both_final_large;      // at least one unconstrained
+        }
+        if (inert) {
+          ti[e] = 1;
+          if (!(f1 & kFlagTentative)) nodes.flags[ra] = (uint8_t)(f1 | kFlagTentative);
+          if (!(f2 & kFlagTentative)) nodes.flags[rb] = (uint8_t)(f2 | kFlagTentative);
+        }
       }
+    }
+    if (inert) {
+      kept_all[gpos[e]] = 1;
+      settled[e] = 1;
+    } else {
+      active[e] = 1;
+      CcUnion(cc, ra, rb);
     }
   }
   // What the edge turned out to be is three bits per edge, one 64-bit word per wavefront and
   // class (a dense flag + code array per edge was 5 of the 17 bytes this kernel wrote per edge,
-  // with 2 % of the edges active), plus the number of active edges per workgroup for the ordered
-  // compaction (k_compact_active).
-  const unsigned long long ma = __ballot(active != 0);
-  const unsigned long long ms = __ballot(settled != 0);
-  const unsigned long long mt = __ballot(ti != 0);
+  // with 2 % of the edges active), plus the number of active edges per block of 256 edges for the
+  // ordered compaction (k_compact_active).
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) {
-    const size_t gw = (size_t)blockIdx.x * 4 + w;
-    M.active[gw] = ma;
-    M.settled[gw] = ms;
-    M.tentative[gw] = mt;
-    wave_cnt[w] = (int)__popcll(ma);
-    wave_kept[w] = (int)__popcll(ma | ms);
-    // (only "any" is read back; an atomic per wavefront on this one word would serialise the
-    // kernel wherever constrained regions meet)
-    if (mt != 0 && *num_ti == 0) *num_ti = 1;
+  const int n_blocks = (n_b + 255) >> 8;
+  unsigned long long ma[kFilterPer], ms[kFilterPer];
+#pragma unroll
+  for (int e = 0; e < kFilterPer; ++e) {
+    ma[e] = __ballot(active[e] != 0);
+    ms[e] = __ballot(settled[e] != 0);
+    const unsigned long long mt = __ballot(ti[e] != 0);
+    const int vb = blockIdx.x * kFilterPer + e;   // the block of 256 edges
+    if (lane == 0 && vb < n_blocks) {
+      const size_t gw = (size_t)vb * 4 + w;
+      M.active[gw] = ma[e];
+      M.settled[gw] = ms[e];
+      M.tentative[gw] = mt;
+      wave_cnt[e][w] = (int)__popcll(ma[e]);
+      wave_kept[e][w] = (int)__popcll(ma[e] | ms[e]);
+      // (only "any" is read back; an atomic per wavefront on this one word would serialise the
+      // kernel wherever constrained regions meet)
+      if (mt != 0 && *num_ti == 0) *num_ti = 1;
+    }
   }
   __syncthreads();
   // Roots and position only where something reads them back (the compaction: active; the
   // clearing of the marks: tentative; the rollback: every kept mark the filter set) -- most
-  // edges of a stage are internal, so the records of a workgroup's active / settled edges are
-  // packed at the head of the workgroup's 256 slots (FilterSlot: the readers recompute the rank
+  // edges of a stage are internal, so the records of a block's active / settled edges are
+  // packed at the head of the block's 256 slots (FilterSlot: the readers recompute the rank
   // from the masks); scattered 4-byte stores cost a 64-byte sector each.
-  if (active | settled) {
-    int rank = (int)__popcll((ma | ms) & ((1ull << lane) - 1ull));
-    for (int k = 0; k < w; ++k) rank += wave_kept[k];
-    const int slot = blockIdx.x * 256 + rank;
-    e_ra[slot] = ra;
-    e_rb[slot] = rb;
-    e_gpos[slot] = gpos;
+#pragma unroll
+  for (int e = 0; e < kFilterPer; ++e) {
+    const int vb = blockIdx.x * kFilterPer + e;
+    if (active[e] | settled[e]) {
+      int rank = (int)__popcll((ma[e] | ms[e]) & ((1ull << lane) - 1ull));
+      for (int k = 0; k < w; ++k) rank += wave_kept[e][k];
+      const int slot = vb * 256 + rank;
+      e_ra[slot] = root[2 * e];
+      e_rb[slot] = root[2 * e + 1];
+      e_gpos[slot] = gpos[e];
+    }
+    if (threadIdx.x == 0 && vb < n_blocks) {
+      M.block_cnt[vb] = wave_cnt[e][0] + wave_cnt[e][1] + wave_cnt[e][2] + wave_cnt[e][3];
+    }
   }
-  if (threadIdx.x == 0) M.block_cnt[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
 // Where k_filter left the record (roots, kept position) of edge j of the stage: the rank of the
@@ -654,7 +821,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   }
   if (n_b <= 0) return;
   const int bucket_hi = S.group_hi > bucket ? S.group_hi : bucket + 1;
-  int32_t* d_num_ti = TakeZeroed(S, 2);   // fresh counters per stage: nothing to clear
+  int32_t* d_num_ti = TakeStageScalars(S, 2);   // fresh counters per stage: nothing to clear
   int32_t* d_violation = d_num_ti + 1;
   int32_t* d_num_leaders = S.num_active + 5;
   // The stage's non-empty (bucket, list) segments, from the host copy of the bucket table.
@@ -696,7 +863,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   }
   const int ef0 = NextEvent(S);
   if (ef0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ef0], s));
-  hipLaunchKernelGGL(k_filter, dim3(Blocks(n_b)), dim3(256), 0, s, bucket, bucket_hi, j0, n_b, lists,
+  hipLaunchKernelGGL(k_filter, dim3((unsigned)((n_b + kFilterEdges - 1) / kFilterEdges)), dim3(256), 0, s, bucket, bucket_hi, j0, n_b, lists,
                      bucket_base, S.bucket_prefix, list_slot_base, kept_all, nodes, P, inert_mode, S.cc, S.e_ra, S.e_rb, S.e_gpos,
                      S.masks, d_num_ti, segs);
   const int ef1 = NextEvent(S);
@@ -848,7 +1015,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     VSG_HIP(hipStreamWaitEvent(S.aux_stream, S.aux_fork, 0));
     general_workers(wa, n_work, wave_grid, S.aux_stream);
     VSG_HIP(hipEventRecord(S.aux_join, S.aux_stream));
-    const bool done = RunSpineComponents(spine_in, wa, S, s, [&](const WorkerArgs& w, int n, hipStream_t st) {
+    const bool done = RunSpineComponents(spine_in, wa, n_work, S, s, [&](const WorkerArgs& w, int n, hipStream_t st) {
       general_workers(w, n, WaveGrid(n), st);
     }, 0, 0);
     if (!done) {   // no room in the scratch pool: the wave worker replays them

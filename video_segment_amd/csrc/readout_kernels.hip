@@ -237,11 +237,19 @@ void LaunchRelabelIntervals(const uint32_t* ty, const int32_t* lx, const int32_t
 
 // Open-addressing table of (pair -> smallest order key); empty = all ones.  *distinct counts the
 // pairs entered (the caller falls back to listing every pair when the table gets too full).
+// Once more than half the table is taken the caller's fall-back is certain (*distinct only grows),
+// so inserts stop there: a pair is only ever dropped after that point, and nobody probes a table
+// that is filling up (with 2^21 distinct pairs and more every insert would scan it end to end).
 __device__ __forceinline__ void PairTableInsert(const PairTable& t, unsigned long long pair,
                                                 unsigned long long order, int32_t* distinct) {
   unsigned long long x = pair * 0x9E3779B97F4A7C15ull;
   unsigned h = (unsigned)(x >> 40) & t.mask;
+  const int half = (int)((t.mask >> 1) + 1u);
   for (unsigned probe = 0; probe <= t.mask; ++probe) {
+    if ((probe & 63u) == 0 &&
+        __hip_atomic_load(distinct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > half) {
+      return;
+    }
     unsigned long long k = t.key[h];
     if (k == ~0ull) {
       k = atomicCAS(&t.key[h], ~0ull, pair);

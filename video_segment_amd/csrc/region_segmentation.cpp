@@ -430,12 +430,15 @@ struct FlowHist {
 // -- from a polynomial arctangent (Abramowitz & Stegun 4.4.49, |error| <= 2e-8 rad) where that
 // cannot be wrong: the bin position it gives has to be at least 1e-4 of a bin away from a bin edge,
 // 25 times what the polynomial, the float rounding of the angle and of the product can move it
-// together.  Returns -1 otherwise (edges, axes, zero and non-finite vectors: the caller evaluates
-// atan2).
+// together.  Returns -1 otherwise (edges, every vector with a zero component -- signed zeros --, zero
+// and non-finite vectors: the caller evaluates atan2).
 inline int FastFlowBin(float x, float y, int num_bins) {
   const double ax = std::fabs((double)x), ay = std::fabs((double)y);
   const double mx = std::max(ax, ay), mn = std::min(ax, ay);
   if (!(mx > 0) || !(mx <= std::numeric_limits<double>::max())) return -1;
+  // An axis-aligned vector has a zero component whose SIGN atan2 honours (atan2(-0.0, x < 0) = -pi,
+  // not +pi) and `y < 0` below cannot see: the caller evaluates atan2.
+  if (mn == 0) return -1;
   const double z = mn / mx, z2 = z * z;
   double p = 0.0028662257;
   p = p * z2 - 0.0161657367;

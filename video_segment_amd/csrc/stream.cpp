@@ -3,6 +3,7 @@
 #include "stream.h"
 
 #include <atomic>
+#include <exception>
 #include <thread>
 
 #include <algorithm>
@@ -277,9 +278,24 @@ void DenseSegmentationHip::ChunkBoundaryOutput(bool flush) {
       std::fill(ids, ids + wh_, -1);
       RenderIdImage(*overlap_segmentations_[k], W_, ids);
     };
-    std::thread other(render, 1);
-    render(0);
+    // (a throwing render -- VSG_REQUIRE in RenderIdImage, bad_alloc -- must neither leave a joinable
+    // thread behind nor escape from the second thread: both end in std::terminate)
+    std::exception_ptr other_error;
+    std::thread other([&] {
+      try {
+        render(1);
+      } catch (...) {
+        other_error = std::current_exception();
+      }
+    });
+    try {
+      render(0);
+    } catch (...) {
+      other.join();
+      throw;
+    }
     other.join();
+    if (other_error) std::rethrow_exception(other_error);
   }
   for (int k = 0; k < 2; ++k) {
     halo_ids_dev_[k].ensure(wh_);
