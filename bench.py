@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use device 0")
     ap.add_argument("--cpu-frames", type=int, default=20)
+    ap.add_argument("--pipelined-leg", action="store_true",
+                    help="also measure two chunk engines on one video (video_segment_amd/pipelined.py)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the information-only legs after the timed region (other configs, other "
                          "inputs, several streams per GPU)")
@@ -256,11 +258,26 @@ def kernel_table(W, H, chunk):
     profiles/<round>_kernel_table.json): counters cannot be collected inside the timed process."""
     if (W, H, chunk) != (1920, 1080, 20):
         return None
-    for tag in ("r4",):
+    for tag in PROFILE_TAGS:
         path = os.path.join(ROOT, "profiles", "%s_kernel_table.json" % tag)
         if os.path.exists(path):
-            return json.load(open(path))
+            t = json.load(open(path))
+            if t.get("source_hash") != kernel_source_hash():
+                # counters of other kernels than the ones that just ran are not quoted
+                return {"stale": True, "note": "%s was taken from other kernel sources (hash %s, running %s): "
+                                               "run tools/measure_round.sh" % (
+                                                   os.path.basename(path), t.get("source_hash"), kernel_source_hash())}
+            return t
     return None
+
+
+PROFILE_TAGS = ("r5", "r4", "r3", "r2")
+
+
+def kernel_source_hash():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_hash import source_hash
+    return source_hash(ROOT)
 
 
 def stage_ms(acc, steps):
@@ -337,6 +354,7 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps, out):
                       "steady-state chunks, inputs resident in HBM" % chunk,
           "value": fps4, "unit": "frames/s", "ms_per_step": r4["dt"] / 2 * 1e3,
           "stage_ms_per_step": stage_ms(r4["acc"], 2),
+          "device_bytes_per_stream": r4["device_bytes_per_stream"],
           "roofline_note": "%.0f B/px/frame -> %.2f GB/s" % (px_bytes, fps4 * w4 * h4 * px_bytes / 1e9)}
     if not args.no_cpu_baseline:
         ns = 8
@@ -436,28 +454,57 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps, out):
         fps = r["frames"] / r["dt"]
         wl[kind] = {"input": label, "value": fps, "unit": "frames/s", "ms_per_step": r["dt"] / 2 * 1e3,
                     "merges_per_step": r["acc"]["merges"] / 2, "stage_ms_per_step": stage_ms(r["acc"], 2)}
+        if not args.no_cpu_baseline:
+            # a short oracle sample of THIS input at THIS size (its first chunk, flushed; the oracle
+            # threaded the way the reference threads graph construction), byte for byte -- the
+            # full-size checks with a constrained chunk are tests/test_gpu_configs.py
+            ns = chunk
+            hf = [f.cpu().numpy() for f in fr[:ns]]
+            flh = synth.const_flow(W, H)
+            ol.set_threads(max(1, min(os.cpu_count() or 1, 8)))
+            try:
+                t0 = time.perf_counter()
+                st = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
+                g = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=device_index),
+                                          has_flow=True)
+                same = True
+                for k in range(ns):
+                    no = st.process_frame(hf[k], flh if k > 0 else None, flush=(k == ns - 1))
+                    ng = g.process_frame(fr[k], flow if k > 0 else None, flush=(k == ns - 1))
+                    same = same and no == ng and all(g.result_bytes(i) == st.result_bytes(i) for i in range(no))
+                same = same and bool((g.last_merge_stats() == st.last_merge_stats()).all())
+                g.close()
+                st.close()
+            finally:
+                ol.set_threads(1)
+            wl[kind]["parity_checked"] = bool(same)
+            wl[kind]["parity_sample"] = "first %d frames as one flushed chunk against oracle/libvs_oracle.so, %.1f s" % (
+                ns, time.perf_counter() - t0)
         del fr
     out["workloads"] = wl
 
     # ---- the same video over two chunk engines on the one GPU (video_segment_amd/pipelined.py) ------
-    fr = make_frames("bench", W, H, chunk + (chunk - 1) * 6, dev)
-    pipe = vsg.PipelinedDenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=device_index),
-                                          has_flow=True)
-    got = 0
-    for k, f in enumerate(fr):
-        got += pipe.process_frame(f, flow if k > 0 else None, flush=(k == len(fr) - 1))
-    stamps = pipe.stamps
-    pipe.close()
-    assert got == len(fr)
-    steady = (stamps[-2] - stamps[1]) / (len(stamps) - 3)   # without the first and the flushed chunk
-    out["pipelined"] = {
-        "workload": "the headline video, even chunks on one DenseSegmentation engine and odd chunks on a "
-                    "second one (two host threads, label planes handed over on the device): an engine "
-                    "builds its chunk graph while the other one merges; byte-identical output "
-                    "(tests/test_gpu_pipelined.py)",
-        "value": (chunk - 1) / steady, "unit": "frames/s", "ms_per_step": steady * 1e3,
-        "chunks_timed": len(stamps) - 3}
-    del fr
+    # (no longer part of the default extras: since round 4 it gains nothing over one stream, see
+    # DESIGN 7; tests/test_gpu_pipelined.py keeps it correct, --pipelined-leg measures it)
+    if args.pipelined_leg:
+        fr = make_frames("bench", W, H, chunk + (chunk - 1) * 6, dev)
+        pipe = vsg.PipelinedDenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=device_index),
+                                              has_flow=True)
+        got = 0
+        for k, f in enumerate(fr):
+            got += pipe.process_frame(f, flow if k > 0 else None, flush=(k == len(fr) - 1))
+        stamps = pipe.stamps
+        pipe.close()
+        assert got == len(fr)
+        steady = (stamps[-2] - stamps[1]) / (len(stamps) - 3)   # without the first and the flushed chunk
+        out["pipelined"] = {
+            "workload": "the headline video, even chunks on one DenseSegmentation engine and odd chunks on a "
+                        "second one (two host threads, label planes handed over on the device): an engine "
+                        "builds its chunk graph while the other one merges; byte-identical output "
+                        "(tests/test_gpu_pipelined.py)",
+            "value": (chunk - 1) / steady, "unit": "frames/s", "ms_per_step": steady * 1e3,
+            "chunks_timed": len(stamps) - 3}
+        del fr
 
     # ---- S concurrent streams on the one GPU -------------------------------------------------------
     # One PROCESS per stream (the control flow of --gpus S with every rank on this GPU: gloo barrier
@@ -568,11 +615,31 @@ def main():
         r = time_streams(vsg, frames, flow, W, H, chunk, S, Wm, K, local_rank, barrier)
         tt = torch.tensor([r["dt"]], dtype=torch.float64, device=dev)
         fo = torch.tensor([r["frames"]], dtype=torch.float64, device=dev)
+        ranks_info = None
         if world > 1:
+            # what every rank did on its own clock, and what the collective backend itself saw: a
+            # SUM of ones over the process group is the number of ranks the all-reduce (RCCL over
+            # xGMI with the nccl backend) really spanned, the devices show that they are distinct
+            mine = torch.tensor([r["frames"] / r["dt"], float(local_rank), 1.0], dtype=torch.float64, device=dev)
+            gathered = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            ones = torch.ones(1, dtype=torch.float64, device=dev)
+            dist.all_reduce(ones, op=dist.ReduceOp.SUM)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.all_reduce(fo, op=dist.ReduceOp.SUM)
+            props = torch.cuda.get_device_properties(local_rank)
+            ranks_info = {
+                "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                "allreduce_sum_of_ones": float(ones.item()),
+                "per_rank_frames_per_s": [float(g[0].item()) for g in gathered],
+                "per_rank_device_index": [int(g[1].item()) for g in gathered],
+                "rank0_device": "%s (%d CUs, %.0f GB)" % (props.name, props.multi_processor_count,
+                                                          props.total_memory / 1e9),
+                "expected": "streams are independent (no data-path collective): >= 0.95 x N x the one-GPU "
+                            "value with two free host cores per GPU, per-rank values within a few per cent "
+                            "of each other (DESIGN 7)"}
         result = {"dt": float(tt.item()), "frames": float(fo.item()), "acc": r["acc"],
-                  "device_bytes_per_stream": r["device_bytes_per_stream"],
+                  "device_bytes_per_stream": r["device_bytes_per_stream"], "ranks": ranks_info,
                   "parallelism": "%d independent 1080p stream(s) per GPU x %d GPU(s)" % (S, world)}
         # PCIe-inclusive leg (rank 0, one stream, not `value`): the same steady-state chunks with
         # frames and flow handed over as host buffers, so that the H2D copies are timed as well.
@@ -624,13 +691,18 @@ def main():
         traffic, traffic_note = None, "no PMC summary under profiles/"
         traffic_same_run = None
         pmc_path = None
-        for tag in ("r4", "r3", "r2"):
+        for tag in PROFILE_TAGS:
             cand = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag, dom[0]))
             if os.path.exists(cand):
                 pmc_path = cand
                 break
-        if pmc_path and (W, H, chunk) == (1920, 1080, 20):
-            pmc = json.load(open(pmc_path))
+        pmc = json.load(open(pmc_path)) if pmc_path else None
+        if pmc is not None and pmc.get("source_hash") != kernel_source_hash():
+            traffic_note = ("%s was taken from other kernel sources (hash %s, running %s): not quoted; "
+                            "tools/measure_round.sh collects it" % (os.path.basename(pmc_path),
+                                                                   pmc.get("source_hash"), kernel_source_hash()))
+            pmc = None
+        if pmc is not None and (W, H, chunk) == (1920, 1080, 20):
             traffic = pmc["fetch_bytes_per_launch_raw"] + pmc["write_bytes_per_launch_raw"]
             traffic_note = ("FETCH_SIZE + WRITE_SIZE per launch, raw counters, from " + pmc["source"])
             # (the counter passes are a run of their own, with their own number of launches: the
@@ -694,6 +766,7 @@ def main():
             },
             "stage_ms_per_step": stage_ms(acc, K),
             "device_bytes_per_stream": result.get("device_bytes_per_stream"),
+            "ranks": result.get("ranks"),
             "edges_per_step": acc["edges_total"] / K,
             "merges_per_step": acc["merges"] / K,
         }

@@ -60,6 +60,13 @@ def test_two_ranks_control_flow(mode, port):
     # two ranks x two timed steps x 19 frames (streams) or one 4-chunk video (chain: 20 + 3 x 19)
     frames = out["value"] * out["ms_per_step"] * out["steps"] / 1e3
     assert abs(frames - (76 if mode == "streams" else 77)) < 1e-6
+    if mode == "streams":
+        # the N > 1 line says by itself how many ranks the collective backend spanned and what
+        # every one of them measured
+        rk = out["ranks"]
+        assert rk["world_size"] == 2 and rk["allreduce_sum_of_ones"] == 2.0 and rk["backend"] == "gloo"
+        assert len(rk["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in rk["per_rank_frames_per_s"])
+        assert out["value"] <= sum(rk["per_rank_frames_per_s"]) * (1 + 1e-9)   # MAX over ranks of the time
 
 
 def test_committed_round_line_carries_every_key():

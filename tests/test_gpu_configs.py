@@ -31,36 +31,65 @@ def vsg():
     return v
 
 
-def _stream_both(vsg, W, H, N, chunk, frame_fn, flow, pad_to=None):
+def _stream_both(vsg, W, H, N, chunk, frame_fn, flow, pad_to=None, flush_last=True, threads=1):
     """Feeds the same frames to the HIP stream and the oracle; returns the number of compared
-    messages.  pad_to: row stride in bytes of the frame buffer handed to both."""
-    g = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=flow)
-    o = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=flow)
-    fl = synth.const_flow(W, H) if flow else None
-    total = 0
-    for k in range(N):
-        frame = frame_fn(W, H, k)
-        if pad_to is not None:
-            buf = np.zeros((H, pad_to), np.uint8)
-            buf[:, :W * 3] = frame.reshape(H, W * 3)
-            frame = np.lib.stride_tricks.as_strided(buf, (H, W, 3), (pad_to, 3, 1))
-        f = fl if (flow and k > 0) else None
-        ng = g.process_frame(frame, f, flush=(k == N - 1))
-        no = o.process_frame(frame, f, flush=(k == N - 1))
-        assert ng == no, (k, ng, no)
-        if ng:
-            assert np.array_equal(g.last_merge_stats(), o.last_merge_stats()), k
-        for i in range(ng):
-            assert g.result_bytes(i) == o.result_bytes(i), "SegmentationDesc differs at %d/%d" % (k, i)
-        total += ng
-    g.close()
-    o.close()
-    return total
+    messages.  pad_to: row stride in bytes of the frame buffer handed to both; flush_last=False:
+    the stream just ends after a chunk boundary (the last chunk compared is a steady-state one);
+    threads: the oracle's graph construction threads (its results do not depend on them)."""
+    ol.set_threads(threads)
+    try:
+        g = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=flow)
+        o = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=flow)
+        fl = synth.const_flow(W, H) if flow else None
+        total = 0
+        for k in range(N):
+            frame = frame_fn(W, H, k)
+            if pad_to is not None:
+                buf = np.zeros((H, pad_to), np.uint8)
+                buf[:, :W * 3] = frame.reshape(H, W * 3)
+                frame = np.lib.stride_tricks.as_strided(buf, (H, W, 3), (pad_to, 3, 1))
+            f = fl if (flow and k > 0) else None
+            last = flush_last and k == N - 1
+            ng = g.process_frame(frame, f, flush=last)
+            no = o.process_frame(frame, f, flush=last)
+            assert ng == no, (k, ng, no)
+            if ng:
+                assert np.array_equal(g.last_merge_stats(), o.last_merge_stats()), k
+            for i in range(ng):
+                assert g.result_bytes(i) == o.result_bytes(i), "SegmentationDesc differs at %d/%d" % (k, i)
+            total += ng
+        g.close()
+        o.close()
+        return total
+    finally:
+        ol.set_threads(1)
 
 
 def test_bench_workload_1080p_vs_oracle(vsg):
     """The bench's own workload at full size, two chunk boundaries + flush, byte for byte."""
     assert _stream_both(vsg, 1920, 1080, 41, 20, synth.bench_frame, True) == 41
+
+
+@pytest.mark.parametrize("kind", ["blobs", "noise"])
+def test_bench_reported_inputs_1080p_vs_oracle(vsg, kind):
+    """The two inputs bench.py reports beside the headline (`workloads`: value noise with a thousand
+    regions per chunk, gradient + independent +-40 noise with percolating middle buckets) at the size
+    they are reported at -- where the size-triggered decompositions live (window targets per
+    bucket, kept-lane reservations, sampled list ranking, twelve windows) --: the unconstrained
+    first chunk and one steady-state constrained chunk, byte for byte."""
+    import torch
+    dev = torch.device("cuda", 0)
+
+    def frame(W, H, k):   # (the generator's torch form: the numpy one takes 1.5 s per noise frame;
+        return synth.frame_torch(kind, W, H, k, dev).cpu().numpy()   # tests/test_synth.py holds them equal)
+
+    assert _stream_both(vsg, 1920, 1080, 39, 20, frame, True, flush_last=False, threads=8) == 38
+
+
+def test_constrained_chunk_2560x1440_vs_oracle(vsg):
+    """Between the headline size and 4K (eight to nine bucket-0 windows): first and one constrained
+    chunk of the bench generator, byte for byte."""
+    assert _stream_both(vsg, 2560, 1440, 39, 20, synth.bench_frame, True, flush_last=False, threads=8) == 38
 
 
 def test_config0_standin_272x480_vs_oracle(vsg):
@@ -145,8 +174,8 @@ def test_config3_full_size_chain_stream_oracle(vsg):
 def test_config4_overseg_3840x2160_c5(vsg):
     """BASELINE configs[4], over-segmentation half, at the survey's C5 size: 3840x2160 + flow,
     N = 40, chunk 20 (the unconstrained chunk, one constrained chunk and the flushed tail).  The
-    first chunk (19 output frames) is byte-identical to the CPU oracle; the whole run is
-    deterministic and every frame checked is a partition with consistent sizes.  (The
+    first chunk AND the constrained chunk (38 output frames) are byte-identical to the CPU oracle;
+    the whole run is deterministic and every frame checked is a partition with consistent sizes.  (The
     hierarchical RegionSegmentation on top of it: tests/test_region_segmentation.py.)"""
     import torch
     W, H, N, chunk = 3840, 2160, 40, 20
@@ -173,11 +202,11 @@ def test_config4_overseg_3840x2160_c5(vsg):
     try:
         o = ol.OracleStream(W, H, ol.default_options(chunk_size=chunk), has_flow=True)
         want = []
-        for k in range(chunk):
+        for k in range(2 * chunk - 1):   # up to the boundary of the first constrained chunk
             n = o.process_frame(frames_h[k], fl_h if k > 0 else None, flush=False)
             want += [o.result_bytes(i) for i in range(n)]
         o.close()
     finally:
         ol.set_threads(1)
-    assert len(want) == chunk - 1
-    assert runs[0][:chunk - 1] == want
+    assert len(want) == 2 * (chunk - 1)
+    assert runs[0][:2 * (chunk - 1)] == want

@@ -50,3 +50,41 @@ def test_concurrent_handles_on_one_device(vsg):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("mode", [None, "1", "2"])
+def test_more_streams_than_cores(vsg, monkeypatch, mode):
+    """A stream's host thread waits for the device's scalars about 150 times per chunk (the mailbox,
+    DESIGN 4.8).  Spinning is the fastest way to wait while every stream has a core of its own; six
+    streams on two cores (sched_setaffinity) would starve each other -- and the oracle threads
+    beside them -- if they only ever spun.  Unset, VSG_MAIL_YIELD yields by itself once the process
+    holds more graphs than half its cores; 1 and 2 force the yielding and the sleeping wait.  Same
+    bytes, and the test finishes (the box has a hard timeout on hangs)."""
+    import os
+    import time
+    if mode is None:
+        monkeypatch.delenv("VSG_MAIL_YIELD", raising=False)
+    else:
+        monkeypatch.setenv("VSG_MAIL_YIELD", mode)
+    old = os.sched_getaffinity(0)
+    cores = sorted(old)[:2]
+    errors = []
+
+    def work(i):
+        try:
+            run_streams(vsg, 96 + 16 * (i % 3), 64 + 8 * (i % 3), 22 + i, ("bench", "smooth", "noise")[i % 3], True,
+                        8 + (i % 3), seed=40 + i)
+        except BaseException as e:   # noqa: BLE001
+            errors.append((i, e))
+    t0 = time.time()
+    try:
+        os.sched_setaffinity(0, cores)
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    finally:
+        os.sched_setaffinity(0, old)
+    assert not errors, errors
+    assert time.time() - t0 < 240

@@ -55,14 +55,13 @@ def test_chain_self_check_is_silent(vsg, monkeypatch, capfd):
                                  # a pool of zeroed counters so small that it changes halves within a chunk
                                  {"VSG_SPINE_MIN": "32", "VSG_ZERO_POOL": "4096", "VSG_SPINE_CHECK": "1"},
                                  # Euler tours ranked by sampling (every 64th arc) whatever their length
-                                 {"VSG_SPINE_MIN": "32", "VSG_RANK_SPLIT_MIN": "0", "VSG_SPINE_CHECK": "1",
-                                  "VSG_SPINE_BLOCK_MAX": "0"},
-                                 # the loops of the tree machinery as loops of kernels for every component
-                                 # (block mode off), and a stage's components split between the two forms
-                                 {"VSG_SPINE_MIN": "32", "VSG_SPINE_BLOCK_MAX": "0", "VSG_SPINE_CHECK": "1"},
-                                 {"VSG_SPINE_MIN": "32", "VSG_SPINE_BLOCK_MAX": "96", "VSG_SPINE_CHECK": "1"},
-                                 {"VSG_SPINE_MIN": "32", "VSG_SPINE_BLOCK_MAX": "200", "VSG_SPINE_MAX_EDGES": "4096",
-                                  "VSG_SPINE_FAST_MIN": "0"}])
+                                 {"VSG_SPINE_MIN": "32", "VSG_RANK_SPLIT_MIN": "0", "VSG_SPINE_CHECK": "1"},
+                                 # every round of the spanning forest answered before the next is launched
+                                 {"VSG_SPINE_MIN": "32", "VSG_BOR_AHEAD": "0", "VSG_SPINE_CHECK": "1"},
+                                 # the arrays that hold a stage's active edges start far too small and
+                                 # grow inside the stages (the compaction is repeated)
+                                 {"VSG_ACTIVE_CAP": "64"},
+                                 {"VSG_ACTIVE_CAP": "64", "VSG_SPINE_MIN": "32", "VSG_FORCE_ROLLBACK": "1"}])
 def test_stage_decomposition_variants(vsg, monkeypatch, env):
     """The stage driver's two decompositions are exact whatever their parameters: a bucket split
     into consecutive rank windows (each its own filter -> components -> replay), runs of equal

@@ -12,6 +12,7 @@ import sys
 
 sys.path.insert(0, __file__.rsplit("/", 1)[0])
 from pmc_summary import short  # noqa: E402
+from source_hash import source_hash  # noqa: E402
 
 HBM_PEAK = 8000.0
 
@@ -42,7 +43,7 @@ def main():
     print(json.dumps({"source": "rocprofv3 --kernel-trace --stats and --pmc FETCH_SIZE / WRITE_SIZE / LDS "
                                 "bank conflicts (separate passes) of 'bench.py --no-cpu-baseline --no-pcie-leg "
                                 "--no-extras', tools/measure_round.sh; raw counters",
-                      "chunks_profiled": chunks, "all_kernels_ms_per_step": total_ms,
+                      "source_hash": source_hash(), "chunks_profiled": chunks, "all_kernels_ms_per_step": total_ms,
                       "launches_per_step": sum(v[0] for v in per.values()) / chunks, "top": rows}, indent=1))
 
 

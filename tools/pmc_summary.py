@@ -17,7 +17,12 @@ uncalibrated -- the rates are lower bounds for streaming kernels."""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_hash import source_hash  # noqa: E402
+
 
 HBM_PEAK = 8000.0   # GB/s
 
@@ -113,6 +118,7 @@ def main():
                     "fetch_bytes_per_launch_raw": e.get("FETCH_SIZE_KB_per_launch", 0.0) * 1e3,
                     "write_bytes_per_launch_raw": e.get("WRITE_SIZE_KB_per_launch", 0.0) * 1e3,
                     "algorithmic_bytes_per_launch_same_run": same_run.get(tag),
+                    "source_hash": source_hash(),
                     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
                               "'bench.py --no-cpu-baseline --no-pcie-leg --no-extras', tools/measure_round.sh; "
                               "raw counters (gfx950: FETCH_SIZE may under-count wide streaming "

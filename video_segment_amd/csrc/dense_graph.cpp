@@ -6,6 +6,7 @@
 // FastSegmentationGraph::SegmentGraph / MergeConstrainedRegions / DetermineNeighborIdsImpl
 // (segmentation/segmentation_graph.h:339-496, 703-786).
 #include "dense_graph.h"
+#include "scan_device.h"
 
 #include <algorithm>
 #include <chrono>
@@ -97,8 +98,7 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   VSG_HIP(hipEventCreateWithFlags(&aux_fork_, hipEventDisableTiming));
   VSG_HIP(hipEventCreateWithFlags(&aux_join_, hipEventDisableTiming));
 
-  size_t temp = ScanTempBytes((int)N);
-  cub_temp_.alloc(temp);
+  scan_sums_.alloc(kScanMaxTiles);
   Reset(max_frames);
   MailRegisterGraph(1);
 }
@@ -219,12 +219,29 @@ void DenseGraphHip::AddTemporal(const float* cur, const float* prev, const float
 
 void DenseGraphHip::FinishBuilding() { VSG_HIP(hipStreamSynchronize(stream_)); }
 
+// Stage scratch comes in two sizes.  Per EDGE of a stage (the largest bucket: 139 M edges at 1080p):
+// only what k_filter leaves for every edge -- the packed records of the active / settled edges, three
+// mask bits, the per-block counts.  Per ACTIVE edge (a few per cent of a stage, 30 % in the bucket of
+// the giant components): everything the compaction, the run leaders, the sort by component, the
+// workers' segments and the undo buffers need -- 106 bytes per edge, which sized for the largest
+// bucket was 18 of the 29 GB a 1080p stream held.  The active arrays grow on demand (RunBucketStage
+// learns the number of active edges before it uses them) and keep their size between chunks.
 void DenseGraphHip::EnsureScratch(size_t n) {
   if (n <= scratch_edges_) return;
   n = n + n / 8 + 1024;
   e_ra_.alloc(n);
   e_rb_.alloc(n);
   e_gpos_.alloc(n);
+  // three mask words per 64 edges (rounded up to whole workgroups of 256 edges)
+  filter_masks_.alloc(3 * (4 * ((n + 255) / 256) + 4));
+  block_cnt_.alloc((n + 255) / 256 + 2);
+  block_off_.alloc((n + 255) / 256 + 2);
+  scratch_edges_ = n;
+}
+
+void DenseGraphHip::EnsureActiveScratch(size_t n) {
+  if (n <= scratch_active_) return;
+  n = n + n / 8 + 1024;
   e_active_.alloc(n);
   e_apos_.alloc(n);
   a_ra_.alloc(n);
@@ -237,10 +254,6 @@ void DenseGraphHip::EnsureScratch(size_t n) {
   seg_key_.alloc(n);
   seg_cnt_.alloc(n);
   seg_off_.alloc(n);
-  // three mask words per 64 edges (rounded up to whole workgroups of 256 edges)
-  filter_masks_.alloc(3 * (4 * ((n + 255) / 256) + 4));
-  block_cnt_.alloc((n + 255) / 256 + 2);
-  block_off_.alloc((n + 255) / 256 + 2);
   lead_pos_.alloc(n);
   l_ra_.alloc(n);
   l_rb_.alloc(n);
@@ -249,11 +262,10 @@ void DenseGraphHip::EnsureScratch(size_t n) {
   bk_cons_.alloc(2 * n);
   bk_flags_.alloc(2 * n);
   size_t temp = cub_temp_.size();
-  temp = std::max(temp, SortPairsU32TempBytes((int)n));
-  temp = std::max(temp, ScanTempBytes((int)n));
-  temp = std::max(temp, RleTempBytes((int)n));
+  // (the largest sort of a stage: the arcs of the spanning trees, two per tree edge -- merge_spine.hip)
+  temp = std::max(temp, SortPairsU32TempBytes((int)std::min<size_t>(2 * n, 0x7fffffff)));
   if (temp > cub_temp_.size()) cub_temp_.alloc(temp);
-  scratch_edges_ = n;
+  scratch_active_ = n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -395,25 +407,56 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   for (int b = 0; b < kNumBuckets; ++b) n_max = std::max<int64_t>(n_max, bucket_prefix[b + 1] - bucket_prefix[b]);
   VSG_REQUIRE(bucket_prefix[kNumBuckets] >= 0, -1, "too many edges");
   EnsureScratch((size_t)std::max<int64_t>(n_max, 1));
+  // (a first guess for a handle that has not seen a chunk yet; later chunks start with what the
+  // earlier ones needed)
+  if (const char* e = getenv("VSG_ACTIVE_CAP")) {   // test hook: start small, grow inside the stages
+    EnsureActiveScratch((size_t)std::max(1, atoi(e)));
+  } else {
+    EnsureActiveScratch(std::min<size_t>((size_t)std::max<int64_t>(n_max, 1),
+                                         std::max<size_t>((size_t)n_max / 8, (size_t)1 << 20)));
+  }
   bucket_prefix_dev_.ensure(bucket_prefix.size());
   H2D(bucket_prefix_dev_.get(), bucket_prefix.data(), bucket_prefix.size(), stream_);
 
   MergeScratch S = {};
-  S.e_ra = e_ra_.get();
-  S.e_rb = e_rb_.get();
-  S.e_gpos = e_gpos_.get();
-  S.e_active = e_active_.get();
-  S.e_apos = e_apos_.get();
-  S.a_ra = a_ra_.get();
-  S.a_rb = a_rb_.get();
-  S.a_gpos = a_gpos_.get();
-  S.a_comp = a_comp_.get();
-  S.a_idx = a_idx_.get();
-  S.s_comp = s_comp_.get();
-  S.s_idx = s_idx_.get();
-  S.seg_key = seg_key_.get();
-  S.seg_cnt = seg_cnt_.get();
-  S.seg_off = seg_off_.get();
+  auto bind_scratch = [this, &S]() {
+    S.e_ra = e_ra_.get();
+    S.e_rb = e_rb_.get();
+    S.e_gpos = e_gpos_.get();
+    S.e_active = e_active_.get();
+    S.e_apos = e_apos_.get();
+    S.a_ra = a_ra_.get();
+    S.a_rb = a_rb_.get();
+    S.a_gpos = a_gpos_.get();
+    S.a_comp = a_comp_.get();
+    S.a_idx = a_idx_.get();
+    S.s_comp = s_comp_.get();
+    S.s_idx = s_idx_.get();
+    S.seg_key = seg_key_.get();
+    S.seg_cnt = seg_cnt_.get();
+    S.seg_off = seg_off_.get();
+    S.lead_pos = lead_pos_.get();
+    S.l_ra = l_ra_.get();
+    S.l_rb = l_rb_.get();
+    S.l_gpos = l_gpos_.get();
+    S.bk_ds = bk_ds_.get();
+    S.bk_cons = bk_cons_.get();
+    S.bk_flags = bk_flags_.get();
+    S.cub_temp = cub_temp_.get();
+    S.cub_temp_bytes = cub_temp_.size();
+    S.scan = ScanScratch{scan_sums_.get()};
+    S.active_cap = (int)std::min<size_t>(scratch_active_, 0x7fffffff);
+  };
+  bind_scratch();
+  S.grow_active = [this, bind_scratch](long long need) {
+    // (nothing of the stage is in the active arrays yet: RunBucketStage asks before it uses them)
+    VSG_HIP(hipStreamSynchronize(stream_));
+    VSG_HIP(hipStreamSynchronize(aux_stream_));
+    VSG_HIP(hipStreamSynchronize(aux2_stream_));
+    EnsureActiveScratch((size_t)need);
+    bind_scratch();
+    return true;
+  };
   S.num_active = scalars_.get();
   S.num_segs = scalars_.get() + 1;
   {
@@ -424,9 +467,6 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     S.masks.block_cnt = block_cnt_.get();
     S.block_off = block_off_.get();
   }
-  S.bk_ds = bk_ds_.get();
-  S.bk_cons = bk_cons_.get();
-  S.bk_flags = bk_flags_.get();
   S.force_rollback = getenv("VSG_FORCE_ROLLBACK") ? 1 : 0;
   S.small_seg = getenv("VSG_SMALL_SEG") ? std::max(1, atoi(getenv("VSG_SMALL_SEG"))) : 24;
   // Sizes that follow the graph rather than the 1080p bench: the tree replay's scratch pool holds
@@ -465,9 +505,6 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.spine_debug = getenv("VSG_SPINE_DEBUG") ? 1 : 0;
   S.spine_check = getenv("VSG_SPINE_CHECK") ? 1 : 0;
   S.rank_split_min = getenv("VSG_RANK_SPLIT_MIN") ? atoi(getenv("VSG_RANK_SPLIT_MIN")) : (1 << 20);
-  // (a workgroup of 1024 threads walks 32 edges per thread and phase at 32 K edges: above that the
-  // loops of kernels over all CUs are the faster form again)
-  S.spine_block_max = getenv("VSG_SPINE_BLOCK_MAX") ? atoi(getenv("VSG_SPINE_BLOCK_MAX")) : 32768;
   S.spine_fast = getenv("VSG_SPINE_FAST") ? atoi(getenv("VSG_SPINE_FAST")) : 2;   // streamed passes
   S.spine_fast_min = getenv("VSG_SPINE_FAST_MIN") ? atoi(getenv("VSG_SPINE_FAST_MIN")) : 32768;
   if (S.spine_min > 0) {
@@ -507,10 +544,6 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.aux2_stream = aux2_stream_;
   S.aux_fork = aux_fork_;
   S.aux_join = aux_join_;
-  S.lead_pos = lead_pos_.get();
-  S.l_ra = l_ra_.get();
-  S.l_rb = l_rb_.get();
-  S.l_gpos = l_gpos_.get();
   S.use_rle = getenv("VSG_RLE") ? atoi(getenv("VSG_RLE")) : 1;
   S.wave_dbg = getenv("VSG_WAVE_DBG") ? atoi(getenv("VSG_WAVE_DBG")) : 0;
   S.wave_debug = (S.wave_dbg != 0 || getenv("VSG_DEBUG_STAGES") || getenv("VSG_DEBUG_STATS")) ? 1 : 0;
@@ -520,8 +553,6 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.rollbacks = &rollbacks_;
   S.cc = cc_.get();
   S.stats = stats_.get();
-  S.cub_temp = cub_temp_.get();
-  S.cub_temp_bytes = cub_temp_.size();
   ev_used_ = 0;
   ev_wave_.clear();
   ev_filter_.clear();
@@ -898,7 +929,7 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
     const int n = end - begin;
     if (n <= 0) return;
     LaunchConstrainedRuns(nodes(), begin, end, d_vals, d_flags, stream_);
-    ExclusiveSumI32(cub_temp_.get(), cub_temp_.size(), d_flags, d_offs, n, stream_);
+    ExclusiveSum(ScanScratch{scan_sums_.get()}, d_flags, d_offs, n, stream_);
     int last_off = 0, last_flag = 0;
     D2H(&last_off, d_offs + (n - 1), 1, stream_);
     D2H(&last_flag, d_flags + (n - 1), 1, stream_);
@@ -906,7 +937,7 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
     const int k = last_off + last_flag;
     const size_t old = out->node.size();
     if (k > 0) {
-      EnsureScratch((size_t)k);
+      EnsureActiveScratch((size_t)k);
       LaunchCompactIndexValue(d_flags, d_offs, d_vals, n, a_ra_.get(), a_rb_.get(), stream_);
       out->node.resize(old + k);
       out->value.resize(old + k);
@@ -1175,8 +1206,7 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
                        stream_);
   }
   VSG_HIP(hipMemsetAsync(row_counts_.get() + rows, 0, sizeof(int32_t), stream_));
-  ExclusiveSumI32(cub_temp_.get(), cub_temp_.size(), row_counts_.get(), row_offsets_.get(),
-                  rows + 1, stream_);
+  ExclusiveSum(ScanScratch{scan_sums_.get()}, row_counts_.get(), row_offsets_.get(), rows + 1, stream_);
   int num_iv = 0;
   D2H(&num_iv, row_offsets_.get() + rows, 1, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
@@ -1208,7 +1238,7 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
     int32_t* d_flags = cc_.get();
     int32_t* d_offs = label_img_.get();
     LaunchNonzeroFlags(adjust_.get(), (int)N, d_flags, stream_);
-    ExclusiveSumI32(cub_temp_.get(), cub_temp_.size(), d_flags, d_offs, (int)N, stream_);
+    ExclusiveSum(ScanScratch{scan_sums_.get()}, d_flags, d_offs, (int)N, stream_);
     int lo = 0, lf = 0;
     D2H(&lo, d_offs + (N - 1), 1, stream_);
     D2H(&lf, d_flags + (N - 1), 1, stream_);

@@ -96,6 +96,7 @@ class DenseGraphHip {
   };
 
   void EnsureScratch(size_t n_edges_max);
+  void EnsureActiveScratch(size_t n_active_max);
   void DebugHash(const char* where);
   void SortList(ListBuf& lb, int per_px);
   void MergeConstrainedHostAssisted();
@@ -177,8 +178,10 @@ class DenseGraphHip {
   double last_density_ = 1.0;                      // active / all edges of the last measured stage
   int spine_max_edges_grown_ = 0;   // what the pool was enlarged to for this video's largest stage
   DevBuf<unsigned long long> stats_;
-  DevBuf<uint8_t> cub_temp_;
-  size_t scratch_edges_ = 0;
+  DevBuf<uint8_t> cub_temp_;      // temporary storage of the library radix sort
+  DevBuf<int32_t> scan_sums_;     // tile sums of the hand-written scans (scan_device.h)
+  size_t scratch_edges_ = 0;    // capacity of the per-edge stage scratch (EnsureScratch)
+  size_t scratch_active_ = 0;   // capacity of the per-active-edge stage scratch (EnsureActiveScratch)
   // flow sampling for the tube analysis
   DevBuf<int32_t> flow_req_dev_;
   DevBuf<float2> flow_samples_dev_;

@@ -90,7 +90,14 @@ void LaunchInitNodes(const float* feat, size_t n, int base, const int32_t* cons_
 void LaunchInitVirtualNodes(const int32_t* labels, size_t n, int base, int num_labels,
                             int32_t* first_scratch, NodeArrays nodes, hipStream_t s);
 
-// ---- sort_scan.hip (hipCUB wrappers) --------------------------------------------------
+// ---- scan_device.h: hand-written device-wide scans (the merge path and the read-out) -------------------
+// Scratch of the scans of one stream (all scans of a graph run on its main stream): the tile sums.
+constexpr int kScanMaxTiles = 4096;
+struct ScanScratch {
+  int32_t* sums;   // [kScanMaxTiles]
+};
+
+// ---- sort_scan.hip (rocPRIM radix sort, and the 64-bit sort / unique of the read-out) -----------------
 size_t SortPairsU32TempBytes(int n);
 void SortPairsU32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
                   const uint32_t* vals_in, uint32_t* vals_out, int n, int end_bit, hipStream_t s);
@@ -98,13 +105,6 @@ size_t SortKeysU64TempBytes(int n);
 void SortKeysU64(void* temp, size_t temp_bytes, const unsigned long long* in,
                  unsigned long long* out, int n,
                  hipStream_t s);
-size_t ScanTempBytes(int n);
-void ExclusiveSumI32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, int n,
-                     hipStream_t s);
-size_t RleTempBytes(int n);
-// unique_out[num_runs], counts_out[num_runs], *num_runs_out (device)
-void RunLengthEncodeU32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* unique_out,
-                        int32_t* counts_out, int32_t* num_runs_out, int n, hipStream_t s);
 size_t UniqueU64TempBytes(int n);
 void UniqueU64(void* temp, size_t temp_bytes, const unsigned long long* in,
                unsigned long long* out,
@@ -177,7 +177,11 @@ struct FilterSegs {
   int n;
 };
 struct MergeScratch {
-  // sized for the largest bucket (n_max edges)
+  // e_ra / e_rb / e_gpos, the masks and the block counts are sized for the largest bucket; everything
+  // else holds active edges only: active_cap of them (grow_active enlarges those arrays -- all
+  // streams are drained, nothing of the current stage may be in them yet -- and rebinds the pointers)
+  int active_cap;
+  std::function<bool(long long need)> grow_active;
   int32_t* e_ra;         // root of node a at filter time (per bucket edge)
   int32_t* e_rb;
   uint32_t* e_gpos;      // global kept position (list_slot_base[l] + pos)
@@ -226,8 +230,6 @@ struct MergeScratch {
   int spine_max_edges;   // at most this many edges per stage (scratch pool)
   int spine_debug, spine_check;
   int rank_split_min;    // Euler tours of at least this many arcs are ranked by sampling (k_rank_walk)
-  int spine_block_max;   // components of at most this many edges: one workgroup each runs the loops of
-                         // the tree machinery (forest rounds, list ranking, path maxima); 0: never
   int spine_fast;        // the plain steps of a spine through the streamed chain (k_spine_chain)
   int spine_fast_min;    // ... from this many tree edges on (seven more launches)
   int32_t* spine_pool;   // scratch, SpinePoolInts(spine_max_edges) ints
@@ -248,8 +250,9 @@ struct MergeScratch {
   int64_t* rollbacks;
   int32_t* cc;           // [N] component scratch (identity outside a stage)
   unsigned long long* stats;   // [16]: forced, regular, small, wave edges, debug x4; [8..15] undo copy
-  void* cub_temp;
+  void* cub_temp;        // temporary storage of the radix sort
   size_t cub_temp_bytes;
+  ScanScratch scan;
   // HIP event pairs recorded around k_filter / k_merge_wave launches (resolved by the caller
   // after the stream has been synchronised).
   std::vector<hipEvent_t>* ev_pool;

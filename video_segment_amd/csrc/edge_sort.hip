@@ -56,24 +56,6 @@ __device__ __forceinline__ int TruncToIntX86(float v) {
   return (int)v;
 }
 
-// hist[bin] += 1 for every lane of the wavefront (bin < 0: the lane has nothing), with one LDS
-// atomic per RUN of equal bins in consecutive lanes.  Neighbouring edges of a smooth frame have equal
-// keys, and 64 lanes adding to one LDS word serialise (80-90 % of the LDS cycles of the key kernels
-// were bank conflicts): the lane before is compared through a DPP wave shift, a ballot marks the
-// run heads, and a head adds the distance to the next head.  All 64 lanes have to be active.
-__device__ __forceinline__ void HistAddRuns(int32_t* __restrict__ hist, int bin) {
-  const int lane = (int)(threadIdx.x & 63);
-  // wave_shr:1 -- lane i receives lane i - 1, lane 0 keeps -2 (no bin)
-  const int prev = __builtin_amdgcn_update_dpp(-2, bin, 0x138, 0xf, 0xf, false);
-  const bool head = prev != bin;
-  const unsigned long long heads = __ballot(head);
-  if (head && bin >= 0) {
-    const unsigned long long above = (heads >> lane) >> 1;   // the heads after this lane
-    const int len = above ? (int)__builtin_ctzll(above) + 1 : 64 - lane;
-    atomicAdd(&hist[bin], len);
-  }
-}
-
 // The matrix is zeroed before the kernel (one coalesced memset); a tile only touches the few bins
 // it has edges in -- 2050 scattered 4-byte stores per tile would cost more HBM write traffic than
 // the keys themselves.
@@ -100,14 +82,12 @@ __global__ __launch_bounds__(256) void k_spatial_keys(const float* __restrict__ 
   const size_t base = (size_t)blockIdx.x * kTilePxSpatial;
 #pragma unroll 2
   for (int i = 0; i < kTilePxSpatial / 256; ++i) {
-    if (base + (size_t)i * 256 >= n) break;   // (the whole workgroup: HistAddRuns needs full wavefronts)
     const size_t pix = base + (size_t)i * 256 + threadIdx.x;
-    const bool in = pix < n;
-    const size_t pc = in ? pix : n - 1;
-    const int y = (int)(pc / W), x = (int)(pc - (size_t)y * W);
-    const float ab = fb[pc], ag = fg[pc], ar = fr[pc];
+    if (pix >= n) break;
+    const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
+    const float ab = fb[pix], ag = fg[pix], ar = fr[pix];
     ushort4 k4 = make_ushort4(kInvalidKey, kInvalidKey, kInvalidKey, kInvalidKey);
-    const bool has_r = in && x < W - 1, has_b = in && y < H - 1, has_l = x > 0;
+    const bool has_r = x < W - 1, has_b = y < H - 1, has_l = x > 0;
     if (has_r) {
       const size_t q = pix + 1;
       k4.x = BucketOf(ColorDist(ab, ag, ar, fb[q], fg[q], fr[q], l1));
@@ -124,11 +104,11 @@ __global__ __launch_bounds__(256) void k_spatial_keys(const float* __restrict__ 
         k4.w = BucketOf(ColorDist(ab, ag, ar, fb[q], fg[q], fr[q], l1));
       }
     }
-    if (in) keys[pix] = k4;
-    HistAddRuns(lds_hist, !in ? -1 : k4.x == kInvalidKey ? kBinInvalid : (int)k4.x);
-    HistAddRuns(lds_hist, !in ? -1 : k4.y == kInvalidKey ? kBinInvalid : (int)k4.y);
-    HistAddRuns(lds_hist, !in ? -1 : k4.z == kInvalidKey ? kBinInvalid : (int)k4.z);
-    HistAddRuns(lds_hist, !in ? -1 : k4.w == kInvalidKey ? kBinInvalid : (int)k4.w);
+    keys[pix] = k4;
+    atomicAdd(&lds_hist[k4.x == kInvalidKey ? kBinInvalid : k4.x], 1);
+    atomicAdd(&lds_hist[k4.y == kInvalidKey ? kBinInvalid : k4.y], 1);
+    atomicAdd(&lds_hist[k4.z == kInvalidKey ? kBinInvalid : k4.z], 1);
+    atomicAdd(&lds_hist[k4.w == kInvalidKey ? kBinInvalid : k4.w], 1);
   }
   __syncthreads();
   StoreTileHist(lds_hist, blockIdx.x, num_tiles, hist);
@@ -154,24 +134,22 @@ __global__ __launch_bounds__(256) void k_temporal_keys(const float* __restrict__
     const size_t pix0 = base + (size_t)i * 256;
     if (pix0 >= n) break;
     const size_t pix = pix0 + threadIdx.x;
-    const bool in = pix < n;   // (every lane walks the nine neighbours: HistAddRuns needs full wavefronts)
-    {
-      const size_t pc = in ? pix : n - 1;
-      const int y = (int)(pc / W), x = (int)(pc - (size_t)y * W);
+    if (pix < n) {
+      const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
       int px = x, py = y;
       if (flow) {
-        const float2 f = reinterpret_cast<const float2*>(flow)[pc];
+        const float2 f = reinterpret_cast<const float2*>(flow)[pix];
         px = TruncToIntX86((float)x + f.x);
         py = TruncToIntX86((float)y + f.y);
         px = max(0, min(W - 1, px));
         py = max(0, min(H - 1, py));
       }
-      if (in) prev_idx[pix] = py * W + px;
+      prev_idx[pix] = py * W + px;
       float ab = 0, ag = 0, ar = 0;
       if (!is_virtual) {
-        ab = cur[pc];
-        ag = cur[n + pc];
-        ar = cur[2 * n + pc];
+        ab = cur[pix];
+        ag = cur[n + pix];
+        ar = cur[2 * n + pix];
       }
       int k = 0;
 #pragma unroll
@@ -180,7 +158,7 @@ __global__ __launch_bounds__(256) void k_temporal_keys(const float* __restrict__
         for (int dx = -1; dx <= 1; ++dx, ++k) {
           uint16_t key = kInvalidKey;
           const int qy = py + dy, qx = px + dx;
-          if (in && qy >= 0 && qy < H && qx >= 0 && qx < W) {
+          if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
             if (is_virtual) {
               key = (uint16_t)kNumBuckets;
             } else {
@@ -188,8 +166,8 @@ __global__ __launch_bounds__(256) void k_temporal_keys(const float* __restrict__
               key = BucketOf(ColorDist(ab, ag, ar, prev[q], prev[n + q], prev[2 * n + q], l1));
             }
           }
-          if (in) stage[threadIdx.x * 9 + k] = key;
-          HistAddRuns(lds_hist, !in ? -1 : key == kInvalidKey ? kBinInvalid : (int)key);
+          stage[threadIdx.x * 9 + k] = key;
+          atomicAdd(&lds_hist[key == kInvalidKey ? kBinInvalid : key], 1);
         }
       }
     }
@@ -312,10 +290,9 @@ __global__ __launch_bounds__(256) void k_scatter_slots(const uint16_t* __restric
   // the wavefront's contiguous quarter (a multiple of 64 slots)
   const int quarter = ((n_slots + 255) / 256) * 64;
   const int q_beg = min(n_slots, wave * quarter), q_end = min(n_slots, (wave + 1) * quarter);
-  for (int i0 = q_beg; i0 < q_end; i0 += 64) {   // (whole wavefronts: HistAddRuns)
-    const int i = i0 + lane;
-    const int key = i < q_end ? (int)lds_keys[i] : -1;
-    HistAddRuns(cnt[wave], key < 0 ? -1 : key == kInvalidKey ? kBinInvalid : key);
+  for (int i = q_beg + lane; i < q_end; i += 64) {
+    const int key = lds_keys[i];
+    atomicAdd(&cnt[wave][key == kInvalidKey ? kBinInvalid : key], 1);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < kBucketSlots; b += 256) {
@@ -329,46 +306,20 @@ __global__ __launch_bounds__(256) void k_scatter_slots(const uint16_t* __restric
   }
   __syncthreads();
   const uint32_t slot0 = (uint32_t)(px0 * kPerPx);
-  const unsigned long long lt = (1ull << lane) - 1ull;
   for (int i0 = q_beg; i0 < q_end; i0 += 64) {
     const int i = i0 + lane;
     const bool valid = i < q_end;
     const int key = valid ? (int)lds_keys[i] : (int)kInvalidKey;
     const int bin = key == kInvalidKey ? kBinInvalid : key;
-    // Rank of the slot among the slots of the step with the same bin.  A step of a smooth frame
-    // holds a handful of distinct bins: they are peeled off one by one (first pending lane's bin,
-    // one compare = one ballot); a step that still has lanes pending after kPeel bins finishes
-    // with the twelve ballots of the bin's bits (a noisy frame: up to 64 distinct bins).
-    constexpr int kPeel = 5;
-    int rank = 0, tot = 0, leader = 0;
-    unsigned long long pend = ~0ull;   // (lanes past the end carry the bin of the edges that do not exist)
-    for (int it = 0; it < kPeel && pend != 0; ++it) {
-      const int ld = (int)__builtin_ctzll(pend);
-      const int kb = __builtin_amdgcn_readlane(bin, ld);
-      const unsigned long long m = __ballot(bin == kb);
-      if (bin == kb) {
-        rank = (int)__popcll(m & lt);
-        tot = (int)__popcll(m);
-        leader = ld;
-      }
-      pend &= ~m;
-    }
-    if (pend != 0) {
-      const unsigned long long same = SameBinMask(bin);   // (a pending lane's bin is pending in all its lanes)
-      if ((pend >> lane) & 1ull) {
-        rank = (int)__popcll(same & lt);
-        tot = (int)__popcll(same);
-        leader = (int)__builtin_ctzll(same);
-      }
-    }
-    // The step's first slot of every bin takes the bin's output range with one LDS atomic (LDS
-    // operations of a wavefront execute in program order, so step after step the ranges follow
-    // each other: stable) and hands the start to the others -- no barrier between the steps.
-    int start = 0;
-    if (rank == 0) start = atomicAdd(&cnt[wave][bin], tot);
-    start = __shfl(start, leader);
+    const unsigned long long same = SameBinMask(bin);
+    const int rank = (int)__popcll(same & ((1ull << lane) - 1ull));
+    const int start = cnt[wave][bin];
     // Slots of edges that do not exist are not listed (nothing ever reads that tail).
     if (valid && bin != kBinInvalid) slots_out[start + rank] = slot0 + (uint32_t)i;
+    __builtin_amdgcn_wave_barrier();
+    if (rank == 0) cnt[wave][bin] = start + (int)__popcll(same);   // one lane per distinct bin
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

@@ -386,11 +386,8 @@ constexpr int kSpineListCap = 4095;
 int SelectLargeSegments(int max_segs, const int32_t* num_segs, const int32_t* seg_off, const int32_t* seg_cnt,
                         int min_cnt, long long max_edges, MergeScratch& S, hipStream_t s, SpineInput* out,
                         long long* wanted_edges);
-// pool_used: ints of S.spine_pool already taken (by the caller's lists and outer levels); n_total:
-// edges in wa's arrays (what a fall-back launch of the ordinary workers is sized for).  Returns false
-// when nothing has been replayed (no room in the scratch pool): the caller hands the components to
-// the ordinary workers.
-bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, int n_total, MergeScratch& S, hipStream_t s,
+// pool_used: ints of S.spine_pool already taken (by the caller's lists and outer levels).
+bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch& S, hipStream_t s,
                         const SpineWorkers& run_workers, size_t pool_used, int depth);
 
 }  // namespace vsg

@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "merge_common.h"
+#include "scan_device.h"
 
 namespace vsg {
 
@@ -95,7 +96,16 @@ __global__ __launch_bounds__(256) void k_bor_min(int n, const int32_t* __restric
                                                   const int32_t* __restrict__ ev, int32_t* __restrict__ estate,
                                                   int32_t* __restrict__ cc, uint32_t* __restrict__ best,
                                                   int32_t* __restrict__ ecu, int32_t* __restrict__ ecv,
-                                                  int32_t* __restrict__ alive) {
+                                                  int32_t* __restrict__ alive, const int32_t* __restrict__ gate,
+                                                  int32_t* __restrict__ next_len) {
+  // next_len: the word the compaction after this round counts into (the length of the next list):
+  // cleared here, a round ahead of its use -- it has to outlive any number of rounds, which the
+  // rotating pool of zeroed counters does not promise.
+  if (blockIdx.x == 0 && threadIdx.x == 0) *next_len = 0;
+  // gate: the number of live edges the round before found (k_bor_hook).  The host launches a round
+  // before it has read that number (the wait for it would leave the GPU idle once per round); a round
+  // behind a complete forest is empty.
+  if (gate && *gate == 0) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (list_len) n = min(n, *list_len);   // (the list was compacted on the device: n is its capacity)
   const int e = i < n ? (list ? list[i] : i) : -1;
@@ -145,13 +155,19 @@ __global__ __launch_bounds__(256) void k_bor_hook(int n, const int32_t* __restri
                                                    const uint32_t* __restrict__ best,
                                                    const int32_t* __restrict__ ecu, const int32_t* __restrict__ ecv,
                                                    const int32_t* __restrict__ alive,
-                                                   unsigned long long* __restrict__ mail, unsigned mail_seq) {
+                                                   unsigned long long* __restrict__ mail, unsigned mail_seq,
+                                                   const int32_t* __restrict__ gate, int32_t* __restrict__ total_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool idle = gate && *gate == 0;   // (see k_bor_min)
   if (blockIdx.x == 0) {   // (k_bor_min is complete: its counters are final)
-    int v = threadIdx.x < kAliveSlots ? alive[threadIdx.x * 16] : 0;
+    int v = (!idle && threadIdx.x < kAliveSlots) ? alive[threadIdx.x * 16] : 0;
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if (threadIdx.x == 0) MailPost(mail, mail_seq, 0, v);
+    if (threadIdx.x == 0) {
+      *total_out = v;   // the next round's gate
+      MailPost(mail, mail_seq, 0, v);
+    }
   }
+  if (idle) return;
   if (list_len) n = min(n, *list_len);
   if (i >= n) return;
   const int e = list ? list[i] : i;
@@ -203,245 +219,6 @@ __global__ __launch_bounds__(256) void k_bor_compact(int n, const int32_t* __res
   }
 }
 
-// ---- block mode: one workgroup per component, the loops inside the kernel -------------------------------
-// The rounds of the spanning forest, the steps of the list ranking and the jumps of the path maxima
-// are loops of kernels over ALL listed components with a host wait per Boruvka round -- fine for the
-// giant components of the force-merge buckets, but a window of bucket 0 holds a hundred components
-// of 2-30 K edges and pays the same log n launches and seven waits for them.  Components
-// of at most MergeScratch::spine_block_max edges get one workgroup each instead: the same algorithms
-// on the same arrays, a workgroup barrier where the launch boundary was, no host round trip.  The
-// chains of dependent loads of a thread's edges advance together, four edges at a time.
-constexpr int kBlkThreads = 1024;
-constexpr int kBlkBatch = 4;
-
-// What a kernel boundary gave the loops above: everything written before is visible after (stores
-// complete before the barrier; the vector L1 holds nothing older than the barrier afterwards).
-__device__ __forceinline__ void BlockPhase() {
-  __threadfence();
-  __syncthreads();
-  __threadfence();
-}
-
-__global__ __launch_bounds__(kBlkThreads) void k_bor_block(int K, const int32_t* __restrict__ comp_base,
-                                                            const int32_t* __restrict__ eu,
-                                                            const int32_t* __restrict__ ev, int32_t* __restrict__ estate,
-                                                            int32_t* __restrict__ cc, uint32_t* __restrict__ best,
-                                                            int32_t* __restrict__ ecu, int32_t* __restrict__ ecv,
-                                                            int32_t* __restrict__ failed) {
-  const int k = blockIdx.x;
-  if (k >= K) return;
-  const int e0 = comp_base[k], e1 = comp_base[k + 1];
-  const int lane = threadIdx.x & 63;
-  for (int round = 0;; ++round) {
-    if (round >= 32) {   // (Boruvka halves the number of components every round)
-      if (threadIdx.x == 0) *failed = 1;
-      return;
-    }
-    // ---- the smallest rank that leaves every component (k_bor_min) ------------------------------------------
-    int any_alive = 0;
-    for (int base = e0; base < e1; base += kBlkThreads * kBlkBatch) {
-      int e[kBlkBatch], x[2 * kBlkBatch];
-      bool live[kBlkBatch];
-#pragma unroll
-      for (int q = 0; q < kBlkBatch; ++q) {
-        e[q] = base + q * kBlkThreads + (int)threadIdx.x;
-        live[q] = e[q] < e1 && (round == 0 || estate[e[q]] == 0);
-      }
-#pragma unroll
-      for (int q = 0; q < kBlkBatch; ++q) {
-        x[2 * q] = live[q] ? eu[e[q]] : -1;
-        x[2 * q + 1] = live[q] ? ev[e[q]] : -1;
-      }
-      if (round > 0) {   // CcFind with path halving, all chains of the batch together
-        for (bool any = true; any;) {
-          int p[2 * kBlkBatch], gp[2 * kBlkBatch];
-#pragma unroll
-          for (int c = 0; c < 2 * kBlkBatch; ++c) p[c] = x[c] >= 0 ? cc[x[c]] : -1;
-#pragma unroll
-          for (int c = 0; c < 2 * kBlkBatch; ++c) gp[c] = p[c] != x[c] ? cc[p[c]] : p[c];
-          any = false;
-#pragma unroll
-          for (int c = 0; c < 2 * kBlkBatch; ++c) {
-            if (p[c] == x[c]) continue;       // x is the root
-            if (gp[c] == p[c]) {
-              x[c] = p[c];                    // its parent is
-            } else {
-              cc[x[c]] = gp[c];               // (every value ever written is an ancestor)
-              x[c] = gp[c];
-              any = true;
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < kBlkBatch; ++q) {
-        int cu = x[2 * q], cv = x[2 * q + 1];
-        if (live[q] && cu == cv) {   // both ends in one component by now
-          estate[e[q]] = 2;
-          live[q] = false;
-        }
-        if (!live[q]) cu = cv = -1;
-        if (live[q] && round > 0) {
-          ecu[e[q]] = cu;
-          ecv[e[q]] = cv;
-        }
-        // (as in k_bor_min: ranks grow with the lane, so a lane whose component already appears in
-        // the lane before it has nothing to add; a plain, possibly stale read -- only ever too
-        // large -- keeps most of the others away from the atomic)
-        const int pu = __shfl_up(cu, 1), pv = __shfl_up(cv, 1);
-        if (live[q]) {
-          const uint32_t key = BorKey(round, e[q]);
-          const bool has_prev = lane != 0;
-          if (!(has_prev && (cu == pu || cu == pv)) && key < best[cu]) atomicMin(&best[cu], key);
-          if (!(has_prev && (cv == pu || cv == pv)) && key < best[cv]) atomicMin(&best[cv], key);
-          any_alive = 1;
-        }
-      }
-    }
-    BlockPhase();
-    if (!__syncthreads_or(any_alive)) return;
-    // ---- the edges that are the minimum of one of their two components join them (k_bor_hook) ----------------
-    for (int base = e0; base < e1; base += kBlkThreads * kBlkBatch) {
-      int e[kBlkBatch], cu[kBlkBatch], cv[kBlkBatch];
-      bool live[kBlkBatch];
-#pragma unroll
-      for (int q = 0; q < kBlkBatch; ++q) {
-        e[q] = base + q * kBlkThreads + (int)threadIdx.x;
-        live[q] = e[q] < e1 && estate[e[q]] == 0;
-      }
-#pragma unroll
-      for (int q = 0; q < kBlkBatch; ++q) {
-        cu[q] = live[q] ? (round == 0 ? eu[e[q]] : ecu[e[q]]) : -1;
-        cv[q] = live[q] ? (round == 0 ? ev[e[q]] : ecv[e[q]]) : -1;
-      }
-      uint32_t bu[kBlkBatch], bv[kBlkBatch];
-#pragma unroll
-      for (int q = 0; q < kBlkBatch; ++q) {
-        bu[q] = live[q] ? best[cu[q]] : 0u;
-        bv[q] = live[q] ? best[cv[q]] : 0u;
-      }
-#pragma unroll
-      for (int q = 0; q < kBlkBatch; ++q) {
-        if (!live[q]) continue;
-        const uint32_t key = BorKey(round, e[q]);
-        if (bu[q] == key || bv[q] == key) {
-          CcUnion(cc, eu[e[q]], ev[e[q]]);
-          estate[e[q]] = 1;
-        }
-      }
-    }
-    BlockPhase();
-  }
-}
-
-// The tree edges of component k are the positions [scan[comp_base[k]], scan[comp_base[k + 1]]) of the
-// compacted list (scan: exclusive scan of the tree-edge flags over the concatenated edges); its
-// arcs are twice that range.
-__device__ __forceinline__ void BlockTreeRange(int k, int K, const int32_t* __restrict__ comp_base,
-                                               const int32_t* __restrict__ scan, int mt, int& t0, int& t1) {
-  t0 = scan[comp_base[k]];
-  t1 = k + 1 < K ? scan[comp_base[k + 1]] : mt;
-}
-
-// List ranking of the component's Euler tour by pointer jumping (k_rank_step), until every arc has
-// reached the end of the tour.  The result is left in d1 whatever the number of steps.
-__global__ __launch_bounds__(kBlkThreads) void k_rank_block(int K, const int32_t* __restrict__ comp_base,
-                                                             const int32_t* __restrict__ scan, int mt,
-                                                             int32_t* __restrict__ s0, int32_t* __restrict__ d0,
-                                                             int32_t* __restrict__ s1, int32_t* __restrict__ d1) {
-  const int k = blockIdx.x;
-  if (k >= K) return;
-  int t0, t1;
-  BlockTreeRange(k, K, comp_base, scan, mt, t0, t1);
-  const int a0 = 2 * t0, a1 = 2 * t1;
-  int32_t* S[2] = {s0, s1};
-  int32_t* D[2] = {d0, d1};
-  int cur = 0;
-  for (int span = 1; span < a1 - a0; span *= 2) {
-    const int32_t* si = S[cur];
-    const int32_t* di = D[cur];
-    int32_t* so = S[cur ^ 1];
-    int32_t* dout = D[cur ^ 1];
-    int more = 0;
-    for (int base = a0; base < a1; base += kBlkThreads * kBlkBatch) {
-      int a[kBlkBatch], sx[kBlkBatch], dx[kBlkBatch], s2[kBlkBatch], d2[kBlkBatch];
-#pragma unroll
-      for (int q = 0; q < kBlkBatch; ++q) {
-        a[q] = base + q * kBlkThreads + (int)threadIdx.x;
-        sx[q] = a[q] < a1 ? si[a[q]] : kNone;
-        dx[q] = a[q] < a1 ? di[a[q]] : 0;
-      }
-#pragma unroll
-      for (int q = 0; q < kBlkBatch; ++q) {
-        s2[q] = sx[q] != kNone ? si[sx[q]] : kNone;
-        d2[q] = sx[q] != kNone ? di[sx[q]] : 0;
-      }
-#pragma unroll
-      for (int q = 0; q < kBlkBatch; ++q) {
-        if (a[q] >= a1) continue;
-        so[a[q]] = s2[q];
-        dout[a[q]] = dx[q] + d2[q];
-        more |= s2[q] != kNone;
-      }
-    }
-    cur ^= 1;
-    BlockPhase();
-    if (!__syncthreads_or(more)) break;
-  }
-  if (cur == 0) {
-    for (int a = a0 + (int)threadIdx.x; a < a1; a += kBlkThreads) d1[a] = d0[a];
-  }
-}
-
-// Path maxima of the component's tree by pointer jumping (k_jump_max), until every vertex has
-// reached the root; the result is left in v1.
-__global__ __launch_bounds__(kBlkThreads) void k_jump_block(int K, const int32_t* __restrict__ comp_base,
-                                                             const int32_t* __restrict__ scan, int mt,
-                                                             int32_t* __restrict__ j0, int32_t* __restrict__ v0,
-                                                             int32_t* __restrict__ j1, int32_t* __restrict__ v1) {
-  const int k = blockIdx.x;
-  if (k >= K) return;
-  int t0, t1;
-  BlockTreeRange(k, K, comp_base, scan, mt, t0, t1);
-  int32_t* J[2] = {j0, j1};
-  int32_t* V[2] = {v0, v1};
-  int cur = 0;
-  for (int span = 1; span < t1 - t0; span *= 2) {
-    const int32_t* ji = J[cur];
-    const int32_t* vi = V[cur];
-    int32_t* jo = J[cur ^ 1];
-    int32_t* vo = V[cur ^ 1];
-    int more = 0;
-    for (int base = t0; base < t1; base += kBlkThreads * kBlkBatch) {
-      int j[kBlkBatch], p[kBlkBatch], v[kBlkBatch], pp[kBlkBatch], vp[kBlkBatch];
-#pragma unroll
-      for (int q = 0; q < kBlkBatch; ++q) {
-        j[q] = base + q * kBlkThreads + (int)threadIdx.x;
-        p[q] = j[q] < t1 ? ji[j[q]] : kNone;
-        v[q] = j[q] < t1 ? vi[j[q]] : 0;
-      }
-#pragma unroll
-      for (int q = 0; q < kBlkBatch; ++q) {
-        pp[q] = p[q] != kNone ? ji[p[q]] : kNone;
-        vp[q] = p[q] != kNone ? vi[p[q]] : 0;
-      }
-#pragma unroll
-      for (int q = 0; q < kBlkBatch; ++q) {
-        if (j[q] >= t1) continue;
-        jo[j[q]] = pp[q];
-        vo[j[q]] = p[q] != kNone ? max(v[q], vp[q]) : v[q];
-        more |= pp[q] != kNone;
-      }
-    }
-    cur ^= 1;
-    BlockPhase();
-    if (!__syncthreads_or(more)) break;
-  }
-  if (cur == 0) {
-    for (int j = t0 + (int)threadIdx.x; j < t1; j += kBlkThreads) v1[j] = v0[j];
-  }
-}
-
 // ---- R: the largest region of every component --------------------------------------------------------
 constexpr int kRootStride = 16;
 __global__ __launch_bounds__(256) void k_spine_pick_root(int mE, int K, const int32_t* __restrict__ eu,
@@ -488,26 +265,36 @@ __global__ void k_spine_roots(int K, const unsigned long long* __restrict__ root
 }
 
 // ---- tree edges -> arcs ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_flag_state(int mE, const int32_t* __restrict__ estate, int want,
-                                                     int32_t* __restrict__ flag) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < mE) flag[e] = (estate[e] == want) ? 1 : 0;
-}
+// Flag -> number -> report, as one fused scan (scan_device.h): flag[e] = (state[e] == want), scan[e] =
+// flagged edges before e, the total stored and posted to the host.
+struct StateFlagValue {
+  const int32_t* state;
+  int want;
+  __device__ int operator()(int e) const { return state[e] == want ? 1 : 0; }
+};
+struct FlagScanEmit {
+  int32_t* flag;   // (null: not kept)
+  int32_t* scan;
+  __device__ void operator()(int e, int f, int before) const {
+    if (flag) flag[e] = f;
+    scan[e] = before;
+  }
+};
+struct TotalPostFinish {
+  int32_t* count;
+  unsigned long long* mail;
+  unsigned mail_seq;
+  __device__ void operator()(int total) const {
+    *count = total;
+    MailPost(mail, mail_seq, 0, total);
+  }
+};
 
 __global__ __launch_bounds__(256) void k_compact_tree(int mE, const int32_t* __restrict__ flag,
                                                        const int32_t* __restrict__ scan,
                                                        int32_t* __restrict__ te_e) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < mE && flag[e]) te_e[scan[e]] = e;
-}
-
-__global__ void k_scan_total(int n, const int32_t* __restrict__ flag, const int32_t* __restrict__ scan,
-                             int32_t* __restrict__ count, unsigned long long* __restrict__ mail, unsigned mail_seq,
-                             const int32_t* __restrict__ also) {
-  const int total = scan[n - 1] + flag[n - 1];
-  *count = total;
-  MailPost(mail, mail_seq, 0, total);
-  if (also) MailPost(mail, mail_seq, 1, *also);   // (a second value for the same wait)
 }
 
 __global__ __launch_bounds__(256) void k_arc_keys(int mt, const int32_t* __restrict__ te_e,
@@ -727,26 +514,35 @@ __global__ __launch_bounds__(256) void k_gather_side(int n, const uint32_t* __re
 }
 
 // Spine edges in rank order: the child end (whose side cluster is absorbed) and whether it is the
-// edge's first region.  comp_spine[k]: start of component k's spine (from the scan).
-__global__ __launch_bounds__(256) void k_compact_spine(int mE, int K, const int32_t* __restrict__ flag,
-                                                        const int32_t* __restrict__ scan,
-                                                        const int32_t* __restrict__ eu,
-                                                        const int32_t* __restrict__ ev,
-                                                        const int32_t* __restrict__ childidx,
-                                                        const int32_t* __restrict__ te_e,
-                                                        const int32_t* __restrict__ comp_base,
-                                                        int32_t* __restrict__ sp_child, int32_t* __restrict__ sp_is_a,
-                                                        int32_t* __restrict__ comp_spine) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= mE) return;
-  if (flag[e]) {
-    const int ju = childidx[eu[e]];
-    const bool child_is_u = ju != kNone && te_e[ju] == e;
-    sp_child[scan[e]] = child_is_u ? eu[e] : ev[e];
-    sp_is_a[scan[e]] = child_is_u ? 1 : 0;
+// edge's first region -- moved together by the fused scan of the spine flags.  comp_spine[k]: start of
+// component k's spine (from the scan).
+struct SpineEmit {
+  const int32_t* eu;
+  const int32_t* ev;
+  const int32_t* childidx;
+  const int32_t* te_e;
+  int32_t* scan;
+  int32_t* sp_child;
+  int32_t* sp_is_a;
+  __device__ void operator()(int e, int f, int before) const {
+    scan[e] = before;
+    if (f) {
+      const int ju = childidx[eu[e]];
+      const bool child_is_u = ju != kNone && te_e[ju] == e;
+      sp_child[before] = child_is_u ? eu[e] : ev[e];
+      sp_is_a[before] = child_is_u ? 1 : 0;
+    }
   }
-  if (e == mE - 1) comp_spine[K] = scan[e] + flag[e];
-  if (e < K) comp_spine[e] = scan[comp_base[e]];
+};
+struct SpineFinish {
+  int32_t* comp_spine;
+  int K;
+  __device__ void operator()(int total) const { comp_spine[K] = total; }
+};
+__global__ __launch_bounds__(256) void k_comp_spine(int K, const int32_t* __restrict__ comp_base,
+                                                     const int32_t* __restrict__ scan, int32_t* __restrict__ comp_spine) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < K) comp_spine[k] = scan[comp_base[k]];
 }
 
 // ---- the spine ---------------------------------------------------------------------------------------------
@@ -1572,45 +1368,8 @@ int SelectLargeSegments(int max_segs, const int32_t* num_segs, const int32_t* se
 // Returns false when the scratch pool cannot hold them (the caller hands them to the ordinary
 // workers instead).  On return the side clusters and the spines are queued on the stream; a
 // failed speculation raises *wa.violation.
-static bool RunSpineSet(const SpineInput& in, const WorkerArgs& wa, MergeScratch& S, hipStream_t s,
-                        const SpineWorkers& run_workers, size_t pool_used, int depth, bool block_mode);
-
-bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, int n_total, MergeScratch& S, hipStream_t s,
+bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch& S, hipStream_t s,
                         const SpineWorkers& run_workers, size_t pool_used, int depth) {
-  if (in.segs.empty()) return false;
-  if (S.spine_block_max <= 0) return RunSpineSet(in, wa, S, s, run_workers, pool_used, depth, false);
-  // Components of at most spine_block_max edges: one workgroup each (block mode); the others as
-  // before.  A stage that holds both kinds is replayed as two sets, one after the other on the
-  // stream (their regions are disjoint; the scratch of the first is free when the second starts:
-  // same stream, and the first set's work on the third stream has been joined by then).
-  SpineInput small, large;
-  for (const SpineSeg& g : in.segs) (g.cnt <= S.spine_block_max ? small : large).segs.push_back(g);
-  if (large.segs.empty()) return RunSpineSet(small, wa, S, s, run_workers, pool_used, depth, true);
-  if (small.segs.empty()) return RunSpineSet(large, wa, S, s, run_workers, pool_used, depth, false);
-  const bool ok_small = RunSpineSet(small, wa, S, s, run_workers, pool_used, depth, true);
-  const bool ok_large = RunSpineSet(large, wa, S, s, run_workers, pool_used, depth, false);
-  if (!ok_small && !ok_large) return false;   // nothing has been replayed: the caller's fall-back covers both
-  if (!ok_small || !ok_large) {
-    // no room in the scratch pool for one of the sets: the wave worker replays exactly that one
-    // (the sets are told apart by size: small = [smallest listed, spine_block_max], large above)
-    int lo = 0x7fffffff;
-    for (const SpineSeg& g : in.segs) lo = std::min(lo, g.cnt);
-    WorkerArgs w3 = wa;
-    w3.work_list = nullptr;
-    if (!ok_small) {
-      w3.wave_min = lo - 1;
-      w3.wave_max = S.spine_block_max + 1;
-    } else {
-      w3.wave_min = S.spine_block_max;
-      w3.wave_max = 0x7fffffff;
-    }
-    run_workers(w3, n_total, s);
-  }
-  return true;
-}
-
-static bool RunSpineSet(const SpineInput& in, const WorkerArgs& wa, MergeScratch& S, hipStream_t s,
-                        const SpineWorkers& run_workers, size_t pool_used, int depth, bool block_mode) {
   const int K = (int)in.segs.size();
   if (K == 0) return false;
   std::vector<int32_t> base(K + 1, 0), off(K);
@@ -1658,7 +1417,6 @@ static bool RunSpineSet(const SpineInput& in, const WorkerArgs& wa, MergeScratch
 
   // ---- tree edges ----------------------------------------------------------------------------------------
   int dbg_rounds = 0;
-  const int32_t* bor_failed = nullptr;   // block mode: set by a forest that did not converge
   auto NowMs = [] {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   };
@@ -1667,68 +1425,93 @@ static bool RunSpineSet(const SpineInput& in, const WorkerArgs& wa, MergeScratch
     VSG_HIP(hipStreamSynchronize(s));
     std::fprintf(stderr, "[vsg]   forest: gather+root %.2f ms\n", NowMs() - tph[0]);
   }
-  if (block_mode) {
-    // all rounds inside one kernel, one workgroup per component (ecu / ecv as below)
-    int32_t* d_failed = TakeZeroed(S, 1);
-    hipLaunchKernelGGL(k_bor_block, dim3(K), dim3(kBlkThreads), 0, s, K, d_base, eu, ev, estate, cc, best, side_key,
-                       spine_flag, d_failed);
-    bor_failed = d_failed;
-  } else {
+  {
     const size_t forest_mark = pool.mark();
     const int32_t* list = nullptr;      // the edges the rounds still look at (null: all)
     const int32_t* list_len = nullptr;  // its length, on the device
     int n_list = mE;                    // its capacity
     int32_t* lists[2] = {nullptr, nullptr};
     int which = 0;
+    // Rounds over a short list are launched one ahead of the host's knowledge: the number of live
+    // edges of round r is read while round r + 1 is queued behind it (gated on the device: empty when
+    // round r found nothing alive), so the GPU does not idle through a host round trip per round.
+    // Long lists (the giant components) stay synchronous: there the round after next is worth
+    // compacting for, and an unneeded pass over 40 M edges is not free.
+    const int ahead_max = getenv("VSG_BOR_AHEAD") ? atoi(getenv("VSG_BOR_AHEAD")) : (4 << 20);
+    MailSlot waiting[2];
+    int n_waiting = 0;
+    const int32_t* gate = nullptr;
+    int32_t* len_words = scalars + 8;   // [2]: the length of the current list / of the one the next compaction builds
+    int len_cur = 0;
     for (int round = 0;; ++round) {
       dbg_rounds = round;
       VSG_REQUIRE(round < 32, -4, "spine: the spanning forest did not converge");
-      int32_t* d_ctr = TakeZeroed(S, 16 * kAliveSlots + 4);   // edges alive in this round (spread), then the length of the next list
+      int32_t* d_ctr = TakeZeroed(S, 16 * kAliveSlots + 4);   // edges alive in this round (spread), then the round's total
+      int32_t* d_next_len = len_words + (len_cur ^ 1);
       // ecu / ecv (the components of the round) live in the side_key / spine_flag arrays, which are
       // only written once the forest is done
       hipLaunchKernelGGL(k_bor_min, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, list_len, round, eu, ev,
-                         estate, cc, best, side_key, spine_flag, d_ctr);
+                         estate, cc, best, side_key, spine_flag, d_ctr, gate, d_next_len);
       const MailSlot m_alive = NextMail(*S.mail);
       hipLaunchKernelGGL(k_bor_hook, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, list_len, round, eu, ev,
-                         estate, cc, best, side_key, spine_flag, d_ctr, m_alive.dev, m_alive.seq);
+                         estate, cc, best, side_key, spine_flag, d_ctr, m_alive.dev, m_alive.seq, gate,
+                         d_ctr + 16 * kAliveSlots + 1);
+      gate = d_ctr + 16 * kAliveSlots + 1;
+      waiting[n_waiting++] = m_alive;
+      const int depth = n_list <= ahead_max ? 1 : 0;   // rounds that may stay unanswered
       const double tr0 = dbg_big ? NowMs() : 0;
-      int alive = 0;
-      MailWait(m_alive, 1, &alive, s);
-      if (dbg_big) std::fprintf(stderr, "[vsg]   forest round %d: %d in list, %d alive, %.2f ms\n", round, n_list, alive, NowMs() - tr0);
-      if (alive == 0) break;
-      if (alive < n_list / 2 && n_list > (1 << 16)) {   // drop the settled edges from the rounds to come
-        if (!lists[0]) {
-          const size_t m = pool.mark();
-          lists[0] = pool.take(alive);
-          lists[1] = pool.take(alive);
-          if (!pool.ok) {   // without room the rounds simply keep the longer list
-            pool.ok = true;
-            pool.release(m);
-            lists[0] = lists[1] = nullptr;
-          }
-        }
-        if (lists[0]) {
-          // (at most `alive` edges are left: the ones this round hooked are gone as well)
-          hipLaunchKernelGGL(k_bor_compact, dim3(Blocks(((size_t)n_list + kBorCompactPer - 1) / kBorCompactPer)),
-                             dim3(256), 0, s, n_list, list, list_len, estate, lists[which], d_ctr + 16 * kAliveSlots);
-          list = lists[which];
-          list_len = d_ctr + 16 * kAliveSlots;
-          which ^= 1;
-          n_list = alive;
+      int alive = -1;
+      bool complete = false;
+      while (n_waiting > depth) {
+        MailWait(waiting[0], 1, &alive, s);
+        waiting[0] = waiting[1];
+        --n_waiting;
+        if (alive == 0) {
+          complete = true;   // (a round launched behind it is empty)
+          break;
         }
       }
+      if (dbg_big) std::fprintf(stderr, "[vsg]   forest round %d: %d in list, %d alive, %.2f ms\n", round, n_list, alive, NowMs() - tr0);
+      if (complete) break;
+      // Drop the settled edges from the rounds to come.  Synchronous rounds know how many edges are
+      // alive and compact when that is less than half the list.  One round ahead of the answers the
+      // host cannot wait for a count before it decides: from the second round on a long list is
+      // compacted after every round, and how many edges that leaves is only known on the device
+      // (list_len).  n_list -- the capacity the kernels are launched for -- may only shrink together
+      // with a compaction: `alive` (the last count answered) bounds what the NEW list holds, not the
+      // entries of a list that stays.
+      const bool compact = depth == 1 ? (round >= 1 && n_list > (1 << 16))
+                                      : (alive < n_list / 2 && n_list > (1 << 16));
+      if (!compact) continue;
+      if (!lists[0]) {
+        const size_t m = pool.mark();
+        const size_t cap = depth == 1 ? (size_t)n_list : (size_t)alive;
+        lists[0] = pool.take(cap);
+        lists[1] = pool.take(cap);
+        if (!pool.ok) {   // without room the rounds simply keep the longer list
+          pool.ok = true;
+          pool.release(m);
+          lists[0] = lists[1] = nullptr;
+        }
+      }
+      if (!lists[0]) continue;
+      hipLaunchKernelGGL(k_bor_compact, dim3(Blocks(((size_t)n_list + kBorCompactPer - 1) / kBorCompactPer)),
+                         dim3(256), 0, s, n_list, list, list_len, estate, lists[which], d_next_len);
+      list = lists[which];
+      list_len = d_next_len;
+      len_cur ^= 1;
+      which ^= 1;
+      // (at most `alive` edges are left: the ones hooked since that count are gone as well)
+      if (alive >= 0) n_list = std::min(n_list, alive);
     }
     pool.release(forest_mark);
   }
   Mark(1);
-  hipLaunchKernelGGL(k_flag_state, dim3(Blocks(mE)), dim3(256), 0, s, mE, estate, 1, flag);
-  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, flag, scan, mE, s);
   const MailSlot m_mt = NextMail(*S.mail);
-  hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, s, mE, flag, scan, scalars + 1, m_mt.dev, m_mt.seq, bor_failed);
-  int mt_post[2] = {0, 0};
-  MailWait(m_mt, bor_failed ? 2 : 1, mt_post, s);
-  const int mt = mt_post[0];
-  VSG_REQUIRE(mt_post[1] == 0, -4, "spine: the spanning forest did not converge");
+  FusedScan(S.scan, StateFlagValue{estate, 1}, FlagScanEmit{flag, scan}, TotalPostFinish{scalars + 1, m_mt.dev, m_mt.seq},
+            mE, s);
+  int mt = 0;
+  MailWait(m_mt, 1, &mt, s);
   VSG_REQUIRE(mt > 0, -4, "spine: a component without tree edges");
   const int na = 2 * mt;
   int32_t* te_e = pool.take(mt);
@@ -1758,12 +1541,7 @@ static bool RunSpineSet(const SpineInput& in, const WorkerArgs& wa, MergeScratch
                      root_vertex, succ[0], dist[0]);
   int cur = 0;
   bool ranked = false;
-  if (block_mode) {
-    hipLaunchKernelGGL(k_rank_block, dim3(K), dim3(kBlkThreads), 0, s, K, d_base, scan, mt, succ[0], dist[0], succ[1],
-                       dist[1]);
-    cur = 1;
-    ranked = true;
-  } else if (na >= S.rank_split_min) {
+  if (na >= S.rank_split_min) {
     // sampled ranking: the reduced list (every 64th arc + the K tour heads) by pointer jumping
     const int ns = (na + kRankSplit - 1) / kRankSplit + K;
     const size_t rmark = pool.mark();
@@ -1804,23 +1582,28 @@ static bool RunSpineSet(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   // The jumps double the distance covered; the trees are usually shallow (a hub and what hangs off
   // it), so every few steps the device says whether any vertex is still short of its root.
   int cj = 0;
-  if (block_mode) {
-    hipLaunchKernelGGL(k_jump_block, dim3(K), dim3(kBlkThreads), 0, s, K, d_base, scan, mt, jump[0], val[0], jump[1],
-                       val[1]);
-    cj = 1;
-  }
-  for (int span = 1, step = 0; !block_mode && span < mt; span *= 2, ++step) {
-    const bool ask = (step % 3 == 2) && span * 2 < mt;
-    int32_t* d_more = ask ? TakeZeroed(S, 1) : nullptr;
-    hipLaunchKernelGGL(k_jump_max, dim3(Blocks(mt)), dim3(256), 0, s, mt, jump[cj], val[cj], jump[cj ^ 1],
-                       val[cj ^ 1], d_more);
-    cj ^= 1;
-    if (ask) {
-      const MailSlot m = NextMail(*S.mail);
-      LaunchMailPost(m, d_more, nullptr, nullptr, nullptr, s);
-      int more = 0;
-      MailWait(m, 1, &more, s);
-      if (!more) break;
+  {
+    // (the answer to a question is read three steps later: a step behind a finished walk only copies,
+    // so the steps launched meanwhile change nothing, and the GPU does not wait for the host)
+    MailSlot asked = {nullptr, nullptr, 0};
+    bool have_asked = false;
+    for (int span = 1, step = 0; span < mt; span *= 2, ++step) {
+      const bool ask = (step % 3 == 2) && span * 2 < mt;
+      int32_t* d_more = ask ? TakeZeroed(S, 1) : nullptr;
+      hipLaunchKernelGGL(k_jump_max, dim3(Blocks(mt)), dim3(256), 0, s, mt, jump[cj], val[cj], jump[cj ^ 1],
+                         val[cj ^ 1], d_more);
+      cj ^= 1;
+      if (ask) {
+        const MailSlot m = NextMail(*S.mail);
+        LaunchMailPost(m, d_more, nullptr, nullptr, nullptr, s);
+        if (have_asked) {
+          int more = 0;
+          MailWait(asked, 1, &more, s);
+          if (!more) break;
+        }
+        asked = m;
+        have_asked = true;
+      }
     }
   }
   // (scan still maps an edge to its position among the tree edges)
@@ -1831,10 +1614,9 @@ static bool RunSpineSet(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   Mark(3);
   // ---- side clusters: segments for the ordinary workers ------------------------------------------------------
   pool.release(arcs_mark);   // the tour is done with
-  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, flag, scan, mE, s);
   const MailSlot m_side = NextMail(*S.mail);
-  hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, s, mE, flag, scan, scalars + 2, m_side.dev, m_side.seq,
-                     nullptr);
+  FusedScan(S.scan, ScanLoadI32{flag}, FlagScanEmit{nullptr, scan}, TotalPostFinish{scalars + 2, m_side.dev, m_side.seq},
+            mE, s);
   int n_side = 0;
   MailWait(m_side, 1, &n_side, s);
   const size_t ns = (size_t)(n_side > 0 ? n_side : 1);
@@ -1851,10 +1633,9 @@ static bool RunSpineSet(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   if (!pool.ok) return false;
   hipLaunchKernelGGL(k_compact_side, dim3(Blocks(mE)), dim3(256), 0, s, mE, flag, scan, side_key, sk_in, si_in);
   // spine edges (the scan buffer is reused once the side positions are consumed)
-  hipLaunchKernelGGL(k_flag_state, dim3(Blocks(mE)), dim3(256), 0, s, mE, spine_flag, 1, flag);
-  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, flag, scan, mE, s);
-  hipLaunchKernelGGL(k_compact_spine, dim3(Blocks(mE)), dim3(256), 0, s, mE, K, flag, scan, eu, ev, childidx,
-                     te_e, d_base, sp_child, sp_is_a, comp_spine);
+  FusedScan(S.scan, StateFlagValue{spine_flag, 1}, SpineEmit{eu, ev, childidx, te_e, scan, sp_child, sp_is_a},
+            SpineFinish{comp_spine, K}, mE, s);
+  hipLaunchKernelGGL(k_comp_spine, dim3(Blocks(K)), dim3(256), 0, s, K, d_base, scan, comp_spine);
   int dbg_spine_edges = 0;
   if (S.spine_debug) {
     std::vector<int32_t> cs(K + 1);
@@ -1866,8 +1647,7 @@ static bool RunSpineSet(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   if (n_side > 0) {
     SortPairsU32(S.cub_temp, S.cub_temp_bytes, sk_in, sk, si_in, si, n_side, 32, s);
     int32_t* d_nseg = scalars + 3;
-    RunLengthEncodeU32(S.cub_temp, S.cub_temp_bytes, sk, seg_key, seg_cnt, d_nseg, n_side, s);
-    ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, seg_cnt, seg_off, n_side, s);
+    RunsOfSortedKeys(S.scan, sk, n_side, seg_off, seg_cnt, d_nseg, s);
     hipLaunchKernelGGL(k_gather_side, dim3(Blocks(n_side)), dim3(256), 0, s, n_side, si, d_base, d_off, K, wa.s_ra,
                        wa.s_rb, wa.s_gpos, o_ra, o_rb, o_gpos);
     WorkerArgs w2 = wa;
@@ -1905,7 +1685,7 @@ static bool RunSpineSet(const SpineInput& in, const WorkerArgs& wa, MergeScratch
       } else {
         run_workers(w2, n_side, s);
       }
-      if (!RunSpineComponents(nested, w2, n_side, S, s, run_workers, pool_used + pool.used, depth + 1)) {
+      if (!RunSpineComponents(nested, w2, S, s, run_workers, pool_used + pool.used, depth + 1)) {
         WorkerArgs w3 = w2;   // no room: the wave worker replays them
         w3.wave_min = w2.wave_max - 1;
         w3.wave_max = 0x7fffffff;
@@ -1944,7 +1724,7 @@ static bool RunSpineSet(const SpineInput& in, const WorkerArgs& wa, MergeScratch
         hipLaunchKernelGGL(k_spine_fast_init, dim3((K + 63) / 64), dim3(64), 0, s, K, comp_spine, F, pass == 0 ? 1 : 0);
         hipLaunchKernelGGL(k_spine_prep, dim3(Blocks((size_t)mt + 1)), dim3(256), 0, s, mt, K, comp_spine,
                            root_vertex, sp_child, wa.nodes, wa.T, F);
-        ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, F.sizes, F.pre, mt + 1, s);
+        ExclusiveSum(S.scan, F.sizes, F.pre, mt + 1, s);
         hipLaunchKernelGGL(k_spine_chain, dim3(K), dim3(64 * (1 + kChProducers)), 0, s, K, comp_spine, root_vertex,
                            wa.nodes, F);
         hipLaunchKernelGGL(k_spine_verify, dim3(Blocks((size_t)F.ck_stride)), dim3(256), 0, s, K, comp_spine,

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "merge_common.h"
+#include "scan_device.h"
 
 namespace vsg {
 
@@ -98,15 +99,12 @@ void LaunchMailPost(const MailSlot& slot, const int32_t* p0, const int32_t* p1, 
 static std::atomic<int> g_live_graphs{0};
 void MailRegisterGraph(int delta) { g_live_graphs.fetch_add(delta, std::memory_order_relaxed); }
 
-static int UsableCores() {
-  static const int n = [] {
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) return (int)CPU_COUNT(&set);
-    const unsigned h = std::thread::hardware_concurrency();
-    return h ? (int)h : 1;
-  }();
-  return n;
+static int UsableCores() {   // (of the calling thread, now: a syscall per wait is nothing beside the wait)
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) return (int)CPU_COUNT(&set);
+  const unsigned h = std::thread::hardware_concurrency();
+  return h ? (int)h : 1;
 }
 
 int MailYieldMode() {
@@ -588,7 +586,8 @@ __global__ __launch_bounds__(256) void k_compact_active(int n_b, FilterMasks M,
                                                          uint32_t* __restrict__ a_gpos,
                                                          int32_t* __restrict__ num_active,
                                                          const int32_t* __restrict__ num_ti,
-                                                         unsigned long long* __restrict__ mail, unsigned mail_seq) {
+                                                         unsigned long long* __restrict__ mail, unsigned mail_seq,
+                                                         int a_cap) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t gw0 = (size_t)blockIdx.x * 4;
@@ -597,10 +596,13 @@ __global__ __launch_bounds__(256) void k_compact_active(int n_b, FilterMasks M,
   for (int k = 0; k < w; ++k) base += (int)__popcll(M.active[gw0 + k]);
   if ((m >> lane) & 1ull) {
     const int p = base + (int)__popcll(m & ((1ull << lane) - 1ull));
-    const int slot = FilterSlot(M, j);
-    a_ra[p] = e_ra[slot];
-    a_rb[p] = e_rb[slot];
-    a_gpos[p] = e_gpos[slot];
+    // (more active edges than the arrays hold: the host sees the total, enlarges them and compacts again)
+    if (p < a_cap) {
+      const int slot = FilterSlot(M, j);
+      a_ra[p] = e_ra[slot];
+      a_rb[p] = e_rb[slot];
+      a_gpos[p] = e_gpos[slot];
+    }
   }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
     const int total = base + (int)__popcll(m);
@@ -755,42 +757,45 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
 // is reported through the violation flag and replayed edge by edge (rollback, like a violated
 // optimistic stage).  Workers therefore replay leaders only; k_resolve_followers copies the kept
 // marks afterwards.
-__global__ __launch_bounds__(256) void k_mark_leaders(int n, const int32_t* __restrict__ a_ra,
-                                                       const int32_t* __restrict__ a_rb,
-                                                       int32_t* __restrict__ lead) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= n) return;
-  int l = 1;
-  if (p > 0) {
+// (one fused scan: the leader flag of position p, its exclusive prefix = the leader's index, the
+// leaders moved together, their number posted to the host -- scan_device.h)
+struct LeaderValue {
+  const int32_t* a_ra;
+  const int32_t* a_rb;
+  __device__ int operator()(int p) const {
+    if (p == 0) return 1;
     const int ra = a_ra[p], rb = a_rb[p], qa = a_ra[p - 1], qb = a_rb[p - 1];
-    l = !((ra == qa && rb == qb) || (ra == qb && rb == qa));
+    return !((ra == qa && rb == qb) || (ra == qb && rb == qa));
   }
-  lead[p] = l;
-}
-
-__global__ __launch_bounds__(256) void k_compact_leaders(int n, const int32_t* __restrict__ lead,
-                                                          const int32_t* __restrict__ lpos,
-                                                          const int32_t* __restrict__ a_ra,
-                                                          const int32_t* __restrict__ a_rb,
-                                                          const uint32_t* __restrict__ a_gpos,
-                                                          int32_t* __restrict__ l_ra,
-                                                          int32_t* __restrict__ l_rb,
-                                                          uint32_t* __restrict__ l_gpos,
-                                                          int32_t* __restrict__ num_leaders,
-                                                          unsigned long long* __restrict__ mail, unsigned mail_seq) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= n) return;
-  if (lead[p]) {
-    const int q = lpos[p];
-    l_ra[q] = a_ra[p];
-    l_rb[q] = a_rb[p];
-    l_gpos[q] = a_gpos[p];
+};
+struct LeaderEmit {
+  const int32_t* a_ra;
+  const int32_t* a_rb;
+  const uint32_t* a_gpos;
+  int32_t* lead;
+  int32_t* lpos;
+  int32_t* l_ra;
+  int32_t* l_rb;
+  uint32_t* l_gpos;
+  __device__ void operator()(int p, int is_lead, int q) const {
+    lead[p] = is_lead;
+    lpos[p] = q;
+    if (is_lead) {
+      l_ra[q] = a_ra[p];
+      l_rb[q] = a_rb[p];
+      l_gpos[q] = a_gpos[p];
+    }
   }
-  if (p == n - 1) {
-    *num_leaders = lpos[p] + lead[p];
-    MailPost(mail, mail_seq, 0, lpos[p] + lead[p]);
+};
+struct LeaderFinish {
+  int32_t* num_leaders;
+  unsigned long long* mail;
+  unsigned mail_seq;
+  __device__ void operator()(int total) const {
+    *num_leaders = total;
+    MailPost(mail, mail_seq, 0, total);
   }
-}
+};
 
 __global__ __launch_bounds__(256) void k_resolve_followers(int n, const int32_t* __restrict__ lead,
                                                             const int32_t* __restrict__ lpos,
@@ -871,14 +876,20 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     VSG_HIP(hipEventRecord((*S.ev_pool)[ef1], s));
     S.ev_filter->emplace_back(ef0, ef1);
   }
-  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, S.masks.block_cnt, S.block_off, (int)Blocks(n_b), s);
-  const MailSlot m_active = NextMail(*S.mail);
-  hipLaunchKernelGGL(k_compact_active, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks, S.block_off,
-                     S.e_ra, S.e_rb, S.e_gpos, S.a_ra, S.a_rb, S.a_gpos, S.num_active, d_num_ti, m_active.dev,
-                     m_active.seq);
-  VSG_HIP(hipGetLastError());
+  ExclusiveSum(S.scan, S.masks.block_cnt, S.block_off, (int)Blocks(n_b), s);
   int h[2] = {0, 0};   // num_active, num_ti
-  MailWait(m_active, 2, h, s);
+  for (int attempt = 0;; ++attempt) {
+    const MailSlot m_active = NextMail(*S.mail);
+    hipLaunchKernelGGL(k_compact_active, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks, S.block_off,
+                       S.e_ra, S.e_rb, S.e_gpos, S.a_ra, S.a_rb, S.a_gpos, S.num_active, d_num_ti, m_active.dev,
+                       m_active.seq, S.active_cap);
+    VSG_HIP(hipGetLastError());
+    MailWait(m_active, 2, h, s);
+    if (h[0] <= S.active_cap) break;
+    // the arrays that hold active edges are too small for this stage: enlarge them, compact again
+    VSG_REQUIRE(attempt == 0 && S.grow_active && S.grow_active(h[0]) && h[0] <= S.active_cap, -4,
+                "stage scratch: cannot hold the active edges");
+  }
   const int n_active = h[0];
   const int n_ti = h[1];
   auto clear_marks = [&]() {
@@ -901,13 +912,10 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   int n_work = n_active;
   int32_t* lead = S.e_active;       // free after the compaction
   if (rle) {
-    hipLaunchKernelGGL(k_mark_leaders, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra,
-                       S.a_rb, lead);
-    ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, lead, S.lead_pos, n_active, s);
     const MailSlot m_lead = NextMail(*S.mail);
-    hipLaunchKernelGGL(k_compact_leaders, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, lead,
-                       S.lead_pos, S.a_ra, S.a_rb, S.a_gpos, S.l_ra, S.l_rb, S.l_gpos,
-                       d_num_leaders, m_lead.dev, m_lead.seq);
+    FusedScan(S.scan, LeaderValue{S.a_ra, S.a_rb},
+              LeaderEmit{S.a_ra, S.a_rb, S.a_gpos, lead, S.lead_pos, S.l_ra, S.l_rb, S.l_gpos},
+              LeaderFinish{d_num_leaders, m_lead.dev, m_lead.seq}, n_active, s);
     MailWait(m_lead, 1, &n_work, s);
     w_ra = S.l_ra;
     w_rb = S.l_rb;
@@ -917,11 +925,8 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   hipLaunchKernelGGL(k_component_ids, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, S.cc,
                      S.a_comp, S.a_idx);
   SortPairsU32(S.cub_temp, S.cub_temp_bytes, S.a_comp, S.s_comp, S.a_idx, S.s_idx, n_work, 32, s);
-  RunLengthEncodeU32(S.cub_temp, S.cub_temp_bytes, S.s_comp, S.seg_key, S.seg_cnt, S.num_segs,
-                     n_work, s);
-  // Segment offsets: exclusive scan over n_work counts (only the first num_segs are defined;
-  // the prefix of an exclusive scan never depends on later elements).
-  ExclusiveSumI32(S.cub_temp, S.cub_temp_bytes, S.seg_cnt, S.seg_off, n_work, s);
+  // the components = the runs of equal keys: first position and length of every run
+  RunsOfSortedKeys(S.scan, S.s_comp, n_work, S.seg_off, S.seg_cnt, S.num_segs, s);
 
   // The large components are replayed along their Kruskal tree (merge_spine.hip): the choice is
   // made on the host from the list of components above the threshold.
@@ -984,7 +989,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   wa.small_seg = small_seg;
   wa.wave_min = small_seg;
   wa.wave_max = spine_thr;
-  // work list of the wave worker: the RLE keys are not read again, the control words follow the
+  // work list of the wave worker (seg_key: scratch of n_work entries), the control words follow the
   // stage's scalars
   wa.work_cap = n_work / (small_seg + 1) + 1;
   wa.work_list = (size_t)kWaveClasses * wa.work_cap <= (size_t)n_work ? S.seg_key : nullptr;
@@ -1015,7 +1020,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     VSG_HIP(hipStreamWaitEvent(S.aux_stream, S.aux_fork, 0));
     general_workers(wa, n_work, wave_grid, S.aux_stream);
     VSG_HIP(hipEventRecord(S.aux_join, S.aux_stream));
-    const bool done = RunSpineComponents(spine_in, wa, n_work, S, s, [&](const WorkerArgs& w, int n, hipStream_t st) {
+    const bool done = RunSpineComponents(spine_in, wa, S, s, [&](const WorkerArgs& w, int n, hipStream_t st) {
       general_workers(w, n, WaveGrid(n), st);
     }, 0, 0);
     if (!done) {   // no room in the scratch pool: the wave worker replays them
@@ -1106,6 +1111,25 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
                        S.lead_pos, S.a_gpos, S.l_gpos, kept_all);
   }
   clear_marks();
+  VSG_HIP(hipGetLastError());
+}
+
+// seg_cnt[r] = seg_off[r + 1] - seg_off[r], the last run ends at n.
+__global__ __launch_bounds__(256) void k_run_counts(int n, const int32_t* __restrict__ num_runs,
+                                                     const int32_t* __restrict__ seg_off,
+                                                     int32_t* __restrict__ seg_cnt) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int m = *num_runs;
+  if (r >= m) return;
+  seg_cnt[r] = (r + 1 < m ? seg_off[r + 1] : n) - seg_off[r];
+}
+
+void RunsOfSortedKeys(const ScanScratch& sc, const uint32_t* keys, int n, int32_t* seg_off, int32_t* seg_cnt,
+                      int32_t* num_runs, hipStream_t s) {
+  if (n <= 0) return;
+  FusedScan(sc, RunHeadValue{keys}, RunHeadEmit{seg_off}, RunHeadFinish{num_runs}, n, s);
+  // (the number of runs is only known on the device: one thread per position, most return at once)
+  hipLaunchKernelGGL(k_run_counts, dim3(Blocks(n)), dim3(256), 0, s, n, num_runs, seg_off, seg_cnt);
   VSG_HIP(hipGetLastError());
 }
 

@@ -1,9 +1,11 @@
-// sort_scan.hip -- thin wrappers around rocPRIM/hipCUB device-wide primitives.
+// sort_scan.hip -- thin wrappers around the rocPRIM/hipCUB device-wide radix sort (and the 64-bit
+// unique of the read-out).
 //
-// Only generic building blocks (stable LSD radix sort, exclusive scan, run-length encode,
-// unique) come from the library; every kernel that encodes the segmentation algorithm itself
-// is hand-written in build_kernels.hip / merge_*.hip / readout_kernels.hip.
-// (The bucket sort of the edge slots is hand-written: edge_sort.hip.)
+// The stable LSD radix sort is the one generic building block left from the library; scans, run
+// detection and compactions are hand-written and fused into the kernels around them
+// (scan_device.h), like every kernel that encodes the segmentation algorithm itself
+// (build_kernels.hip / merge_*.hip / readout_kernels.hip; the bucket sort of the edge slots:
+// edge_sort.hip).
 #include <hipcub/hipcub.hpp>
 
 #include "device_graph.h"
@@ -34,32 +36,6 @@ size_t SortKeysU64TempBytes(int n) {
 void SortKeysU64(void* temp, size_t temp_bytes, const unsigned long long* in, unsigned long long* out, int n,
                  hipStream_t s) {
   VSG_HIP(hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, in, out, n, 0, 64, s));
-}
-
-size_t ScanTempBytes(int n) {
-  size_t bytes = 0;
-  VSG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int32_t*)nullptr,
-                                           (int32_t*)nullptr, n));
-  return bytes;
-}
-
-void ExclusiveSumI32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, int n,
-                     hipStream_t s) {
-  VSG_HIP(hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, n, s));
-}
-
-size_t RleTempBytes(int n) {
-  size_t bytes = 0;
-  VSG_HIP(hipcub::DeviceRunLengthEncode::Encode(nullptr, bytes, (const uint32_t*)nullptr,
-                                                (uint32_t*)nullptr, (int32_t*)nullptr,
-                                                (int32_t*)nullptr, n));
-  return bytes;
-}
-
-void RunLengthEncodeU32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* unique_out,
-                        int32_t* counts_out, int32_t* num_runs_out, int n, hipStream_t s) {
-  VSG_HIP(hipcub::DeviceRunLengthEncode::Encode(temp, temp_bytes, in, unique_out, counts_out,
-                                                num_runs_out, n, s));
 }
 
 size_t UniqueU64TempBytes(int n) {
