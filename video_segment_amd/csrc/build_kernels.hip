@@ -103,35 +103,63 @@ void LaunchMinMax(const uint8_t* bgr, size_t stride, int W, int H, int* mm, hipS
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: bilateral filter.  One workgroup = 256 threads = a 64x16 output tile (4 rows per thread),
-// staged with its 4 px replicate halo in LDS next to the 12288-entry exp LUT (48 KiB).
-// The accumulation order over the 49 taps and every rounding step follow
-// ParallelBilateralColor::operator() exactly.
+// K1: bilateral filter.  One workgroup = 1024 threads = a 64x64 output tile, staged with its 4 px
+// replicate halo in LDS next to the 12288-entry exp LUT (48 KiB + 61 KiB: one workgroup of sixteen
+// wavefronts per CU, four per SIMD -- the kernel is a stream of LDS reads and LUT gathers whose
+// latency needs that many wavefronts to hide; 256 threads with their own LUT copy left one or two
+// per SIMD, the SIMDs half idle).  A thread filters two vertically adjacent pixels A (row y) and
+// B (row y + 1) together: their 9x9 windows overlap in eight rows, so a tile value is read once for
+// both (58 positions instead of 2 x 49 taps), and the arithmetic of the two runs as packed f32
+// pairs {A, B} (v_pk_mul_f32 / v_pk_add_f32: IEEE single, no contraction -- the same roundings as
+// two scalar operations).  The accumulation order over the 49 taps of EACH pixel (rows outer,
+// columns inner) and every rounding step follow ParallelBilateralColor::operator() exactly; a
+// position that is a tap of only one of the two contributes weight 0 to the other (x + 0 = x,
+// l * 0 = +0: exact, the sums are non-negative).
 // ------------------------------------------------------------------------------------------
-constexpr int kTileW = 64, kTileH = 16, kRad = 4;
+constexpr int kTileW = 64, kTileH = 64, kRad = 4;
 constexpr int kHaloW = kTileW + 2 * kRad, kHaloH = kTileH + 2 * kRad;
 constexpr int kLutBins = 12288;
+constexpr int kBilThreads = 1024;
 
-__global__ __launch_bounds__(256) void k_bilateral(const uint8_t* __restrict__ bgr, size_t stride,
-                                                    int W, int H, const float* __restrict__ lut_g,
-                                                    float scale, float* __restrict__ out_b,
-                                                    float* __restrict__ out_g,
-                                                    float* __restrict__ out_r, int tiles_x,
-                                                    int num_tiles) {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Tap (i, j) of the circular window, and its index in the reference's enumeration (rows i = -4 .. 4
+// outer, columns j inner, kept if i^2 + j^2 <= 16: image_filter.cpp:216-225).
+constexpr bool TapIn(int i, int j) {
+  return i >= -kRad && i <= kRad && j >= -kRad && j <= kRad && i * i + j * j <= kRad * kRad;
+}
+constexpr int TapIdx(int i, int j) {
+  int k = 0;
+  for (int a = -kRad; a <= kRad; ++a) {
+    for (int b = -kRad; b <= kRad; ++b) {
+      if (a == i && b == j) return k;
+      if (a * a + b * b <= kRad * kRad) ++k;
+    }
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(kBilThreads) void k_bilateral(const uint8_t* __restrict__ bgr, size_t stride,
+                                                            int W, int H, const float* __restrict__ lut_g,
+                                                            float scale, float* __restrict__ out_b,
+                                                            float* __restrict__ out_g,
+                                                            float* __restrict__ out_r, int tiles_x,
+                                                            int num_tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* lut = smem;                         // [12288]
   float* tb = smem + kLutBins;               // [kHaloH * kHaloW]
   float* tg = tb + kHaloH * kHaloW;
   float* tr = tg + kHaloH * kHaloW;
   const int tid = threadIdx.x;
-  for (int i = tid; i < kLutBins; i += 256) lut[i] = lut_g[i];
+  for (int i = tid; i < kLutBins; i += kBilThreads) lut[i] = lut_g[i];
   const float c255 = (float)(1.0 / 255.0);   // convertTo(CV_32FC3, 1.0/255.0)
+  const f32x2 scale2 = {scale, scale};
 
   for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
     const int x0 = (tile % tiles_x) * kTileW;
     const int y0 = (tile / tiles_x) * kTileH;
     __syncthreads();
-    for (int idx = tid; idx < kHaloH * kHaloW; idx += 256) {
+    for (int idx = tid; idx < kHaloH * kHaloW; idx += kBilThreads) {
       const int ty = idx / kHaloW, tx = idx - ty * kHaloW;
       const int gy = min(max(y0 + ty - kRad, 0), H - 1);   // BORDER_REPLICATE
       const int gx = min(max(x0 + tx - kRad, 0), W - 1);
@@ -143,45 +171,61 @@ __global__ __launch_bounds__(256) void k_bilateral(const uint8_t* __restrict__ b
     __syncthreads();
     const int tx = tid & 63;
     const int x = x0 + tx;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ty = (tid >> 6) + 4 * r;
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+      const int ty = 2 * ((tid >> 6) + 16 * r);   // rows ty (pixel A) and ty + 1 (pixel B)
       const int y = y0 + ty;
       if (x >= W || y >= H) continue;
-      const int c = (ty + kRad) * kHaloW + (tx + kRad);
-      const float my_b = tb[c], my_g = tg[c], my_r = tr[c];
-      float weight_sum = 0, sum_b = 0, sum_g = 0, sum_r = 0;
-      int k = 0;
+      const int c = (ty + kRad) * kHaloW + (tx + kRad);   // A's centre; B's is one tile row below
+      const f32x2 my_b = {tb[c], tb[c + kHaloW]};
+      const f32x2 my_g = {tg[c], tg[c + kHaloW]};
+      const f32x2 my_r = {tr[c], tr[c + kHaloW]};
+      f32x2 weight_sum = {0.0f, 0.0f}, sum_b = {0.0f, 0.0f}, sum_g = {0.0f, 0.0f}, sum_r = {0.0f, 0.0f};
 #pragma unroll
-      for (int i = -kRad; i <= kRad; ++i) {
+      for (int t = -kRad; t <= kRad + 1; ++t) {      // tile row relative to A: A's tap row t, B's tap row t - 1
 #pragma unroll
         for (int j = -kRad; j <= kRad; ++j) {
-          if (i * i + j * j > kRad * kRad) continue;
-          const int o = c + i * kHaloW + j;
+          const bool in_a = TapIn(t, j), in_b = TapIn(t - 1, j);
+          if (!in_a && !in_b) continue;
+          const int o = c + t * kHaloW + j;
           const float lb = tb[o], lg = tg[o], lr = tr[o];
-          const float diff_b = my_b - lb;
-          const float diff_g = my_g - lg;
-          const float diff_r = my_r - lr;
-          const int idx = (int)((diff_b * diff_b + diff_g * diff_g + diff_r * diff_r) * scale);
-          const float weight = c_space_w[k] * lut[idx];
+          const f32x2 l_b = {lb, lb}, l_g = {lg, lg}, l_r = {lr, lr};
+          const f32x2 diff_b = my_b - l_b;
+          const f32x2 diff_g = my_g - l_g;
+          const f32x2 diff_r = my_r - l_r;
+          const f32x2 d2 = (diff_b * diff_b + diff_g * diff_g + diff_r * diff_r) * scale2;
+          f32x2 weight = {0.0f, 0.0f};
+          if (in_a) weight.x = c_space_w[TapIdx(t, j)] * lut[(int)d2.x];
+          if (in_b) weight.y = c_space_w[TapIdx(t - 1, j)] * lut[(int)d2.y];
           weight_sum += weight;
-          sum_b += lb * weight;
-          sum_g += lg * weight;
-          sum_r += lr * weight;
-          ++k;
+          sum_b += l_b * weight;
+          sum_g += l_g * weight;
+          sum_r += l_r * weight;
         }
       }
       const size_t pix = (size_t)y * W + x;
-      if (weight_sum > 0) {
-        // weight_sum = 1.0 / weight_sum in double, rounded to float == IEEE 1.0f / weight_sum.
-        const float inv = 1.0f / weight_sum;
-        out_b[pix] = sum_b * inv;
-        out_g[pix] = sum_g * inv;
-        out_r[pix] = sum_r * inv;
+      // weight_sum = 1.0 / weight_sum in double, rounded to float == IEEE 1.0f / weight_sum.
+      if (weight_sum.x > 0) {
+        const float inv = 1.0f / weight_sum.x;
+        out_b[pix] = sum_b.x * inv;
+        out_g[pix] = sum_g.x * inv;
+        out_r[pix] = sum_r.x * inv;
       } else {
         out_b[pix] = 0.0f;
         out_g[pix] = 0.0f;
         out_r[pix] = 0.0f;
+      }
+      if (y + 1 < H) {
+        if (weight_sum.y > 0) {
+          const float inv = 1.0f / weight_sum.y;
+          out_b[pix + W] = sum_b.y * inv;
+          out_g[pix + W] = sum_g.y * inv;
+          out_r[pix + W] = sum_r.y * inv;
+        } else {
+          out_b[pix + W] = 0.0f;
+          out_g[pix + W] = 0.0f;
+          out_r[pix + W] = 0.0f;
+        }
       }
     }
   }
@@ -206,9 +250,9 @@ void LaunchBilateral(const uint8_t* bgr, size_t stride, int W, int H, const floa
   const int tiles_x = (W + kTileW - 1) / kTileW;
   const int tiles_y = (H + kTileH - 1) / kTileH;
   const int num_tiles = tiles_x * tiles_y;
-  const int grid = min(num_tiles, 512);   // 2 workgroups per CU (70 KiB LDS each), persistent
+  const int grid = min(num_tiles, 256);   // one workgroup per CU (109 KiB LDS each), persistent
   const size_t n = (size_t)W * H;
-  hipLaunchKernelGGL(k_bilateral, dim3(grid), dim3(256), smem, s, bgr, stride, W, H, lut, scale,
+  hipLaunchKernelGGL(k_bilateral, dim3(grid), dim3(kBilThreads), smem, s, bgr, stride, W, H, lut, scale,
                      planes, planes + n, planes + 2 * n, tiles_x, num_tiles);
   VSG_HIP(hipGetLastError());
 }

@@ -459,6 +459,8 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   };
   S.num_active = scalars_.get();
   S.num_segs = scalars_.get() + 1;
+  S.node_key_bits = 1;
+  while (S.node_key_bits < 32 && ((size_t)1 << S.node_key_bits) < N) ++S.node_key_bits;
   {
     const size_t words = 4 * ((scratch_edges_ + 255) / 256) + 4;
     S.masks.active = filter_masks_.get();

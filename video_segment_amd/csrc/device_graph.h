@@ -253,6 +253,7 @@ struct MergeScratch {
   void* cub_temp;        // temporary storage of the radix sort
   size_t cub_temp_bytes;
   ScanScratch scan;
+  int node_key_bits;     // bits of the largest node id: what a radix sort by vertex / component has to look at
   // HIP event pairs recorded around k_filter / k_merge_wave launches (resolved by the caller
   // after the stream has been synchronised).
   std::vector<hipEvent_t>* ev_pool;

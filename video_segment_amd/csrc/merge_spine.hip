@@ -67,17 +67,30 @@ __global__ __launch_bounds__(256) void k_spine_gather(int mE, int K, const int32
                                                        int32_t* __restrict__ estate, int32_t* __restrict__ cc,
                                                        uint32_t* __restrict__ best) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= mE) return;
-  const int lo = CompOf(comp_base, K, e);
-  const int pos = comp_off[lo] + (e - comp_base[lo]);
-  const int u = s_ra[pos], v = s_rb[pos];
-  eu[e] = u;
-  ev[e] = v;
-  estate[e] = 0;
-  cc[u] = u;
-  cc[v] = v;
-  best[u] = 0xffffffffu;
-  best[v] = 0xffffffffu;
+  const bool valid = e < mE;
+  int u = -1, v = -1;
+  if (valid) {
+    const int lo = CompOf(comp_base, K, e);
+    const int pos = comp_off[lo] + (e - comp_base[lo]);
+    u = s_ra[pos];
+    v = s_rb[pos];
+    eu[e] = u;
+    ev[e] = v;
+    estate[e] = 0;
+  }
+  // The per-vertex tables are scattered 4-byte stores (a sector each), and consecutive edges of a
+  // large component share a vertex more often than not (the hub): a lane whose vertex the lane
+  // before it resets as well leaves the store to that lane.
+  const int pu = __shfl_up(u, 1), pv = __shfl_up(v, 1);
+  const bool first = (threadIdx.x & 63) == 0;
+  if (valid && (first || (u != pu && u != pv))) {
+    cc[u] = u;
+    best[u] = 0xffffffffu;
+  }
+  if (valid && v != u && (first || (v != pu && v != pv))) {
+    cc[v] = v;
+    best[v] = 0xffffffffu;
+  }
 }
 
 // ---- Boruvka ----------------------------------------------------------------------------------------
@@ -1535,7 +1548,7 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   if (!pool.ok) return false;
   hipLaunchKernelGGL(k_compact_tree, dim3(Blocks(mE)), dim3(256), 0, s, mE, flag, scan, te_e);
   hipLaunchKernelGGL(k_arc_keys, dim3(Blocks(na)), dim3(256), 0, s, mt, te_e, eu, ev, ak_in, av_in);
-  SortPairsU32(S.cub_temp, S.cub_temp_bytes, ak_in, ak, av_in, av, na, 32, s);
+  SortPairsU32(S.cub_temp, S.cub_temp_bytes, ak_in, ak, av_in, av, na, S.node_key_bits, s);
   hipLaunchKernelGGL(k_arc_first, dim3(Blocks(na)), dim3(256), 0, s, na, ak, av, firstq, pos_arc);
   hipLaunchKernelGGL(k_arc_succ, dim3(Blocks(na)), dim3(256), 0, s, na, ak, av, firstq, pos_arc, te_e, d_base, K,
                      root_vertex, succ[0], dist[0]);
@@ -1645,7 +1658,9 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   Mark(4);
   if (S.spine_check) SpineSelfCheck(base, mE, eu, ev, root_vertex, side_key, spine_flag, te_e, mt);
   if (n_side > 0) {
-    SortPairsU32(S.cub_temp, S.cub_temp_bytes, sk_in, sk, si_in, si, n_side, 32, s);
+    int side_bits = 1;   // the keys are tree-edge indices
+    while (side_bits < 32 && (1ll << side_bits) < (long long)mt) ++side_bits;
+    SortPairsU32(S.cub_temp, S.cub_temp_bytes, sk_in, sk, si_in, si, n_side, side_bits, s);
     int32_t* d_nseg = scalars + 3;
     RunsOfSortedKeys(S.scan, sk, n_side, seg_off, seg_cnt, d_nseg, s);
     hipLaunchKernelGGL(k_gather_side, dim3(Blocks(n_side)), dim3(256), 0, s, n_side, si, d_base, d_off, K, wa.s_ra,

@@ -924,7 +924,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
 
   hipLaunchKernelGGL(k_component_ids, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, S.cc,
                      S.a_comp, S.a_idx);
-  SortPairsU32(S.cub_temp, S.cub_temp_bytes, S.a_comp, S.s_comp, S.a_idx, S.s_idx, n_work, 32, s);
+  SortPairsU32(S.cub_temp, S.cub_temp_bytes, S.a_comp, S.s_comp, S.a_idx, S.s_idx, n_work, S.node_key_bits, s);
   // the components = the runs of equal keys: first position and length of every run
   RunsOfSortedKeys(S.scan, S.s_comp, n_work, S.seg_off, S.seg_cnt, S.num_segs, s);
 
