@@ -7,7 +7,7 @@ statistics of the same command:
 Per kernel: launches, every counter (sum and per launch), and with --stats the average launch
 duration and the HBM rate (FETCH_SIZE + WRITE_SIZE) / duration against the 8 TB/s peak.
 --wave-json OUT writes the per-launch bytes of vsg::k_merge_wave to OUT and those of k_spine to OUT
-with "wave" replaced by "spine", in the form bench.py reads from profiles/r4_pmc_{wave,spine}.json;
+with "wave" replaced by "spine", in the form bench.py reads from profiles/<round>_pmc_{wave,spine}.json;
 --bench-log LOG: the output of the counter pass (bench.py's own JSON line), whose algorithmic bytes
 per launch are stored next to the counters of that same run.
 

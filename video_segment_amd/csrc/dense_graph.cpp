@@ -241,29 +241,43 @@ void DenseGraphHip::EnsureScratch(size_t n) {
 
 void DenseGraphHip::EnsureActiveScratch(size_t n) {
   if (n <= scratch_active_) return;
-  n = n + n / 8 + 1024;
-  e_active_.alloc(n);
-  e_apos_.alloc(n);
-  a_ra_.alloc(n);
-  a_rb_.alloc(n);
-  a_gpos_.alloc(n);
-  a_comp_.alloc(n);
-  a_idx_.alloc(n);
-  s_comp_.alloc(n);
-  s_idx_.alloc(n);
-  seg_key_.alloc(n);
-  seg_cnt_.alloc(n);
-  seg_off_.alloc(n);
-  lead_pos_.alloc(n);
-  l_ra_.alloc(n);
-  l_rb_.alloc(n);
-  l_gpos_.alloc(n);
-  bk_ds_.alloc(2 * n);
-  bk_cons_.alloc(2 * n);
-  bk_flags_.alloc(2 * n);
-  size_t temp = cub_temp_.size();
+  // (half as much again: a stage that needs more than the last one is usually followed by one that
+  // needs more still, and every growth drains the streams)
+  n = std::max(n + n / 8 + 1024, scratch_active_ + scratch_active_ / 2);
+  size_t bytes = 0;
+  auto carve = [&bytes](size_t elems, size_t elem_size) {
+    const size_t at = bytes;
+    bytes += (elems * elem_size + 255) & ~(size_t)255;
+    return at;
+  };
+  const size_t o_e_active = carve(n, 4), o_e_apos = carve(n, 4), o_a_ra = carve(n, 4), o_a_rb = carve(n, 4),
+               o_a_gpos = carve(n, 4), o_a_comp = carve(n, 4), o_a_idx = carve(n, 4), o_s_comp = carve(n, 4),
+               o_s_idx = carve(n, 4), o_seg_key = carve(n, 4), o_seg_cnt = carve(n, 4), o_seg_off = carve(n, 4),
+               o_lead_pos = carve(n, 4), o_l_ra = carve(n, 4), o_l_rb = carve(n, 4), o_l_gpos = carve(n, 4),
+               o_bk_ds = carve(2 * n, sizeof(float4)), o_bk_cons = carve(2 * n, 4), o_bk_flags = carve(2 * n, 1);
+  active_slab_.alloc(bytes);
+  uint8_t* b = active_slab_.get();
+  act_.e_active = reinterpret_cast<int32_t*>(b + o_e_active);
+  act_.e_apos = reinterpret_cast<int32_t*>(b + o_e_apos);
+  act_.a_ra = reinterpret_cast<int32_t*>(b + o_a_ra);
+  act_.a_rb = reinterpret_cast<int32_t*>(b + o_a_rb);
+  act_.a_gpos = reinterpret_cast<uint32_t*>(b + o_a_gpos);
+  act_.a_comp = reinterpret_cast<uint32_t*>(b + o_a_comp);
+  act_.a_idx = reinterpret_cast<uint32_t*>(b + o_a_idx);
+  act_.s_comp = reinterpret_cast<uint32_t*>(b + o_s_comp);
+  act_.s_idx = reinterpret_cast<uint32_t*>(b + o_s_idx);
+  act_.seg_key = reinterpret_cast<uint32_t*>(b + o_seg_key);
+  act_.seg_cnt = reinterpret_cast<int32_t*>(b + o_seg_cnt);
+  act_.seg_off = reinterpret_cast<int32_t*>(b + o_seg_off);
+  act_.lead_pos = reinterpret_cast<int32_t*>(b + o_lead_pos);
+  act_.l_ra = reinterpret_cast<int32_t*>(b + o_l_ra);
+  act_.l_rb = reinterpret_cast<int32_t*>(b + o_l_rb);
+  act_.l_gpos = reinterpret_cast<uint32_t*>(b + o_l_gpos);
+  act_.bk_ds = reinterpret_cast<float4*>(b + o_bk_ds);
+  act_.bk_cons = reinterpret_cast<int32_t*>(b + o_bk_cons);
+  act_.bk_flags = b + o_bk_flags;
   // (the largest sort of a stage: the arcs of the spanning trees, two per tree edge -- merge_spine.hip)
-  temp = std::max(temp, SortPairsU32TempBytes((int)std::min<size_t>(2 * n, 0x7fffffff)));
+  const size_t temp = SortPairsU32TempBytes((int)std::min<size_t>(2 * n, 0x7fffffff));
   if (temp > cub_temp_.size()) cub_temp_.alloc(temp);
   scratch_active_ = n;
 }
@@ -413,7 +427,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     EnsureActiveScratch((size_t)std::max(1, atoi(e)));
   } else {
     EnsureActiveScratch(std::min<size_t>((size_t)std::max<int64_t>(n_max, 1),
-                                         std::max<size_t>((size_t)n_max / 8, (size_t)1 << 20)));
+                                         std::max<size_t>((size_t)n_max / 4, (size_t)1 << 20)));
   }
   bucket_prefix_dev_.ensure(bucket_prefix.size());
   H2D(bucket_prefix_dev_.get(), bucket_prefix.data(), bucket_prefix.size(), stream_);
@@ -423,25 +437,25 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     S.e_ra = e_ra_.get();
     S.e_rb = e_rb_.get();
     S.e_gpos = e_gpos_.get();
-    S.e_active = e_active_.get();
-    S.e_apos = e_apos_.get();
-    S.a_ra = a_ra_.get();
-    S.a_rb = a_rb_.get();
-    S.a_gpos = a_gpos_.get();
-    S.a_comp = a_comp_.get();
-    S.a_idx = a_idx_.get();
-    S.s_comp = s_comp_.get();
-    S.s_idx = s_idx_.get();
-    S.seg_key = seg_key_.get();
-    S.seg_cnt = seg_cnt_.get();
-    S.seg_off = seg_off_.get();
-    S.lead_pos = lead_pos_.get();
-    S.l_ra = l_ra_.get();
-    S.l_rb = l_rb_.get();
-    S.l_gpos = l_gpos_.get();
-    S.bk_ds = bk_ds_.get();
-    S.bk_cons = bk_cons_.get();
-    S.bk_flags = bk_flags_.get();
+    S.e_active = act_.e_active;
+    S.e_apos = act_.e_apos;
+    S.a_ra = act_.a_ra;
+    S.a_rb = act_.a_rb;
+    S.a_gpos = act_.a_gpos;
+    S.a_comp = act_.a_comp;
+    S.a_idx = act_.a_idx;
+    S.s_comp = act_.s_comp;
+    S.s_idx = act_.s_idx;
+    S.seg_key = act_.seg_key;
+    S.seg_cnt = act_.seg_cnt;
+    S.seg_off = act_.seg_off;
+    S.lead_pos = act_.lead_pos;
+    S.l_ra = act_.l_ra;
+    S.l_rb = act_.l_rb;
+    S.l_gpos = act_.l_gpos;
+    S.bk_ds = act_.bk_ds;
+    S.bk_cons = act_.bk_cons;
+    S.bk_flags = act_.bk_flags;
     S.cub_temp = cub_temp_.get();
     S.cub_temp_bytes = cub_temp_.size();
     S.scan = ScanScratch{scan_sums_.get()};
@@ -450,11 +464,17 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   bind_scratch();
   S.grow_active = [this, bind_scratch](long long need) {
     // (nothing of the stage is in the active arrays yet: RunBucketStage asks before it uses them)
+    const double tg0 = NowMs();
     VSG_HIP(hipStreamSynchronize(stream_));
     VSG_HIP(hipStreamSynchronize(aux_stream_));
     VSG_HIP(hipStreamSynchronize(aux2_stream_));
+    const size_t before = scratch_active_;
     EnsureActiveScratch((size_t)need);
     bind_scratch();
+    if (getenv("VSG_DEBUG_STATS")) {
+      std::fprintf(stderr, "[vsg] stage scratch: %zu -> %zu active edges (needed %lld), %.2f ms\n", before,
+                   scratch_active_, need, NowMs() - tg0);
+    }
     return true;
   };
   S.num_active = scalars_.get();
@@ -940,11 +960,11 @@ void DenseGraphHip::MergeConstrainedHostAssisted() {
     const size_t old = out->node.size();
     if (k > 0) {
       EnsureActiveScratch((size_t)k);
-      LaunchCompactIndexValue(d_flags, d_offs, d_vals, n, a_ra_.get(), a_rb_.get(), stream_);
+      LaunchCompactIndexValue(d_flags, d_offs, d_vals, n, act_.a_ra, act_.a_rb, stream_);
       out->node.resize(old + k);
       out->value.resize(old + k);
-      D2H(out->node.data() + old, a_ra_.get(), (size_t)k, stream_);
-      D2H(out->value.data() + old, a_rb_.get(), (size_t)k, stream_);
+      D2H(out->node.data() + old, act_.a_ra, (size_t)k, stream_);
+      D2H(out->value.data() + old, act_.a_rb, (size_t)k, stream_);
       VSG_HIP(hipStreamSynchronize(stream_));
       for (size_t i = old; i < old + (size_t)k; ++i) out->node[i] += begin;
     }

@@ -145,14 +145,22 @@ class DenseGraphHip {
   DevBuf<int32_t> hist_tmp_, hist_sums_;   // edge_sort.hip scratch
   DevBuf<int32_t> first_label_scratch_;
   // merge scratch
-  DevBuf<int32_t> e_ra_, e_rb_, e_active_, e_apos_, a_ra_, a_rb_, seg_cnt_, seg_off_;
-  DevBuf<int32_t> lead_pos_, l_ra_, l_rb_;
-  DevBuf<uint32_t> e_gpos_, a_gpos_, a_comp_, a_idx_, s_comp_, s_idx_, seg_key_, l_gpos_;
-  DevBuf<uint8_t> bk_flags_;
+  DevBuf<int32_t> e_ra_, e_rb_;
+  DevBuf<uint32_t> e_gpos_;
+  // The arrays sized by a stage's ACTIVE edges live in one slab (a single allocation: growing them
+  // in the middle of a stage is one hipFree + hipMalloc, not nineteen), carved up by
+  // EnsureActiveScratch.
+  DevBuf<uint8_t> active_slab_;
+  struct ActiveArrays {
+    int32_t *e_active = nullptr, *e_apos = nullptr, *a_ra = nullptr, *a_rb = nullptr, *seg_cnt = nullptr,
+            *seg_off = nullptr, *lead_pos = nullptr, *l_ra = nullptr, *l_rb = nullptr, *bk_cons = nullptr;
+    uint32_t *a_gpos = nullptr, *a_comp = nullptr, *a_idx = nullptr, *s_comp = nullptr, *s_idx = nullptr,
+             *seg_key = nullptr, *l_gpos = nullptr;
+    float4* bk_ds = nullptr;
+    uint8_t* bk_flags = nullptr;
+  } act_;
   DevBuf<unsigned long long> filter_masks_;   // k_filter's verdict: 3 x one bit per edge
   DevBuf<int32_t> block_cnt_, block_off_;
-  DevBuf<float4> bk_ds_;
-  DevBuf<int32_t> bk_cons_;
   int64_t optimistic_stages_ = 0, rollbacks_ = 0;
   DevBuf<int32_t> scalars_;   // num_active, num_segs, misc
   DevBuf<int32_t> seg_table_dev_;   // k_filter: the segments of the current stage
