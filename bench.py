@@ -302,19 +302,31 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps, out):
     cw, chh, cf = 640, 480, 32
     frames = [synth.frame_torch("bench", cw, chh, k, dev) for k in range(cf)]
 
+    phases = {"create": 0.0, "add_frames": 0.0, "segment": 0.0, "read_out": 0.0, "close": 0.0}
+
     def run_graph():
+        t = [time.perf_counter()]
         g = vsg.DenseSegGraph(cw, chh, cf, device=device_index)
+        t.append(time.perf_counter())
         for f in frames:
             g.add_frame_bgr(f)
         g.finish_building()
+        t.append(time.perf_counter())
         g.segment(983, False)
+        t.append(time.perf_counter())
         g.obtain_results(use_flows=False)
         n = g.num_regions()
+        t.append(time.perf_counter())
         g.close()
+        t.append(time.perf_counter())
+        for i, k in enumerate(phases):
+            phases[k] += t[i + 1] - t[i]
         return n
 
     run_graph()
     torch.cuda.synchronize()
+    for k in phases:
+        phases[k] = 0.0
     t0 = time.perf_counter()
     reps = 3
     for _ in range(reps):
@@ -325,6 +337,7 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps, out):
                       "(DenseSegGraphInterface seam: add frames, SegmentFullGraph(983), ObtainResults + "
                       "DetermineNeighborIds), frames resident in HBM",
           "value": cf / dt, "unit": "frames/s", "ms_per_window": dt * 1e3, "regions": nreg,
+          "phase_ms_per_window": {k: v / reps * 1e3 for k, v in phases.items()},
           "roofline_note": "55 B/px/frame (SURVEY 8(d), spatial-only) -> %.2f GB/s" %
                            (cf / dt * cw * chh * 55.0 / 1e9)}
     if not args.no_cpu_baseline:
@@ -342,6 +355,8 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps, out):
         c1["parity_checked"] = bool(og.num_regions() == nreg)
         og.close()
     out["configs"]["configs[1]"] = c1
+    if os.environ.get("VSG_BENCH_EXTRAS") == "configs1":   # (debugging aid: only this leg)
+        return out
 
     # ---- 3840x2160 + flow (the over-segmentation half of configs[4]) --------------------------
     w4, h4 = 3840, 2160

@@ -1,7 +1,13 @@
 set -u
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r5n
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r5p
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-bash tools/sweep_env.sh $OUT/sweep.log "VSG_WINDOWS=1" "VSG_WINDOWS=2" "VSG_WINDOWS=3" "VSG_WINDOWS=6" "VSG_WINDOWS=12" "VSG_WINDOWS=16 VSG_SPINE_MIN=8192" "VSG_WINDOWS=24 VSG_SPINE_MIN=8192" > /dev/null 2>&1
-cut -c1-100 $OUT/sweep.log
-VSG_DEBUG_STAGES=1 VSG_WINDOWS=2 timeout 120 python tools/perf_probe.py 1920 1080 41 20 2>&1 | grep -E "stage b=[012] " | tail -12 | cut -c1-200
+export VSG_BENCH_EXTRAS=configs1
+for i in 1 2; do
+  timeout 600 python bench.py > $OUT/b_$i.json 2> $OUT/b_$i.err
+  python - <<PY
+import json
+n=json.loads([l for l in open("$OUT/b_$i.json") if l.startswith("{")][-1])
+print(n["value"], n["configs"]["configs[1]"]["ms_per_window"], n["configs"]["configs[1]"]["phase_ms_per_window"])
+PY
+done
