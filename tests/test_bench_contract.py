@@ -72,10 +72,11 @@ def test_two_ranks_control_flow(mode, port):
 def test_committed_round_line_carries_every_key():
     """The default `python bench.py` line of the round (profiles/, produced on an MI355X by
     tools/measure_round.sh): the contract keys plus what the headline depends on -- the other
-    single-GPU configs, the other inputs, the streams sweep."""
+    single-GPU configs, the other inputs (each with its own oracle check), the streams sweep, the
+    memory a stream holds -- and counters that belong to the kernel sources of the same commit."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r4_*_bench_1080p.json")))
-    assert paths, "no round-4 bench line under profiles/"
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r5_*_bench_1080p.json")))
+    assert paths, "no round-5 bench line under profiles/"
     out = last_json_line(open(paths[-1]).read())
     check(out, 1, out["steps"], out["warmup"])
     assert out["vs_baseline"] is None and out["parity_checked"] is True
@@ -84,13 +85,23 @@ def test_committed_round_line_carries_every_key():
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["peak"] == 8000.0
     cfg = out["configs"]
     assert cfg["configs[1]"]["cpu_baseline"]["value"] > 0 and cfg["configs[1]"]["parity_checked"] is True
+    assert set(cfg["configs[1]"]["phase_ms_per_window"]) == {"create", "add_frames", "segment", "read_out", "close"}
     assert cfg["3840x2160"]["value"] > 0 and cfg["configs[4]"]["value"] > 0
-    assert set(out["workloads"]) >= {"checker (headline input)", "blobs", "noise"}
+    # four 3840x2160 streams fit the 288 GB of the device
+    assert (1 << 30) < cfg["3840x2160"]["device_bytes_per_stream"] < 72e9
+    wl = out["workloads"]
+    assert set(wl) >= {"checker (headline input)", "blobs", "noise"}
+    assert wl["blobs"]["parity_checked"] is True and wl["noise"]["parity_checked"] is True
     assert [s["streams"] for s in out["streams_sweep"]] == [1, 2, 4, 8]
-    assert out["pipelined"]["value"] > 0
-    # round 4: a measured denominator, the per-kernel table and the memory a stream holds
+    assert "pipelined" not in out          # (only with --pipelined-leg)
     r = out["roofline"]
     assert r["peak_measured"] > 1000 and 0 < r["frac_of_measured"] < 1
     assert len(r["kernels"]["top"]) == 8 and all(k["ms_per_step"] > 0 for k in r["kernels"]["top"])
     assert 0.9 < r["traffic_vs_algorithmic_same_run"] < 1.5
-    assert out["device_bytes_per_stream"] > (1 << 30)
+    assert (1 << 30) < out["device_bytes_per_stream"] < 24e9
+    # the counters the line quotes were taken from the kernel sources that are committed with it
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_hash import source_hash
+    assert r["kernels"]["source_hash"] == source_hash(ROOT)
+    for name in ("r5_pmc_wave.json", "r5_pmc_spine.json", "r5_kernel_table.json"):
+        assert json.load(open(os.path.join(ROOT, "profiles", name)))["source_hash"] == source_hash(ROOT), name

@@ -421,14 +421,16 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   for (int b = 0; b < kNumBuckets; ++b) n_max = std::max<int64_t>(n_max, bucket_prefix[b + 1] - bucket_prefix[b]);
   VSG_REQUIRE(bucket_prefix[kNumBuckets] >= 0, -1, "too many edges");
   EnsureScratch((size_t)std::max<int64_t>(n_max, 1));
-  // (a first guess for a handle that has not seen a chunk yet -- half the largest bucket: the stage
-  // of the giant components of a first, unconstrained 1080p chunk has 61 M active edges of 139 M, the
-  // window graph of configs[1] 9.5 M of 17 M --; later chunks start with what the earlier ones needed)
+  // (a first guess for a handle that has not seen a chunk yet: a quarter of the largest bucket.  The
+  // stage of the giant components of a first, unconstrained 1080p chunk has 61 M active edges of
+  // 139 M and the window graph of configs[1] 9.5 M of 17 M -- one growth of the slab each, a
+  // millisecond --, a 3840x2160 chunk stays below the quarter, and half the bucket would be 33 GB
+  // there.  Later chunks start with what the earlier ones needed.)
   if (const char* e = getenv("VSG_ACTIVE_CAP")) {   // test hook: start small, grow inside the stages
     EnsureActiveScratch((size_t)std::max(1, atoi(e)));
   } else {
     EnsureActiveScratch(std::min<size_t>((size_t)std::max<int64_t>(n_max, 1),
-                                         std::max<size_t>((size_t)n_max / 2, (size_t)1 << 20)));
+                                         std::max<size_t>((size_t)n_max / 4, (size_t)1 << 20)));
   }
   bucket_prefix_dev_.ensure(bucket_prefix.size());
   H2D(bucket_prefix_dev_.get(), bucket_prefix.data(), bucket_prefix.size(), stream_);
