@@ -58,6 +58,12 @@ def test_chain_self_check_is_silent(vsg, monkeypatch, capfd):
                                  {"VSG_SPINE_MIN": "32", "VSG_RANK_SPLIT_MIN": "0", "VSG_SPINE_CHECK": "1"},
                                  # every round of the spanning forest answered before the next is launched
                                  {"VSG_SPINE_MIN": "32", "VSG_BOR_AHEAD": "0", "VSG_SPINE_CHECK": "1"},
+                                 # the forest's edge list compacted whenever the rounds allow it, however
+                                 # short it is: one round ahead of the host (after every round, its length
+                                 # known on the device only) and synchronously (when half the list is settled)
+                                 {"VSG_SPINE_MIN": "32", "VSG_BOR_COMPACT_MIN": "16", "VSG_SPINE_CHECK": "1"},
+                                 {"VSG_SPINE_MIN": "32", "VSG_BOR_COMPACT_MIN": "16", "VSG_BOR_AHEAD": "0",
+                                  "VSG_SPINE_CHECK": "1", "VSG_ZERO_POOL": "4096"},
                                  # the arrays that hold a stage's active edges start far too small and
                                  # grow inside the stages (the compaction is repeated)
                                  {"VSG_ACTIVE_CAP": "64"},

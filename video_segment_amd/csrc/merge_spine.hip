@@ -1451,6 +1451,9 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
     // Long lists (the giant components) stay synchronous: there the round after next is worth
     // compacting for, and an unneeded pass over 40 M edges is not free.
     const int ahead_max = getenv("VSG_BOR_AHEAD") ? atoi(getenv("VSG_BOR_AHEAD")) : (4 << 20);
+    // (lists shorter than this are not worth a compaction pass; the tests lower it so that every
+    // small case compacts after every round)
+    const int compact_min = getenv("VSG_BOR_COMPACT_MIN") ? atoi(getenv("VSG_BOR_COMPACT_MIN")) : (1 << 16);
     MailSlot waiting[2];
     int n_waiting = 0;
     const int32_t* gate = nullptr;
@@ -1493,8 +1496,8 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
       // (list_len).  n_list -- the capacity the kernels are launched for -- may only shrink together
       // with a compaction: `alive` (the last count answered) bounds what the NEW list holds, not the
       // entries of a list that stays.
-      const bool compact = depth == 1 ? (round >= 1 && n_list > (1 << 16))
-                                      : (alive < n_list / 2 && n_list > (1 << 16));
+      const bool compact = depth == 1 ? (round >= 1 && n_list > compact_min)
+                                      : (alive < n_list / 2 && n_list > compact_min);
       if (!compact) continue;
       if (!lists[0]) {
         const size_t m = pool.mark();
