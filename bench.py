@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=20)
     ap.add_argument("--pipelined-leg", action="store_true",
                     help="also measure two chunk engines on one video (video_segment_amd/pipelined.py)")
+    ap.add_argument("--no-chain-leg", action="store_true",
+                    help="N > 1, --mode streams: skip the short chunk-chain leg after the replicas leg")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the information-only legs after the timed region (other configs, other "
                          "inputs, several streams per GPU)")
@@ -134,6 +136,8 @@ def cpu_baseline(W, H, chunk, n_frames, device):
 ACC_KEYS = ["wave_ms", "wave_launches", "wave_edges", "spine_ms", "spine_launches", "spine_edges",
             "merge_ms", "pre_ms", "edges_ms", "readout_ms", "host_ms", "filter_ms", "filter_launches",
             "edges_total", "merges"]
+DIAG_KEYS = ["stages", "rollbacks", "slab_growths", "spine_pool_growths", "runtime_mallocs", "runtime_frees",
+             "device_syncs", "mail_waits", "mail_wait_ms", "prepare_ms", "constrained_merge_ms"]
 
 
 def add_timings(a, t):
@@ -165,16 +169,18 @@ def make_frames(kind, W, H, n, dev, seed_shift=0, host=False):
 
 
 def time_streams(vsg, frames, flow, W, H, chunk, S, warm, steps, device_index, barrier=None):
-    """S independent streams (one host thread each) over the same resident frames: `warm` untimed
+    """S independent streams (one host thread each) over the same resident frames (flow: one resident
+    field for every frame, or a list with the field of frame k): `warm` untimed
     chunk boundaries per stream, then exactly `steps` timed ones between two synchronisations.
     Every SegmentationDesc of a boundary is fetched inside the timed region."""
     import threading
     torch.cuda.synchronize()
-    free_before = torch.cuda.mem_get_info(device_index)[0]
+    in_use_before = vsg.memory_stats(device_index)["bytes_in_use"]
     streams = [vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=device_index),
                                      has_flow=True) for _ in range(S)]
     torch.cuda.synchronize()
-    accs = [dict((k_, 0) for k_ in ACC_KEYS) for _ in range(S)]
+    accs = [dict((k_, 0) for k_ in ACC_KEYS + DIAG_KEYS) for _ in range(S)]
+    step_ms = [[] for _ in range(S)]
     outs = [0] * S
     pos = [0] * S
     errors = []
@@ -182,9 +188,10 @@ def time_streams(vsg, frames, flow, W, H, chunk, S, warm, steps, device_index, b
     def run_stream(si, n_steps, record):
         stream = streams[si]
         done = 0
+        t_last = time.perf_counter()
         while done < n_steps:
             k = pos[si]
-            n = stream.process_frame(frames[k], flow if k > 0 else None)
+            n = stream.process_frame(frames[k], (flow[k] if isinstance(flow, list) else flow) if k > 0 else None)
             pos[si] = k + 1
             if n:
                 # the consumer side of the boundary: every SegmentationDesc is fetched
@@ -195,6 +202,14 @@ def time_streams(vsg, frames, flow, W, H, chunk, S, warm, steps, device_index, b
                 if record:
                     outs[si] += n
                     add_timings(accs[si], stream.last_timings())
+                    dg = stream.last_diagnostics()
+                    for k_ in DIAG_KEYS:
+                        accs[si][k_] += dg[k_]
+                    now = time.perf_counter()
+                    step_ms[si].append((now - t_last) * 1e3)
+                    t_last = now
+                else:
+                    t_last = time.perf_counter()
 
     def run(si, n_steps, record):
         try:
@@ -226,12 +241,17 @@ def time_streams(vsg, frames, flow, W, H, chunk, S, warm, steps, device_index, b
     sync()
     dt = time.perf_counter() - t0
     # what the streams hold on the device after warm-up and the timed chunks (their scratch only
-    # grows): the drop in free device memory since before they were created
-    device_bytes = max(0, free_before - torch.cuda.mem_get_info(device_index)[0]) // S
+    # grows): the library's own account of the blocks its live handles hold (vsg_device_memory_stats;
+    # the drop in free device memory would miss blocks adopted from the cache of closed handles)
+    device_bytes = max(0, vsg.memory_stats(device_index)["bytes_in_use"] - in_use_before) // S
     for st_ in streams:
         st_.close()
-    acc = dict((k_, sum(a[k_] for a in accs) / S) for k_ in ACC_KEYS)
-    return {"dt": dt, "frames": sum(outs), "acc": acc, "device_bytes_per_stream": int(device_bytes)}
+    acc = dict((k_, sum(a[k_] for a in accs) / S) for k_ in ACC_KEYS + DIAG_KEYS)
+    all_steps = sorted(x for l_ in step_ms for x in l_)
+    spread = ({"min": all_steps[0], "median": all_steps[len(all_steps) // 2], "max": all_steps[-1]}
+              if all_steps else None)
+    return {"dt": dt, "frames": sum(outs), "acc": acc, "device_bytes_per_stream": int(device_bytes),
+            "step_ms": spread}
 
 
 def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=5):
@@ -302,9 +322,11 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps, out):
     cw, chh, cf = 640, 480, 32
     frames = [synth.frame_torch("bench", cw, chh, k, dev) for k in range(cf)]
 
-    phases = {"create": 0.0, "add_frames": 0.0, "segment": 0.0, "read_out": 0.0, "close": 0.0}
+    phase_names = ("create", "add_frames", "segment", "read_out", "close")
 
     def run_graph():
+        """One window on a fresh graph handle, as the reference's callers use the interface
+        (dense_seg_graph_interface.h:58-98); returns (#regions, phase ms, diagnostics of segment)."""
         t = [time.perf_counter()]
         g = vsg.DenseSegGraph(cw, chh, cf, device=device_index)
         t.append(time.perf_counter())
@@ -317,27 +339,49 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps, out):
         g.obtain_results(use_flows=False)
         n = g.num_regions()
         t.append(time.perf_counter())
+        diag = g.diagnostics()
         g.close()
         t.append(time.perf_counter())
-        for i, k in enumerate(phases):
-            phases[k] += t[i + 1] - t[i]
-        return n
+        return n, {k: (t[i + 1] - t[i]) * 1e3 for i, k in enumerate(phase_names)}, diag
 
-    run_graph()
+    mem0 = vsg.memory_stats(device_index)
+    _, first_phases, first_diag = run_graph()      # the first window of the process at this size
     torch.cuda.synchronize()
-    for k in phases:
-        phases[k] = 0.0
+    mem1 = vsg.memory_stats(device_index)
+    reps = 8
+    windows = []
     t0 = time.perf_counter()
-    reps = 3
     for _ in range(reps):
-        nreg = run_graph()
+        tw = time.perf_counter()
+        nreg, ph, diag = run_graph()
+        windows.append({"ms": (time.perf_counter() - tw) * 1e3, "phases": ph, "diag": diag})
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    mem2 = vsg.memory_stats(device_index)
+    wms = sorted(w["ms"] for w in windows)
+    slowest = max(windows, key=lambda w: w["ms"])
+    diag_keys = ("stages", "rollbacks", "slab_growths", "slab_growth_ms", "spine_pool_growths",
+                 "spine_pool_growth_ms", "runtime_mallocs", "runtime_malloc_ms", "runtime_frees",
+                 "runtime_free_ms", "cache_hits", "device_syncs", "device_sync_ms", "mail_waits",
+                 "mail_wait_ms", "mail_wait_longest_ms", "mail_mode", "prepare_ms", "segment_wall_ms")
     c1 = {"workload": "640x480 bench generator, 32-slice window, spatial-only dense graph "
-                      "(DenseSegGraphInterface seam: add frames, SegmentFullGraph(983), ObtainResults + "
-                      "DetermineNeighborIds), frames resident in HBM",
+                      "(DenseSegGraphInterface seam: a fresh graph per window -- create, add frames, "
+                      "SegmentFullGraph(983), ObtainResults + DetermineNeighborIds, delete), frames "
+                      "resident in HBM; %d timed windows after the process's first window at this size" % reps,
           "value": cf / dt, "unit": "frames/s", "ms_per_window": dt * 1e3, "regions": nreg,
-          "phase_ms_per_window": {k: v / reps * 1e3 for k, v in phases.items()},
+          "window_ms": {"min": wms[0], "median": wms[len(wms) // 2], "max": wms[-1],
+                        "all": [round(w["ms"], 2) for w in windows]},
+          "phase_ms_per_window": {k: sum(w["phases"][k] for w in windows) / reps for k in phase_names},
+          "segment_diagnostics_mean": {k: sum(w["diag"][k] for w in windows) / reps for k in diag_keys},
+          "slowest_window": {"ms": slowest["ms"], "phases": slowest["phases"],
+                             "diag": {k: slowest["diag"][k] for k in diag_keys}},
+          "first_window": {"phases": first_phases, "diag": {k: first_diag[k] for k in diag_keys},
+                           "runtime_mallocs": mem1["runtime_mallocs"] - mem0["runtime_mallocs"],
+                           "runtime_malloc_ms": mem1["runtime_malloc_ms"] - mem0["runtime_malloc_ms"]},
+          "device_memory": {"runtime_mallocs_in_timed_windows": mem2["runtime_mallocs"] - mem1["runtime_mallocs"],
+                            "runtime_frees_in_timed_windows": mem2["runtime_frees"] - mem1["runtime_frees"],
+                            "cache_hits_in_timed_windows": mem2["cache_hits"] - mem1["cache_hits"],
+                            "bytes_cached": mem2["bytes_cached"], "cache_limit_bytes": mem2["limit_bytes"]},
           "roofline_note": "55 B/px/frame (SURVEY 8(d), spatial-only) -> %.2f GB/s" %
                            (cf / dt * cw * chh * 55.0 / 1e9)}
     if not args.no_cpu_baseline:
@@ -462,10 +506,14 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps, out):
     flow = torch.from_numpy(synth.const_flow(W, H)).to(dev)
     nfr = chunk + (chunk - 1) * 2
     wl = {"checker (headline input)": {"value": headline_fps, "unit": "frames/s"}}
-    for kind, label in (("blobs", "value noise: 48 px cells of random colour moving with the flow, +-3 noise"),
+    for kind, label in (("varflow", "the headline frames with a spatially varying backward flow (synth.var_flow: "
+                                    "rotation + zoom changing with the frame, cells moving on their own, "
+                                    "out-of-range bands)"),
+                        ("blobs", "value noise: 48 px cells of random colour moving with the flow, +-3 noise"),
                         ("noise", "gradient + independent +-40 noise per pixel and channel")):
-        fr = make_frames(kind, W, H, nfr, dev)
-        r = time_streams(vsg, fr, flow, W, H, chunk, 1, 1, 2, device_index)
+        fr = make_frames("bench" if kind == "varflow" else kind, W, H, nfr, dev)
+        wflow = [synth.flow_torch("var", W, H, k, dev) for k in range(nfr)] if kind == "varflow" else flow
+        r = time_streams(vsg, fr, wflow, W, H, chunk, 1, 1, 2, device_index)
         fps = r["frames"] / r["dt"]
         wl[kind] = {"input": label, "value": fps, "unit": "frames/s", "ms_per_step": r["dt"] / 2 * 1e3,
                     "merges_per_step": r["acc"]["merges"] / 2, "stage_ms_per_step": stage_ms(r["acc"], 2)}
@@ -484,8 +532,10 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps, out):
                                           has_flow=True)
                 same = True
                 for k in range(ns):
-                    no = st.process_frame(hf[k], flh if k > 0 else None, flush=(k == ns - 1))
-                    ng = g.process_frame(fr[k], flow if k > 0 else None, flush=(k == ns - 1))
+                    fh_k = (synth.var_flow(W, H, k) if kind == "varflow" else flh) if k > 0 else None
+                    fd_k = (wflow[k] if isinstance(wflow, list) else wflow) if k > 0 else None
+                    no = st.process_frame(hf[k], fh_k, flush=(k == ns - 1))
+                    ng = g.process_frame(fr[k], fd_k, flush=(k == ns - 1))
                     same = same and no == ng and all(g.result_bytes(i) == st.result_bytes(i) for i in range(no))
                 same = same and bool((g.last_merge_stats() == st.last_merge_stats()).all())
                 g.close()
@@ -495,7 +545,7 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps, out):
             wl[kind]["parity_checked"] = bool(same)
             wl[kind]["parity_sample"] = "first %d frames as one flushed chunk against oracle/libvs_oracle.so, %.1f s" % (
                 ns, time.perf_counter() - t0)
-        del fr
+        del fr, wflow
     out["workloads"] = wl
 
     # ---- the same video over two chunk engines on the one GPU (video_segment_amd/pipelined.py) ------
@@ -530,6 +580,9 @@ def extra_measurements(vsg, args, dev, device_index, headline_fps, out):
     import subprocess
     del flow
     torch.cuda.empty_cache()
+    # (the streams below are other PROCESSES on this GPU: what this process's closed handles left in
+    # the library's device cache goes back to the runtime first)
+    vsg.memory_trim(device_index)
 
     def sub_bench(extra):
         with socket.socket() as sk:
@@ -654,6 +707,7 @@ def main():
                             "value with two free host cores per GPU, per-rank values within a few per cent "
                             "of each other (DESIGN 7)"}
         result = {"dt": float(tt.item()), "frames": float(fo.item()), "acc": r["acc"],
+                  "step_ms": r["step_ms"],
                   "device_bytes_per_stream": r["device_bytes_per_stream"], "ranks": ranks_info,
                   "parallelism": "%d independent 1080p stream(s) per GPU x %d GPU(s)" % (S, world)}
         # PCIe-inclusive leg (rank 0, one stream, not `value`): the same steady-state chunks with
@@ -683,6 +737,33 @@ def main():
                                           "pageable host memory inside the timed region"}
             st_.close()
         del frames
+        # The other partition of SURVEY 8(e), on every N > 1 run: ONE video sharded chunk-wise over
+        # the ranks, the label-plane halo handed from rank to rank through the library's own
+        # ncclSend / ncclRecv (dense_segmentation.cpp:281-331 is the hand-off it replaces).  Two
+        # chunks per rank after one warm-up chunk per rank; information beside `value`, which stays
+        # the replicas number.
+        result["chain"] = None
+        if world > 1 and not args.no_chain_leg:
+            import copy
+            from video_segment_amd.multi_gpu import run_chain_bench
+            a2 = copy.copy(args)
+            a2.steps, a2.warmup = 2, 1
+            vsg.memory_trim(local_rank)
+            try:
+                rc = run_chain_bench(a2, rank, world, local_rank)
+                one = (result["frames"] / result["dt"]) / world
+                result["chain"] = {
+                    "value": rc["frames"] / rc["dt"], "unit": "frames/s (whole job, ONE video)",
+                    "chunks_per_rank": a2.steps, "ms_per_chunk": rc["dt"] / (a2.steps * world) * 1e3,
+                    "rccl_ranks": rc["handoff"]["rccl_ranks"], "transport": rc["handoff"]["transport"],
+                    "handoff_ms": rc["handoff"]["send_ms_per_chunk"],
+                    "recv_wait_ms": rc["handoff"]["recv_wait_ms_per_chunk"],
+                    "bytes_per_handoff": rc["handoff"]["bytes_per_handoff"],
+                    "vs_one_stream": (rc["frames"] / rc["dt"]) / one if one > 0 else None,
+                    "expected": "<= 1.15 x one stream whatever N: the merge of chunk c+1 needs the labels "
+                                "of chunk c, only graph construction and read-out overlap (DESIGN 7)"}
+            except Exception as e:   # noqa: BLE001 -- information only
+                result["chain"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         dt, frames_total, acc = result["dt"], result["frames"], result["acc"]
@@ -780,8 +861,11 @@ def main():
                            fps / world * px * BYTES_PER_PX_FRAME / 1e9),
             },
             "stage_ms_per_step": stage_ms(acc, K),
+            "step_ms_spread": result.get("step_ms"),
+            "diagnostics_per_step": {k_: acc[k_] / K for k_ in DIAG_KEYS if k_ in acc},
             "device_bytes_per_stream": result.get("device_bytes_per_stream"),
             "ranks": result.get("ranks"),
+            "chain": result.get("chain"),
             "edges_per_step": acc["edges_total"] / K,
             "merges_per_step": acc["merges"] / K,
         }

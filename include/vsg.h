@@ -91,6 +91,50 @@ typedef struct vsg_timings {
   int64_t spine_kernel_edges;  /* side clusters absorbed along the spines                    */
 } vsg_timings;
 
+/* Where the last SegmentFullGraph call of a handle spent its host time (diagnostics: a window that
+ * took ten times as long as its neighbours names its reason here).  Times are host wall-clock
+ * milliseconds of the calling thread. */
+typedef struct vsg_diagnostics {
+  double segment_wall_ms;        /* the whole call                                               */
+  double prepare_ms;             /* tables, scratch and pools before the first stage             */
+  double constrained_merge_ms;   /* MergeConstrainedRegions (segmentation_graph.h:703-786)       */
+  int64_t stages;                /* stages (filter -> components -> workers) the buckets took    */
+  int64_t optimistic_stages, rollbacks;
+  int64_t slab_growths;          /* the per-active-edge scratch had to grow inside a stage       */
+  double slab_growth_ms;
+  int64_t spine_pool_growths;    /* the scratch of the Kruskal-tree replay had to grow           */
+  double spine_pool_growth_ms;
+  int64_t runtime_mallocs;       /* hipMalloc / hipHostMalloc calls the call issued              */
+  double runtime_malloc_ms;
+  int64_t runtime_frees;         /* hipFree / hipHostFree calls                                  */
+  double runtime_free_ms;
+  int64_t cache_hits;            /* blocks adopted from the device cache instead                 */
+  int64_t device_syncs;          /* device-wide synchronisations for blocks going back to it     */
+  double device_sync_ms;
+  int64_t mail_waits;            /* scalars the host waited for (mailbox, device_graph.h)        */
+  double mail_wait_ms;           /* host time inside those waits (includes the kernels awaited)  */
+  double mail_wait_longest_ms;
+  int mail_mode;                 /* 0 spin, 1 yield, 2 sleep (VSG_MAIL_YIELD)                    */
+} vsg_diagnostics;
+
+/* Device memory of the library, per device.  A closed handle leaves its blocks in a process-wide
+ * cache and the next handle adopts them (no hipMalloc / hipFree after the first window of a caller
+ * that creates a graph per window, dense_seg_graph_interface.h:58-98); the cached, unused bytes are
+ * bounded (default 40 % of the device's memory; VSG_DEVICE_CACHE_MB, 0 = no cache). */
+typedef struct vsg_memory_stats {
+  int64_t bytes_in_use;       /* device blocks held by live handles                               */
+  int64_t bytes_in_use_peak;
+  int64_t bytes_cached;       /* device blocks waiting for the next handle                        */
+  int64_t limit_bytes;        /* bound of bytes_cached                                            */
+  int64_t runtime_mallocs, runtime_frees, cache_hits, device_syncs;   /* since process start      */
+  double runtime_malloc_ms, runtime_free_ms, device_sync_ms;
+} vsg_memory_stats;
+int vsg_device_memory_stats(int device, vsg_memory_stats* out);
+/* Returns every cached block of the device to the HIP runtime (live handles keep theirs). */
+int vsg_device_memory_trim(int device);
+/* Sets the bound of the cached bytes (0: handles release straight to the runtime; < 0: default). */
+int vsg_device_memory_limit(int device, int64_t bytes);
+
 const char* vsg_last_error(void);
 int vsg_version(void);
 void vsg_default_options(vsg_options* o);
@@ -130,6 +174,7 @@ int vsg_stream_result_bytes(vsg_stream* s, int i, const uint8_t** data, size_t* 
 int vsg_stream_result_id_image(vsg_stream* s, int i, int32_t* out);
 int vsg_stream_last_merge_stats(const vsg_stream* s, int64_t* forced_regular_small);
 int vsg_stream_last_timings(const vsg_stream* s, vsg_timings* t);
+int vsg_stream_last_diagnostics(const vsg_stream* s, vsg_diagnostics* d);
 /* Parity hook: smoothed feature planes of the most recently added frame, W*H*3 f32 BGR
  * interleaved, host memory (PreprocessFeatures output, cpp:164-198). */
 int vsg_stream_last_smoothed(vsg_stream* s, float* out);
@@ -294,6 +339,7 @@ int vsg_graph_temporal_buckets(vsg_graph* g, int t, uint16_t* out /* 9*W*H */, i
 int vsg_graph_node_roots(vsg_graph* g, int32_t* out);
 int vsg_graph_merge_stats(const vsg_graph* g, int64_t* forced_regular_small);
 int vsg_graph_timings(const vsg_graph* g, vsg_timings* t);
+int vsg_graph_diagnostics(const vsg_graph* g, vsg_diagnostics* d);
 
 #ifdef __cplusplus
 }

@@ -5,6 +5,9 @@
 * ``bench_frame``   -- the BASELINE/SURVEY 8(d) bench input: gradient + moving checker scaled
   with the frame width + additive +-3 PCG noise.
 * ``const_flow``    -- constant backward flow (-2, 0).
+* ``var_flow``      -- spatially varying backward flow: a rotation + zoom field around the frame
+  centre that changes with the frame, extra motion on a quarter of the checker cells, and two
+  bands of vectors that point far outside the frame (``flow_torch`` is its torch form).
 """
 import numpy as np
 
@@ -171,6 +174,67 @@ def const_flow(W, H, fx=-2.0, fy=0.0):
     f = np.empty((H, W, 2), np.float32)
     f[..., 0] = fx
     f[..., 1] = fy
+    return f
+
+
+def _var_flow_int(xp, x, y, W, H, t, hash_fn):
+    """The flow of var_flow in units of 1/64 px as two int64 arrays (same integer operations in
+    numpy and torch; every numerator is made non-negative before a division)."""
+    cx, cy = W // 2, H // 2
+    a = (t * 7) % 11 - 5          # zoom term of frame t, -5..5
+    b = (t * 5) % 13 - 6          # rotation term, -6..6
+    half = max(W // 2, 1)
+    big = 1 << 20                 # offset that keeps the numerators positive (|num| < 6 * 1.2 * 192 * W)
+    den = 5 * half
+    # rotation + zoom: up to about +-6 px in the frame corners, on top of the (-2, 0) of const_flow
+    fx = -128 + (a * (x - cx) * 192 - b * (y - cy) * 192 + big * den) // den - big
+    fy = (b * (x - cx) * 192 + a * (y - cy) * 192 + big * den) // den - big
+    # per-object motion: a quarter of the checker cells of bench_frame (as they lie in frame t) move
+    # by up to +-2 px on their own
+    cw = max(1, (16 * W) // 64)
+    ch = max(1, (12 * W) // 64)
+    cell = ((y // ch) * 4099 + (x + 2 * t) // cw) & 0xFFFFFFFF
+    hsh = hash_fn(cell)
+    moving = (hsh % 4) == 0
+    fx = fx + xp.where(moving, ((hsh >> 2) % 5 - 2) * 64, 0)
+    fy = fy + xp.where(moving, ((hsh >> 5) % 5 - 2) * 64, 0)
+    # out-of-range bands (the reference clamps the displaced position, dense_segmentation_graph.h:1126-1135):
+    # eight rows pointing 3 W to the right, eight columns pointing 3 H up
+    row_band = (y >= H // 3) & (y < H // 3 + 8)
+    col_band = (x >= (2 * W) // 3) & (x < (2 * W) // 3 + 8)
+    fx = xp.where(row_band, 3 * W * 64, fx)
+    fy = xp.where(col_band & ~row_band, -3 * H * 64, fy)
+    return fx, fy
+
+
+def var_flow(W, H, t):
+    """Deterministic spatially varying backward flow of frame t (H x W x 2 f32, multiples of 1/64):
+    smooth rotation / zoom field + per-object motion + a band of out-of-range vectors."""
+    x = np.broadcast_to(np.arange(W, dtype=np.int64)[None, :], (H, W))
+    y = np.broadcast_to(np.arange(H, dtype=np.int64)[:, None], (H, W))
+    fx, fy = _var_flow_int(np, x, y, W, H, t, lambda v: _pcg_hash(v.astype(np.uint32)).astype(np.int64))
+    f = np.empty((H, W, 2), np.float32)
+    f[..., 0] = fx.astype(np.float32) * np.float32(1.0 / 64.0)
+    f[..., 1] = fy.astype(np.float32) * np.float32(1.0 / 64.0)
+    return f
+
+
+def flow_torch(kind, W, H, t, device):
+    """const_flow / var_flow generated on `device` (bit-identical to the numpy forms, tests/test_synth.py)."""
+    import torch
+    if kind == "const":
+        f = torch.empty((H, W, 2), dtype=torch.float32, device=device)
+        f[..., 0] = -2.0
+        f[..., 1] = 0.0
+        return f
+    if kind != "var":
+        raise ValueError(kind)
+    x = torch.arange(W, dtype=torch.int64, device=device)[None, :].expand(H, W)
+    y = torch.arange(H, dtype=torch.int64, device=device)[:, None].expand(H, W)
+    fx, fy = _var_flow_int(torch, x, y, W, H, t, _pcg_hash_t)
+    f = torch.empty((H, W, 2), dtype=torch.float32, device=device)
+    f[..., 0] = fx.to(torch.float32) * (1.0 / 64.0)
+    f[..., 1] = fy.to(torch.float32) * (1.0 / 64.0)
     return f
 
 

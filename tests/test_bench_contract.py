@@ -53,7 +53,7 @@ def test_two_ranks_control_flow(mode, port):
            "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "256", "--height", "144",
            "--mode", mode, "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT, env=env)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=360, cwd=ROOT, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     out = last_json_line(p.stdout)
     check(out, 2, 2, 1)
@@ -67,6 +67,14 @@ def test_two_ranks_control_flow(mode, port):
         assert rk["world_size"] == 2 and rk["allreduce_sum_of_ones"] == 2.0 and rk["backend"] == "gloo"
         assert len(rk["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in rk["per_rank_frames_per_s"])
         assert out["value"] <= sum(rk["per_rank_frames_per_s"]) * (1 + 1e-9)   # MAX over ranks of the time
+        # ... and carries the other partition of SURVEY 8(e) as well: a short chunk-chain leg (ONE
+        # video over the ranks, the halo handed on through the transport: RCCL inside the library
+        # on a multi-GPU node, torch.distributed/gloo in this one-GPU control-flow test)
+        ch = out["chain"]
+        assert "error" not in ch, ch
+        assert ch["value"] > 0 and ch["chunks_per_rank"] == 2 and ch["rccl_ranks"] == 0
+        assert ch["handoff_ms"] >= 0 and ch["recv_wait_ms"] >= 0 and ch["bytes_per_handoff"] == 2 * 256 * 144 * 4 + 32
+        assert "expected" in ch and ch["vs_one_stream"] > 0
 
 
 def test_committed_round_line_carries_every_key():

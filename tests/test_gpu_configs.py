@@ -31,11 +31,12 @@ def vsg():
     return v
 
 
-def _stream_both(vsg, W, H, N, chunk, frame_fn, flow, pad_to=None, flush_last=True, threads=1):
+def _stream_both(vsg, W, H, N, chunk, frame_fn, flow, pad_to=None, flush_last=True, threads=1, flow_fn=None):
     """Feeds the same frames to the HIP stream and the oracle; returns the number of compared
     messages.  pad_to: row stride in bytes of the frame buffer handed to both; flush_last=False:
     the stream just ends after a chunk boundary (the last chunk compared is a steady-state one);
-    threads: the oracle's graph construction threads (its results do not depend on them)."""
+    threads: the oracle's graph construction threads (its results do not depend on them);
+    flow_fn(W, H, k): the backward flow of frame k (default: the constant flow)."""
     ol.set_threads(threads)
     try:
         g = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=flow)
@@ -49,6 +50,8 @@ def _stream_both(vsg, W, H, N, chunk, frame_fn, flow, pad_to=None, flush_last=Tr
                 buf[:, :W * 3] = frame.reshape(H, W * 3)
                 frame = np.lib.stride_tricks.as_strided(buf, (H, W, 3), (pad_to, 3, 1))
             f = fl if (flow and k > 0) else None
+            if f is not None and flow_fn is not None:
+                f = flow_fn(W, H, k)
             last = flush_last and k == N - 1
             ng = g.process_frame(frame, f, flush=last)
             no = o.process_frame(frame, f, flush=last)
@@ -84,6 +87,16 @@ def test_bench_reported_inputs_1080p_vs_oracle(vsg, kind):
         return synth.frame_torch(kind, W, H, k, dev).cpu().numpy()   # tests/test_synth.py holds them equal)
 
     assert _stream_both(vsg, 1920, 1080, 39, 20, frame, True, flush_last=False, threads=8) == 38
+
+
+def test_varying_flow_1080p_vs_oracle(vsg):
+    """A spatially varying backward flow at full size (synth.var_flow: rotation + zoom that changes
+    with the frame, cells that move on their own, bands of vectors far out of range): the
+    flow-displaced gather of the temporal edges (dense_segmentation_graph.h:1100-1142) is no longer a
+    shifted copy and FindPreviousTube (:601-629) samples a different vector for every tube.  First
+    chunk and one steady-state constrained chunk, byte for byte."""
+    assert _stream_both(vsg, 1920, 1080, 39, 20, synth.bench_frame, True, flush_last=False, threads=8,
+                        flow_fn=synth.var_flow) == 38
 
 
 def test_constrained_chunk_2560x1440_vs_oracle(vsg):

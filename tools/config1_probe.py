@@ -27,8 +27,9 @@ def run_graph():
     g.obtain_results(use_flows=False)
     n = g.num_regions()
     t2 = time.perf_counter()
+    d = g.diagnostics()
     g.close()
-    return n, (t1 - t0) * 1e3, (t2 - t1) * 1e3
+    return n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, d
 
 
 if "--after-stream" in sys.argv:   # the state bench.py's leg runs in: a 1080p stream has come and gone
@@ -42,9 +43,25 @@ if "--after-stream" in sys.argv:   # the state bench.py's leg runs in: a 1080p s
     del fr, st
     print("(after a 1080p stream of three chunks)")
 
-for rep in range(4):
+reps = 10
+for a in sys.argv[1:]:
+    if a.startswith("--reps="):
+        reps = int(a.split("=")[1])
+all_ms = []
+for rep in range(reps):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n, seg_ms, ro_ms = run_graph()
+    n, seg_ms, ro_ms, d = run_graph()
     torch.cuda.synchronize()
-    print("window %d: %.1f ms (segment %.1f, read-out %.1f), %d regions" % (rep, (time.perf_counter() - t0) * 1e3, seg_ms, ro_ms, n))
+    ms = (time.perf_counter() - t0) * 1e3
+    all_ms.append(ms)
+    print("window %d: %.1f ms (segment %.1f, read-out %.1f), %d regions | stages %d, slab growths %d (%.1f ms), "
+          "spine growths %d (%.1f ms), hipMalloc %d (%.1f ms), hipFree %d (%.1f ms), cache hits %d, device syncs %d "
+          "(%.2f ms), mail waits %d (%.1f ms, longest %.2f), mode %d" % (
+              rep, ms, seg_ms, ro_ms, n, d["stages"], d["slab_growths"], d["slab_growth_ms"],
+              d["spine_pool_growths"], d["spine_pool_growth_ms"], d["runtime_mallocs"], d["runtime_malloc_ms"],
+              d["runtime_frees"], d["runtime_free_ms"], d["cache_hits"], d["device_syncs"], d["device_sync_ms"],
+              d["mail_waits"], d["mail_wait_ms"], d["mail_wait_longest_ms"], d["mail_mode"]))
+s_ = sorted(all_ms[1:])
+print("windows 1..%d: min %.1f median %.1f max %.1f ms -> %.0f frames/s at the median; memory %s" % (
+    reps - 1, s_[0], s_[len(s_) // 2], s_[-1], cf / (s_[len(s_) // 2] * 1e-3), vsg.memory_stats(0)))

@@ -3,4 +3,5 @@ DenseSegmentationUnit hot path).  See DESIGN.md and include/vsg.h."""
 from .dense_segmentation import ChunkChain, DenseSegGraph, DenseSegmentation, default_options  # noqa: F401
 from .pipelined import PipelinedDenseSegmentation  # noqa: F401
 from .region_segmentation import RegionSegmentation, bgr_to_lab, default_region_options  # noqa: F401
-from ._lib import VsgError, VsgOptions, VsgRegionOptions, VsgTimings  # noqa: F401
+from ._lib import (VsgDiagnostics, VsgError, VsgMemoryStats, VsgOptions, VsgRegionOptions, VsgTimings,  # noqa: F401
+                   memory_limit, memory_stats, memory_trim)

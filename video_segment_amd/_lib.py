@@ -58,6 +58,36 @@ class VsgTimings(C.Structure):
     ]
 
 
+class VsgDiagnostics(C.Structure):
+    _fields_ = [
+        ("segment_wall_ms", C.c_double), ("prepare_ms", C.c_double), ("constrained_merge_ms", C.c_double),
+        ("stages", C.c_int64), ("optimistic_stages", C.c_int64), ("rollbacks", C.c_int64),
+        ("slab_growths", C.c_int64), ("slab_growth_ms", C.c_double),
+        ("spine_pool_growths", C.c_int64), ("spine_pool_growth_ms", C.c_double),
+        ("runtime_mallocs", C.c_int64), ("runtime_malloc_ms", C.c_double),
+        ("runtime_frees", C.c_int64), ("runtime_free_ms", C.c_double),
+        ("cache_hits", C.c_int64), ("device_syncs", C.c_int64), ("device_sync_ms", C.c_double),
+        ("mail_waits", C.c_int64), ("mail_wait_ms", C.c_double), ("mail_wait_longest_ms", C.c_double),
+        ("mail_mode", C.c_int),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class VsgMemoryStats(C.Structure):
+    _fields_ = [
+        ("bytes_in_use", C.c_int64), ("bytes_in_use_peak", C.c_int64), ("bytes_cached", C.c_int64),
+        ("limit_bytes", C.c_int64),
+        ("runtime_mallocs", C.c_int64), ("runtime_frees", C.c_int64), ("cache_hits", C.c_int64),
+        ("device_syncs", C.c_int64),
+        ("runtime_malloc_ms", C.c_double), ("runtime_free_ms", C.c_double), ("device_sync_ms", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class VsgRegionOptions(C.Structure):
     _fields_ = [
         ("min_region_num", C.c_int), ("max_region_num", C.c_int),
@@ -72,10 +102,11 @@ class VsgRegionOptions(C.Structure):
 # Every symbol include/vsg.h declares (checked by tests/test_capi_symbols.py).
 EXPORTED_SYMBOLS = [
     "vsg_last_error", "vsg_version", "vsg_default_options", "vsg_device_count",
+    "vsg_device_memory_stats", "vsg_device_memory_trim", "vsg_device_memory_limit",
     "vsg_vectorize_id_image",
     "vsg_stream_create", "vsg_stream_destroy", "vsg_stream_process_frame", "vsg_stream_chunk_size",
     "vsg_stream_result_bytes", "vsg_stream_result_id_image", "vsg_stream_last_merge_stats",
-    "vsg_stream_last_timings", "vsg_stream_last_smoothed", "vsg_stream_export_halo",
+    "vsg_stream_last_timings", "vsg_stream_last_diagnostics", "vsg_stream_last_smoothed", "vsg_stream_export_halo",
     "vsg_stream_import_halo", "vsg_stream_expect_halo", "vsg_stream_restart",
     "vsg_chain_create", "vsg_chain_destroy", "vsg_chain_info", "vsg_chain_send_halo",
     "vsg_chain_recv_halo", "vsg_chain_exchange_halo",
@@ -88,7 +119,7 @@ EXPORTED_SYMBOLS = [
     "vsg_graph_region_sizes", "vsg_graph_index_image", "vsg_graph_get_regions",
     "vsg_graph_get_intervals", "vsg_graph_smoothed",
     "vsg_graph_spatial_buckets", "vsg_graph_temporal_buckets", "vsg_graph_node_roots",
-    "vsg_graph_merge_stats", "vsg_graph_timings",
+    "vsg_graph_merge_stats", "vsg_graph_timings", "vsg_graph_diagnostics",
 ]
 
 
@@ -126,6 +157,9 @@ def lib():
     L.vsg_version.restype = C.c_int
     L.vsg_default_options.argtypes = [C.POINTER(VsgOptions)]
     L.vsg_device_count.restype = C.c_int
+    L.vsg_device_memory_stats.argtypes = [C.c_int, C.POINTER(VsgMemoryStats)]
+    L.vsg_device_memory_trim.argtypes = [C.c_int]
+    L.vsg_device_memory_limit.argtypes = [C.c_int, C.c_int64]
     L.vsg_vectorize_id_image.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.vsg_stream_create.argtypes = [C.POINTER(VsgOptions), C.c_int, C.c_int, C.POINTER(vp)]
     L.vsg_stream_destroy.argtypes = [vp]
@@ -136,6 +170,7 @@ def lib():
     L.vsg_stream_result_id_image.argtypes = [vp, C.c_int, vp]
     L.vsg_stream_last_merge_stats.argtypes = [vp, vp]
     L.vsg_stream_last_timings.argtypes = [vp, C.POINTER(VsgTimings)]
+    L.vsg_stream_last_diagnostics.argtypes = [vp, C.POINTER(VsgDiagnostics)]
     L.vsg_stream_last_smoothed.argtypes = [vp, vp]
     L.vsg_stream_export_halo.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), vp]
     L.vsg_stream_import_halo.argtypes = [vp, vp, vp, C.c_int, vp]
@@ -178,6 +213,7 @@ def lib():
     L.vsg_graph_node_roots.argtypes = [vp, vp]
     L.vsg_graph_merge_stats.argtypes = [vp, vp]
     L.vsg_graph_timings.argtypes = [vp, C.POINTER(VsgTimings)]
+    L.vsg_graph_diagnostics.argtypes = [vp, C.POINTER(VsgDiagnostics)]
     _lib = L
     return L
 
@@ -188,6 +224,22 @@ class VsgError(RuntimeError):
     def __init__(self, msg, code=None):
         super().__init__(msg)
         self.code = code
+
+
+def memory_stats(device=-1):
+    """vsg_device_memory_stats as a dict (bytes held by live handles, bytes cached for the next one,
+    hipMalloc / hipFree calls the library issued so far)."""
+    st = VsgMemoryStats()
+    check(lib().vsg_device_memory_stats(device, C.byref(st)))
+    return st.as_dict()
+
+
+def memory_trim(device=-1):
+    check(lib().vsg_device_memory_trim(device))
+
+
+def memory_limit(nbytes, device=-1):
+    check(lib().vsg_device_memory_limit(device, int(nbytes)))
 
 
 def check(rc):

@@ -116,9 +116,69 @@ struct vsg_graph {
   }
 };
 
+static void FillDiagnostics(const vsg::GraphTimings& gt, vsg_diagnostics* d) {
+  std::memset(d, 0, sizeof(*d));
+  d->segment_wall_ms = gt.segment_wall_ms;
+  d->prepare_ms = gt.prepare_ms;
+  d->constrained_merge_ms = gt.constrained_merge_ms;
+  d->stages = gt.stages;
+  d->optimistic_stages = gt.optimistic_stages;
+  d->rollbacks = gt.rollbacks;
+  d->slab_growths = gt.slab_growths;
+  d->slab_growth_ms = gt.slab_growth_ms;
+  d->spine_pool_growths = gt.spine_growths;
+  d->spine_pool_growth_ms = gt.spine_growth_ms;
+  d->runtime_mallocs = gt.runtime_mallocs;
+  d->runtime_malloc_ms = gt.runtime_malloc_ms;
+  d->runtime_frees = gt.runtime_frees;
+  d->runtime_free_ms = gt.runtime_free_ms;
+  d->cache_hits = gt.cache_hits;
+  d->device_syncs = gt.device_syncs;
+  d->device_sync_ms = gt.device_sync_ms;
+  d->mail_waits = gt.mail_waits;
+  d->mail_wait_ms = gt.mail_wait_ms;
+  d->mail_wait_longest_ms = gt.mail_wait_longest_ms;
+  d->mail_mode = gt.mail_mode;
+}
+
 extern "C" {
 
 const char* vsg_last_error(void) { return g_last_error.c_str(); }
+
+int vsg_device_memory_stats(int device, vsg_memory_stats* out) {
+  return Guard([&] {
+    VSG_REQUIRE(out, VSG_ERR_INVALID, "null argument");
+    const int dev = ResolveDevice(device);
+    const vsg::CacheStats s = vsg::CacheGetStats(dev);
+    out->bytes_in_use = s.bytes_in_use;
+    out->bytes_in_use_peak = s.bytes_in_use_peak;
+    out->bytes_cached = s.bytes_cached;
+    out->limit_bytes = s.limit_bytes;
+    out->runtime_mallocs = s.runtime_mallocs;
+    out->runtime_frees = s.runtime_frees;
+    out->cache_hits = s.cache_hits;
+    out->device_syncs = s.device_syncs;
+    out->runtime_malloc_ms = s.runtime_malloc_ms;
+    out->runtime_free_ms = s.runtime_free_ms;
+    out->device_sync_ms = s.device_sync_ms;
+  });
+}
+
+int vsg_device_memory_trim(int device) {
+  return Guard([&] {
+    const int dev = ResolveDevice(device);
+    DeviceGuard dg(dev);
+    vsg::CacheTrim(dev);
+  });
+}
+
+int vsg_device_memory_limit(int device, int64_t bytes) {
+  return Guard([&] {
+    const int dev = ResolveDevice(device);
+    DeviceGuard dg(dev);
+    vsg::CacheSetLimit(dev, (long long)bytes);
+  });
+}
 int vsg_version(void) { return 100; }
 
 void vsg_default_options(vsg_options* o) {
@@ -252,6 +312,13 @@ int vsg_stream_last_timings(const vsg_stream* s, vsg_timings* t) {
     VSG_REQUIRE(s && t, VSG_ERR_INVALID, "null argument");
     DeviceGuard dg(s->device);
     *t = s->impl->last_timings();
+  });
+}
+
+int vsg_stream_last_diagnostics(const vsg_stream* s, vsg_diagnostics* d) {
+  return Guard([&] {
+    VSG_REQUIRE(s && d, VSG_ERR_INVALID, "null argument");
+    FillDiagnostics(s->impl->last_graph_timings(), d);
   });
 }
 
@@ -594,6 +661,8 @@ void vsg_graph_destroy(vsg_graph* g) {
   (void)Guard([&] {
     DeviceGuard dg(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
+    vsg::QuiesceGuard quiesce;   // one device synchronisation for everything released below
+    quiesce.Begin();
     g->g.reset();
     g->pre.reset();
     g->feats.clear();
@@ -904,6 +973,13 @@ int vsg_graph_timings(const vsg_graph* g, vsg_timings* t) {
     t->spine_kernel_ms = gt.spine_ms;
     t->spine_kernel_launches = gt.spine_launches;
     t->spine_kernel_edges = gt.spine_edges;
+  });
+}
+
+int vsg_graph_diagnostics(const vsg_graph* g, vsg_diagnostics* d) {
+  return Guard([&] {
+    VSG_REQUIRE(g && d, VSG_ERR_INVALID, "null argument");
+    FillDiagnostics(g->g->timings(), d);
   });
 }
 

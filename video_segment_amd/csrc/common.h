@@ -16,6 +16,8 @@
 #include <string>
 #include <vector>
 
+#include "device_cache.h"
+
 namespace vsg {
 
 struct Error : std::runtime_error {
@@ -39,7 +41,8 @@ struct Error : std::runtime_error {
     if (!(cond)) ::vsg::Throw((code), std::string(msg) + " [" #cond "]");                \
   } while (0)
 
-// Simple owning device buffer.
+// Simple owning device buffer.  The block comes from / goes back to the process-wide cache
+// (device_cache.h): a closed handle's memory is adopted by the next one instead of being unmapped.
 template <class T>
 class DevBuf {
  public:
@@ -62,16 +65,16 @@ class DevBuf {
   void alloc(size_t n) {
     release();
     if (n == 0) return;
-    VSG_HIP(hipMalloc(reinterpret_cast<void**>(&p_), n * sizeof(T)));
+    p_ = static_cast<T*>(CacheAlloc(n * sizeof(T), kCacheDevice));
     n_ = n;
   }
   // Grows with slack: sizes that drift from chunk to chunk (intervals, pairs, runs) must not cost
-  // a hipFree + hipMalloc -- both synchronise the whole device -- every time they tick up.
+  // a new block -- and a device synchronisation for the old one -- every time they tick up.
   void ensure(size_t n) {
     if (n > n_) alloc(n + n / 8 + 256);
   }
   void release() {
-    if (p_) (void)hipFree(p_);
+    if (p_) CacheFree(p_);
     p_ = nullptr;
     n_ = 0;
   }
@@ -95,11 +98,11 @@ class PinnedBuf {
     if (n <= n_) return;
     release();
     n = n + n / 4 + 256;   // (with slack: sizes that drift from chunk to chunk)
-    VSG_HIP(hipHostMalloc(reinterpret_cast<void**>(&p_), n * sizeof(T), hipHostMallocDefault));
+    p_ = static_cast<T*>(CacheAlloc(n * sizeof(T), kCachePinned));
     n_ = n;
   }
   void release() {
-    if (p_) (void)hipHostFree(p_);
+    if (p_) CacheFree(p_);
     p_ = nullptr;
     n_ = 0;
   }

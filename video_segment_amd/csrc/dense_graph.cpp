@@ -74,7 +74,7 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
     const int slots = 256;
     const size_t list_cap = 8192;
     const size_t bytes = (size_t)slots * kMailValues * sizeof(unsigned long long) + list_cap * sizeof(int32_t);
-    VSG_HIP(hipHostMalloc(&mail_mem_, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    mail_mem_ = CacheAlloc(bytes, kCacheMappedCoherent);
     std::memset(mail_mem_, 0, bytes);
     void* dev = nullptr;
     VSG_HIP(hipHostGetDevicePointer(&dev, mail_mem_, 0));
@@ -104,13 +104,16 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
 }
 
 DenseGraphHip::~DenseGraphHip() {
+  // (the owner has synchronised the handle's stream; one device synchronisation here instead of one
+  // per buffer that goes back to the cache)
+  quiesce_.Begin();
   MailRegisterGraph(-1);
   for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
   if (aux_fork_) (void)hipEventDestroy(aux_fork_);
   if (aux_join_) (void)hipEventDestroy(aux_join_);
   if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
   if (aux2_stream_) (void)hipStreamDestroy(aux2_stream_);
-  if (mail_mem_) (void)hipHostFree(mail_mem_);
+  if (mail_mem_) CacheFree(mail_mem_);
 }
 
 void DenseGraphHip::Reset(int max_frames) {
@@ -255,6 +258,10 @@ void DenseGraphHip::EnsureActiveScratch(size_t n) {
                o_s_idx = carve(n, 4), o_seg_key = carve(n, 4), o_seg_cnt = carve(n, 4), o_seg_off = carve(n, 4),
                o_lead_pos = carve(n, 4), o_l_ra = carve(n, 4), o_l_rb = carve(n, 4), o_l_gpos = carve(n, 4),
                o_bk_ds = carve(2 * n, sizeof(float4)), o_bk_cons = carve(2 * n, 4), o_bk_flags = carve(2 * n, 1);
+  // (an allocation that throws must not leave the old pointers behind: the slab they point into is
+  // released first, and a later call would return early on the old capacity and bind them)
+  scratch_active_ = 0;
+  act_ = ActiveArrays();
   active_slab_.alloc(bytes);
   uint8_t* b = active_slab_.get();
   act_.e_active = reinterpret_cast<int32_t*>(b + o_e_active);
@@ -344,6 +351,12 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   min_region_size_ = min_region_size;
   const int L = (int)lists_.size();
   const size_t N = wh_ * (size_t)num_frames_;
+  const double t_enter = NowMs();
+  const ThreadAllocCounters alloc0 = ThreadAllocSnapshot();
+  MailWaitResetLongest();
+  const MailWaitCounters mail0 = MailWaitSnapshot();
+  int64_t diag_stages = 0, diag_slab_growths = 0, diag_spine_growths = 0;
+  double diag_slab_ms = 0, diag_spine_ms = 0;
 
   // List table.
   std::vector<ListDesc> desc(L);
@@ -465,7 +478,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     S.active_cap = (int)std::min<size_t>(scratch_active_, 0x7fffffff);
   };
   bind_scratch();
-  S.grow_active = [this, bind_scratch](long long need) {
+  S.grow_active = [this, bind_scratch, &diag_slab_growths, &diag_slab_ms](long long need) {
     // (nothing of the stage is in the active arrays yet: RunBucketStage asks before it uses them)
     const double tg0 = NowMs();
     VSG_HIP(hipStreamSynchronize(stream_));
@@ -474,6 +487,8 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     const size_t before = scratch_active_;
     EnsureActiveScratch((size_t)need);
     bind_scratch();
+    ++diag_slab_growths;
+    diag_slab_ms += NowMs() - tg0;
     if (getenv("VSG_DEBUG_STATS")) {
       std::fprintf(stderr, "[vsg] stage scratch: %zu -> %zu active edges (needed %lld), %.2f ms\n", before,
                    scratch_active_, need, NowMs() - tg0);
@@ -538,7 +553,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   }
   S.spine_pool = spine_pool_.get();
   S.spine_pool_ints = spine_pool_.size();
-  S.grow_spine_pool = [this, &S](long long edges) {
+  S.grow_spine_pool = [this, &S, &diag_spine_growths, &diag_spine_ms](long long edges) {
     // up to what the rank stamps of the spanning forest address (2^27 edges, merge_spine.hip)
     if (getenv("VSG_SPINE_MAX_EDGES") || edges >= (120ll << 20)) return false;
     const long long want = std::min<long long>(edges + edges / 8, 120ll << 20);
@@ -549,13 +564,23 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     const long long nodes = (long long)wh_ * (long long)std::max(capacity_frames_, 1);
     const size_t ints = SpinePoolInts((size_t)want) + (size_t)(29 * std::min(want, nodes));
     if (ints <= spine_pool_.size()) return false;
+    const double tg0 = NowMs();
     size_t free_b = 0, total_b = 0;
     VSG_HIP(hipMemGetInfo(&free_b, &total_b));
-    if (free_b + spine_pool_.size() * sizeof(int32_t) < 2 * ints * sizeof(int32_t)) return false;
+    if (free_b + spine_pool_.size() * sizeof(int32_t) < 2 * ints * sizeof(int32_t)) {
+      // (what closed handles left in the cache counts as free: give it back and look again)
+      int dev = 0;
+      VSG_HIP(hipGetDevice(&dev));
+      CacheTrim(dev);
+      VSG_HIP(hipMemGetInfo(&free_b, &total_b));
+      if (free_b + spine_pool_.size() * sizeof(int32_t) < 2 * ints * sizeof(int32_t)) return false;
+    }
     VSG_HIP(hipStreamSynchronize(stream_));
     VSG_HIP(hipStreamSynchronize(aux_stream_));
     VSG_HIP(hipStreamSynchronize(aux2_stream_));
     spine_pool_.alloc(ints);
+    ++diag_spine_growths;
+    diag_spine_ms += NowMs() - tg0;
     S.spine_pool = spine_pool_.get();
     S.spine_pool_ints = spine_pool_.size();
     S.spine_max_edges = (int)want;
@@ -717,6 +742,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     auto run = [&](int w, int j0, int n, int measure, bool limited) {
       StageInfo info;
       info.want_components = debug_stages ? 2 : measure;
+      ++diag_stages;
       RunStageDebug(b, w, windows, j0, n, P, inert_mode, S, debug_stages, &info);
       group_active += info.replayed;
       if (debug_stages && info.want_components && wave_target_active_ != kNoWindowTarget) {
@@ -865,6 +891,29 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   timings_.merges[0] += (int64_t)st[0];
   timings_.merges[1] += (int64_t)st[1];
   timings_.merges[2] += (int64_t)st[2];
+  {
+    const ThreadAllocCounters a1 = ThreadAllocSnapshot();
+    const MailWaitCounters m1 = MailWaitSnapshot();
+    timings_.stages = diag_stages;
+    timings_.slab_growths = diag_slab_growths;
+    timings_.slab_growth_ms = diag_slab_ms;
+    timings_.spine_growths = diag_spine_growths;
+    timings_.spine_growth_ms = diag_spine_ms;
+    timings_.runtime_mallocs = a1.runtime_mallocs - alloc0.runtime_mallocs;
+    timings_.runtime_malloc_ms = a1.runtime_malloc_ms - alloc0.runtime_malloc_ms;
+    timings_.runtime_frees = a1.runtime_frees - alloc0.runtime_frees;
+    timings_.runtime_free_ms = a1.runtime_free_ms - alloc0.runtime_free_ms;
+    timings_.cache_hits = a1.cache_hits - alloc0.cache_hits;
+    timings_.device_syncs = a1.device_syncs - alloc0.device_syncs;
+    timings_.device_sync_ms = a1.device_sync_ms - alloc0.device_sync_ms;
+    timings_.mail_waits = m1.waits - mail0.waits;
+    timings_.mail_wait_ms = m1.wait_ms - mail0.wait_ms;
+    timings_.mail_wait_longest_ms = m1.longest_ms;
+    timings_.mail_mode = MailYieldMode();
+    timings_.prepare_ms = t0 - t_enter;
+    timings_.constrained_merge_ms = t_mc - t_buckets;
+    timings_.segment_wall_ms = NowMs() - t_enter;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

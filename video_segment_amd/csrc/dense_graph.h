@@ -20,6 +20,17 @@ struct GraphTimings {
   float wave_ms = 0, filter_ms = 0, spine_ms = 0;
   int64_t wave_launches = 0, filter_launches = 0, wave_edges = 0, spine_launches = 0, spine_edges = 0;
   int64_t optimistic_stages = 0, rollbacks = 0;
+  // Diagnostics of the last Segment call (vsg_diagnostics, include/vsg.h): what a window that took
+  // ten times as long as its neighbours spent its time on.
+  int64_t stages = 0;
+  int64_t slab_growths = 0, spine_growths = 0;
+  double slab_growth_ms = 0, spine_growth_ms = 0;
+  int64_t runtime_mallocs = 0, runtime_frees = 0, cache_hits = 0, device_syncs = 0;
+  double runtime_malloc_ms = 0, runtime_free_ms = 0, device_sync_ms = 0;
+  int64_t mail_waits = 0;
+  double mail_wait_ms = 0, mail_wait_longest_ms = 0;
+  int mail_mode = 0;
+  double segment_wall_ms = 0, prepare_ms = 0, constrained_merge_ms = 0;
 };
 
 class DenseGraphHip {
@@ -104,6 +115,7 @@ class DenseGraphHip {
     return NodeArrays{parent_.get(), desc_sz_.get(), cons_.get(), flags_.get()};
   }
 
+  QuiesceGuard quiesce_;   // first member: spans the release of every buffer below (device_cache.h)
   int W_, H_, capacity_frames_, max_frames_;
   bool l1_;
   hipStream_t stream_;

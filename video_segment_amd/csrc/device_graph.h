@@ -144,6 +144,13 @@ void MailWait(const MailSlot& slot, int count, int* values, hipStream_t s);
 // with more streams than cores stops spinning by itself.
 void MailRegisterGraph(int delta);
 int MailYieldMode();
+// What the calling thread spent in MailWait so far (diagnostics: the difference around a call).
+struct MailWaitCounters {
+  long long waits = 0;
+  double wait_ms = 0, longest_ms = 0;
+};
+MailWaitCounters MailWaitSnapshot();
+void MailWaitResetLongest();
 // Posts up to four device scalars from a one-thread kernel (where no kernel of the algorithm is at
 // hand to do it): values[i] = *ptrs[i].
 void LaunchMailPost(const MailSlot& slot, const int32_t* p0, const int32_t* p1, const int32_t* p2,

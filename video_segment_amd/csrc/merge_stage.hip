@@ -112,8 +112,25 @@ int MailYieldMode() {
   return 2 * g_live_graphs.load(std::memory_order_relaxed) > UsableCores() ? 1 : 0;
 }
 
+static thread_local MailWaitCounters t_mail_counters;
+MailWaitCounters MailWaitSnapshot() { return t_mail_counters; }
+void MailWaitResetLongest() { t_mail_counters.longest_ms = 0; }
+
+namespace {
+struct MailWaitTimer {   // host time of one MailWait call, whichever way it ends
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  ~MailWaitTimer() {
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    t_mail_counters.waits += 1;
+    t_mail_counters.wait_ms += ms;
+    if (ms > t_mail_counters.longest_ms) t_mail_counters.longest_ms = ms;
+  }
+};
+}  // namespace
+
 void MailWait(const MailSlot& slot, int count, int* values, hipStream_t s) {
   using clk = std::chrono::steady_clock;
+  MailWaitTimer wait_timer;
   clk::time_point t0;
   bool timed = false;
   const int mode = MailYieldMode();

@@ -135,6 +135,7 @@ DenseSegmentationHip::DenseSegmentationHip(const vsg_options& o, int W, int H)
 }
 
 DenseSegmentationHip::~DenseSegmentationHip() {
+  quiesce_.Begin();   // one device synchronisation for all the buffers released below
   if (stream_) {
     (void)hipStreamSynchronize(stream_);
     graph_.reset();
@@ -144,7 +145,7 @@ DenseSegmentationHip::~DenseSegmentationHip() {
     planes_.reset();
     (void)hipStreamDestroy(stream_);
   }
-  if (halo_ids_host_) (void)hipHostFree(halo_ids_host_);
+  if (halo_ids_host_) CacheFree(halo_ids_host_);
 }
 
 // dense_segmentation.cpp:268-279: float product truncated to int.
@@ -270,7 +271,7 @@ void DenseSegmentationHip::ChunkBoundaryOutput(bool flush) {
   // Render the two overlap segmentations to id images (SegmentationDescToIdImage): both at once,
   // into pinned memory (a pageable source made the two 8 MB copies 1.5 ms per chunk).
   if (!halo_ids_host_) {
-    VSG_HIP(hipHostMalloc(reinterpret_cast<void**>(&halo_ids_host_), 2 * wh_ * sizeof(int32_t), hipHostMallocDefault));
+    halo_ids_host_ = static_cast<int32_t*>(CacheAlloc(2 * wh_ * sizeof(int32_t), kCachePinned));
   }
   {
     auto render = [&](int k) {
@@ -442,6 +443,7 @@ void DenseSegmentationHip::SegmentAndOutputChunk(bool flush) {
   last_timings_.edges_ms = accum_.edges_ms;
   last_timings_.preprocess_launches = accum_.preprocess_launches;
   last_timings_.edge_launches = accum_.edge_launches;
+  last_graph_timings_ = gt;
   last_timings_.merge_ms = gt.merge_ms;
   last_timings_.readout_ms = gt.readout_ms;
   last_timings_.host_post_ms = gt.host_post_ms + (float)(NowMs() - t_host0);

@@ -91,6 +91,7 @@ class DenseSegmentationHip {
   const SegDesc& result(int i) const { return *results_[i]; }
   void last_merge_stats(int64_t* s3) const;
   const vsg_timings& last_timings() const { return last_timings_; }
+  const GraphTimings& last_graph_timings() const { return last_graph_timings_; }
   void CopyLastSmoothed(float* out_interleaved_host);
   int W() const { return W_; }
   int H() const { return H_; }
@@ -111,6 +112,7 @@ class DenseSegmentationHip {
                              int max_label);
   void Retrieve(int frame, bool output_hierarchy, SegDesc* desc) const;
 
+  QuiesceGuard quiesce_;   // first member: spans the release of every buffer below (device_cache.h)
   vsg_options options_;
   int W_, H_;
   size_t wh_;
@@ -151,6 +153,7 @@ class DenseSegmentationHip {
   std::vector<std::string> encoded_;
   int64_t last_merge_stats_[3] = {0, 0, 0};
   vsg_timings last_timings_;
+  GraphTimings last_graph_timings_;   // the graph's own record of the last segmented chunk (diagnostics)
   vsg_timings accum_;   // preprocess / edge time accumulated while the chunk is being built
 };
 

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import VsgOptions, VsgTimings, check, lib
+from ._lib import VsgDiagnostics, VsgOptions, VsgTimings, check, lib
 
 
 def default_options(**kw):
@@ -135,6 +135,12 @@ class DenseSegmentation:
         t = VsgTimings()
         check(lib().vsg_stream_last_timings(self.h, C.byref(t)))
         return t
+
+    def last_diagnostics(self):
+        """vsg_stream_last_diagnostics of the last segmented chunk, as a dict."""
+        d = VsgDiagnostics()
+        check(lib().vsg_stream_last_diagnostics(self.h, C.byref(d)))
+        return d.as_dict()
 
     def last_smoothed(self):
         out = np.empty((self.H, self.W, 3), np.float32)
@@ -346,3 +352,9 @@ class DenseSegGraph:
         t = VsgTimings()
         check(lib().vsg_graph_timings(self.h, C.byref(t)))
         return t
+
+    def diagnostics(self):
+        """vsg_graph_diagnostics of the last segment() call, as a dict."""
+        d = VsgDiagnostics()
+        check(lib().vsg_graph_diagnostics(self.h, C.byref(d)))
+        return d.as_dict()

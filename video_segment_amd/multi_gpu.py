@@ -253,6 +253,8 @@ def run_chain_bench(args, rank, world, local_rank):
     engine = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk, device=local_rank),
                                    has_flow=True)
 
+    handoff = {"send_ms": 0.0, "sends": 0, "recv_ms": 0.0, "recvs": 0}
+
     def run_video(video, record):
         num_frames, plan, mine, frames = video
         frames_out = 0
@@ -264,7 +266,11 @@ def run_chain_bench(args, rank, world, local_rank):
                 eng.expect_halo()   # build first, receive the labels right before the merge
             for k in range(first, last + 1):
                 if c > 0 and k == last:
+                    th = time.perf_counter()
                     transport.recv_halo(eng, (c - 1) % world, rank)
+                    if record:
+                        handoff["recv_ms"] += (time.perf_counter() - th) * 1e3
+                        handoff["recvs"] += 1
                 n = eng.process_frame(frames[k], flow if k > 0 else None, flush=(k == num_frames - 1))
                 if n:
                     fetched = sum(len(eng.result_bytes(i)) for i in range(n))   # consumer side
@@ -288,7 +294,11 @@ def run_chain_bench(args, rank, world, local_rank):
                     acc["edges_total"] += t.edges_total
                     acc["merges"] += t.merges
             if c + 1 < len(plan):
+                th = time.perf_counter()
                 transport.send_halo(eng, (c + 1) % world, rank)
+                if record:
+                    handoff["send_ms"] += (time.perf_counter() - th) * 1e3
+                    handoff["sends"] += 1
         return frames_out
 
     warm = load(Wm * world) if Wm > 0 else None
@@ -313,8 +323,13 @@ def run_chain_bench(args, rank, world, local_rank):
     engine.close()
     if chain is not None:
         chain.close()
+    # (rank 0's own clock: a send returns when the receiver has taken the planes -- it is usually
+    # waiting for them already --, a receive includes the wait for the previous rank's merge)
     return {"dt": float(tt.item()), "frames": float(fo.item()), "acc": acc,
-            "handoff": {"transport": transport.name, "rccl_ranks": rccl_world},
+            "handoff": {"transport": transport.name, "rccl_ranks": rccl_world,
+                        "send_ms_per_chunk": handoff["send_ms"] / max(handoff["sends"], 1),
+                        "recv_wait_ms_per_chunk": handoff["recv_ms"] / max(handoff["recvs"], 1),
+                        "bytes_per_handoff": 2 * W * H * 4 + 32},
             "parallelism": "chain: ONE video, chunks round-robin over %d GPUs, every rank builds its "
                            "chunk graph before it blocks in the receive of the label-plane halo "
                            "(vsg_chain_send_halo / vsg_chain_recv_halo: ncclSend / ncclRecv inside "
