@@ -67,7 +67,12 @@ def test_chain_self_check_is_silent(vsg, monkeypatch, capfd):
                                  # the arrays that hold a stage's active edges start far too small and
                                  # grow inside the stages (the compaction is repeated)
                                  {"VSG_ACTIVE_CAP": "64"},
-                                 {"VSG_ACTIVE_CAP": "64", "VSG_SPINE_MIN": "32", "VSG_FORCE_ROLLBACK": "1"}])
+                                 {"VSG_ACTIVE_CAP": "64", "VSG_SPINE_MIN": "32", "VSG_FORCE_ROLLBACK": "1"},
+                                 # the wide worker (merge_wide.hip: several wavefronts per component in
+                                 # lock-step rounds; off by default) on every component it can take
+                                 {"VSG_WIDE_MIN": "25"},
+                                 {"VSG_WIDE_MIN": "40", "VSG_WIDE_WAVES": "2", "VSG_SPINE_MIN": "0"},
+                                 {"VSG_WIDE_MIN": "25", "VSG_FORCE_ROLLBACK": "1", "VSG_SPINE_MIN": "64"}])
 def test_stage_decomposition_variants(vsg, monkeypatch, env):
     """The stage driver's two decompositions are exact whatever their parameters: a bucket split
     into consecutive rank windows (each its own filter -> components -> replay), runs of equal

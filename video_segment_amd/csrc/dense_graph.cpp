@@ -509,6 +509,14 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   }
   S.force_rollback = getenv("VSG_FORCE_ROLLBACK") ? 1 : 0;
   S.small_seg = getenv("VSG_SMALL_SEG") ? std::max(1, atoi(getenv("VSG_SMALL_SEG"))) : 24;
+  // The wide worker (merge_wide.hip: several wavefronts replay one component in lock-step rounds) is
+  // OFF by default: measured in round 6, it is exact (every parity test with VSG_WIDE_MIN=25) and no
+  // faster -- half the edges of a percolating component hang on ONE region, whose chain is cut at
+  // the first blocked lane wherever the batch ends, so a batch of 256 lanes takes four times the
+  // rounds of a batch of 64.  VSG_WIDE_MIN=n hands it the components of at least n
+  // replayed edges (the largest size class of the work list then starts there).
+  S.wide_min = getenv("VSG_WIDE_MIN") ? atoi(getenv("VSG_WIDE_MIN")) : 0;
+  S.wide_waves = getenv("VSG_WIDE_WAVES") ? atoi(getenv("VSG_WIDE_WAVES")) : 4;
   // Sizes that follow the graph rather than the 1080p bench: the tree replay's scratch pool holds
   // the large components of one stage, which together are at most about one bucket of the chunk
   // graph (1.15 N edges: 48 M at 1080p x 21 slices; the stamped ranks of the spanning forest allow
@@ -851,8 +859,8 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     std::fprintf(stderr, "[vsg] segment: buckets %.1f ms, merge-constrained %.1f ms\n",
                  t_buckets - t0, t_mc - t_buckets);
   }
-  unsigned long long st[48] = {0};
-  D2H(st, stats_.get(), 48, stream_);
+  unsigned long long st[80] = {0};
+  D2H(st, stats_.get(), 80, stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
   if (st[23] != 0) {
     std::fprintf(stderr, "[vsg] chain self check: %llu mismatches\n", st[23]);
@@ -864,6 +872,12 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
                  "cuts %llu; optimistic stages %lld rollbacks %lld\n",
                  st[3], st[7], st[5], st[4], st[6], st[20], st[21], (long long)optimistic_stages_,
                  (long long)rollbacks_);
+    std::fprintf(stderr, "[vsg] wide: edges %llu batches %llu (%.1f lanes each) rounds %llu (%.1f per batch), chain lanes %llu, "
+                 "kept-lane iterations %llu; kcyc per batch: staging %.1f rounds %.1f (%.2f per round)\n",
+                 st[31], st[45], (double)st[72] / std::max(1.0, (double)st[45]), st[44],
+                 (double)st[44] / std::max(1.0, (double)st[45]), st[73], st[74],
+                 st[46] / 1e3 / std::max(1.0, (double)st[45]), st[47] / 1e3 / std::max(1.0, (double)st[45]),
+                 st[47] / 1e3 / std::max(1.0, (double)st[44]));
   }
   timings_.merge_ms = (float)(NowMs() - t0);
   for (auto& pr : ev_wave_) {

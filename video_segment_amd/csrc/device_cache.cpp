@@ -180,6 +180,13 @@ void* CacheAlloc(size_t bytes, CacheKind kind) {
     }
     t_counters.runtime_mallocs += 1;
     t_counters.runtime_malloc_ms += dt;
+    static const bool log_mallocs = getenv("VSG_DEVICE_CACHE_LOG") != nullptr;
+    if (log_mallocs) {   // (debugging aid: who still reaches the runtime allocator in the steady state?)
+      std::fprintf(stderr, "[vsg] runtime allocation: %zu bytes, kind %d, %.2f ms\n", need, (int)kind, dt);
+      void* frames[16];
+      const int nfr = backtrace(frames, 16);
+      backtrace_symbols_fd(frames, nfr, 2);
+    }
     b.p = p;
     b.bytes = need;
     b.kind = kind;

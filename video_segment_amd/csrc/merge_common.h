@@ -346,13 +346,21 @@ struct WorkerArgs {
   // long components start first and nobody strides over a hundred thousand small segments.
   uint32_t* work_list;      // [kWaveClasses][work_cap] segment indices
   int work_cap;
-  int32_t* work_ctl;        // [kWaveClasses] counts, [kWaveClasses] ticket -- zeroed before k_merge_small
+  int32_t* work_ctl;        // [kWaveClasses] counts, [kWaveClasses] the wave worker's ticket, [kWaveClasses + 1]
+                            // the wide worker's -- zeroed before k_merge_small
+  // Components of the largest class with at least wide_min edges (and less than wave_max) are
+  // replayed by the wide worker (merge_wide.hip: wide_waves wavefronts per component); 0: none.
+  int wide_min = 0;
+  int wide_waves = 4;
 };
 constexpr int kWaveClasses = 3;
 constexpr int kWaveClassMin1 = 192;    // class 1: at least this many edges
 constexpr int kWaveClassMin0 = 1536;   // class 0: at least this many edges
 // Round-based replay by one consumer wavefront + one reader wavefront (the default).
 void LaunchMergeWave(int grid, const WorkerArgs& a, bool instrumented, int dbg_flags, hipStream_t s);
+// Lock-step replay by `waves` wavefronts per component (merge_wide.hip); draws its components from
+// class 0 of the work list, so a.work_list must not be null.
+void LaunchMergeWide(int grid, const WorkerArgs& a, int waves, hipStream_t s);
 
 // Next event of the stage's pool (HIP events recorded around the dominant kernels; resolved by the
 // caller once the stream has been synchronised); -1 without a pool.

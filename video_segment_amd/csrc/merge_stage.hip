@@ -685,14 +685,15 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
                                                       unsigned long long* __restrict__ stats,
                                                       int small_seg, int wave_max,
                                                       uint32_t* __restrict__ work_list,
-                                                      int work_cap, int32_t* __restrict__ work_ctl) {
+                                                      int work_cap, int32_t* __restrict__ work_ctl,
+                                                      int cls_min0) {
   const int seg = blockIdx.x * 256 + threadIdx.x;
   unsigned n_forced = 0, n_regular = 0, n_small = 0;
   const int cnt = seg < *num_segs ? seg_cnt[seg] : 0;
   if (work_list) {
     // the wave worker's: filed under its size class (the order inside a class is arbitrary --
     // components are independent); one reservation per wavefront and class
-    const int cls = (cnt > small_seg && cnt < wave_max) ? (cnt >= kWaveClassMin0 ? 0 : (cnt >= kWaveClassMin1 ? 1 : 2)) : -1;
+    const int cls = (cnt > small_seg && cnt < wave_max) ? (cnt >= cls_min0 ? 0 : (cnt >= kWaveClassMin1 ? 1 : 2)) : -1;
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int c = 0; c < kWaveClasses; ++c) {
@@ -1011,17 +1012,34 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   wa.work_cap = n_work / (small_seg + 1) + 1;
   wa.work_list = (size_t)kWaveClasses * wa.work_cap <= (size_t)n_work ? S.seg_key : nullptr;
   wa.work_ctl = wa.work_list ? TakeZeroed(S, 2 * kWaveClasses) : nullptr;
+  wa.wide_min = S.wide_min;
+  wa.wide_waves = S.wide_waves;
   auto general_workers = [&](const WorkerArgs& w, int small_threads, int grid, hipStream_t s) {
     if (w.wave_min == w.small_seg) {
       hipLaunchKernelGGL(k_merge_small, dim3(Blocks(small_threads)), dim3(256), 0, s, w.num_segs,
                          w.seg_off, w.seg_cnt, w.s_ra, w.s_rb, w.s_gpos, w.nodes, w.kept_all, w.T,
                          w.optimistic, w.violation, w.stats, w.small_seg, w.wave_max, w.work_list, w.work_cap,
-                         w.work_ctl);
+                         w.work_ctl,
+                         // (the largest size class starts where the wide worker does, if that is lower)
+                         (w.wide_min > 0 && w.wide_min < kWaveClassMin0) ? std::max(w.wide_min, w.small_seg + 1)
+                                                                        : kWaveClassMin0);
     }
     // the wave worker is timed on the stream it runs on
     const int ew0 = NextEvent(S);
     if (ew0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ew0], s));
-    LaunchMergeWave(grid, w, S.wave_debug != 0, S.wave_dbg, s);
+    // The large components of the work list go to the wide worker (several wavefronts per component,
+    // merge_wide.hip); the wave worker leaves them alone.  (small_threads = the edges of the launch)
+    const bool wide = w.work_list != nullptr && w.wide_min > 0 && w.wide_min < w.wave_max &&
+                      small_threads >= w.wide_min && w.wave_min == w.small_seg;
+    if (wide) {
+      WorkerArgs narrow = w;
+      narrow.wave_max = w.wide_min;
+      LaunchMergeWave(grid, narrow, S.wave_debug != 0, S.wave_dbg, s);
+      const int wide_grid = std::min(small_threads / w.wide_min + 1, 1024);
+      LaunchMergeWide(wide_grid, w, w.wide_waves, s);
+    } else {
+      LaunchMergeWave(grid, w, S.wave_debug != 0, S.wave_dbg, s);
+    }
     const int ew1 = NextEvent(S);
     if (ew1 >= 0) {
       VSG_HIP(hipEventRecord((*S.ev_pool)[ew1], s));
