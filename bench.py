@@ -31,6 +31,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# A stream handle owns three HIP streams (main + two for the ordinary workers beside the tree replay);
+# the HIP runtime maps all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4)
+# and kernels of different streams that share a queue run one after the other.  With S streams per
+# process the runtime therefore needs 3 S queues (measured, 4 threads: 286 -> 348 frames/s with 16
+# queues; one stream: no difference).  Read once, at the first HIP call of the process.
+if "--streams" in sys.argv and "GPU_MAX_HW_QUEUES" not in os.environ:
+    try:
+        _s = int(sys.argv[sys.argv.index("--streams") + 1])
+        if _s > 1:
+            os.environ["GPU_MAX_HW_QUEUES"] = str(min(3 * _s + 1, 24))
+    except (IndexError, ValueError):
+        pass
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (first: a single HIP runtime per process, see video_segment_amd/_lib.py)
 import torch.distributed as dist  # noqa: E402
@@ -76,6 +89,7 @@ def parse():
                     help="also measure two chunk engines on one video (video_segment_amd/pipelined.py)")
     ap.add_argument("--no-chain-leg", action="store_true",
                     help="N > 1, --mode streams: skip the short chunk-chain leg after the replicas leg")
+    ap.add_argument("--chain-leg-timeout", type=int, default=240)
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the information-only legs after the timed region (other configs, other "
                          "inputs, several streams per GPU)")
@@ -743,14 +757,38 @@ def main():
         # chunks per rank after one warm-up chunk per rank; information beside `value`, which stays
         # the replicas number.
         result["chain"] = None
+        chain_timed_out = False
         if world > 1 and not args.no_chain_leg:
             import copy
             from video_segment_amd.multi_gpu import run_chain_bench
             a2 = copy.copy(args)
             a2.steps, a2.warmup = 2, 1
             vsg.memory_trim(local_rank)
-            try:
-                rc = run_chain_bench(a2, rank, world, local_rank)
+            # The leg runs on a thread of its own under a time limit: it is the only part of an N > 1
+            # run whose RCCL path (ncclCommInitRank with rank > 0, ncclSend / ncclRecv between two
+            # devices) no one-GPU box could ever exercise, and a hang there must not cost the replicas
+            # number that is already measured -- on a timeout every rank gives up on its own clock,
+            # rank 0 still prints the line (chain: error) and the processes leave through os._exit.
+            import threading
+            box = {}
+
+            def chain_leg():
+                try:
+                    box["rc"] = run_chain_bench(a2, rank, world, local_rank)
+                except BaseException as e:   # noqa: BLE001 -- information only
+                    box["error"] = "%s: %s" % (type(e).__name__, e)
+
+            th_ = threading.Thread(target=chain_leg, daemon=True)
+            th_.start()
+            th_.join(args.chain_leg_timeout)
+            if th_.is_alive():
+                chain_timed_out = True
+                result["chain"] = {"error": "no result within %d s (the hand-off or a barrier hangs): leg abandoned"
+                                            % args.chain_leg_timeout}
+            elif "error" in box:
+                result["chain"] = {"error": box["error"]}
+            else:
+                rc = box["rc"]
                 one = (result["frames"] / result["dt"]) / world
                 result["chain"] = {
                     "value": rc["frames"] / rc["dt"], "unit": "frames/s (whole job, ONE video)",
@@ -762,8 +800,6 @@ def main():
                     "vs_one_stream": (rc["frames"] / rc["dt"]) / one if one > 0 else None,
                     "expected": "<= 1.15 x one stream whatever N: the merge of chunk c+1 needs the labels "
                                 "of chunk c, only graph construction and read-out overlap (DESIGN 7)"}
-            except Exception as e:   # noqa: BLE001 -- information only
-                result["chain"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         dt, frames_total, acc = result["dt"], result["frames"], result["acc"]
@@ -890,6 +926,9 @@ def main():
             out.update(extras)
         print(json.dumps(out), flush=True)
     if world > 1:
+        if args.mode == "streams" and chain_timed_out:
+            sys.stdout.flush()
+            os._exit(0)   # (a thread of this process still hangs in the abandoned leg)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -434,7 +434,8 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   for (int b = 0; b < kNumBuckets; ++b) n_max = std::max<int64_t>(n_max, bucket_prefix[b + 1] - bucket_prefix[b]);
   VSG_REQUIRE(bucket_prefix[kNumBuckets] >= 0, -1, "too many edges");
   EnsureScratch((size_t)std::max<int64_t>(n_max, 1));
-  // (a first guess for a handle that has not seen a chunk yet: a quarter of the largest bucket.  The
+  // (a first guess for a handle that has not seen a chunk yet: a sixth of the largest bucket (a quarter
+  // until round 6: the rest of a bucket is now replayed in pieces of at most 1.4 N edges, below).  The
   // stage of the giant components of a first, unconstrained 1080p chunk has 61 M active edges of
   // 139 M and the window graph of configs[1] 9.5 M of 17 M -- one growth of the slab each, a
   // millisecond --, a 3840x2160 chunk stays below the quarter, and half the bucket would be 33 GB
@@ -443,7 +444,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     EnsureActiveScratch((size_t)std::max(1, atoi(e)));
   } else {
     EnsureActiveScratch(std::min<size_t>((size_t)std::max<int64_t>(n_max, 1),
-                                         std::max<size_t>((size_t)n_max / 4, (size_t)1 << 20)));
+                                         std::max<size_t>((size_t)n_max / 6, (size_t)1 << 20)));
   }
   bucket_prefix_dev_.ensure(bucket_prefix.size());
   H2D(bucket_prefix_dev_.get(), bucket_prefix.data(), bucket_prefix.size(), stream_);
@@ -517,6 +518,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   // replayed edges (the largest size class of the work list then starts there).
   S.wide_min = getenv("VSG_WIDE_MIN") ? atoi(getenv("VSG_WIDE_MIN")) : 0;
   S.wide_waves = getenv("VSG_WIDE_WAVES") ? atoi(getenv("VSG_WIDE_WAVES")) : 4;
+  S.chain_relax = getenv("VSG_CHAIN_RELAX") ? atoi(getenv("VSG_CHAIN_RELAX")) : 1;
   // Sizes that follow the graph rather than the 1080p bench: the tree replay's scratch pool holds
   // the large components of one stage, which together are at most about one bucket of the chunk
   // graph (1.15 N edges: 48 M at 1080p x 21 slices; the stamped ranks of the spanning forest allow
@@ -526,7 +528,11 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   // the same size on)
   S.spine_min = getenv("VSG_SPINE_MIN") ? atoi(getenv("VSG_SPINE_MIN")) : 2048;
   {
-    const double want = 1.15 * (double)wh_ * (double)capacity_frames_;   // (the handle's capacity, not this chunk's N)
+    // (the handle's capacity, not this chunk's N.  Round 6 measured 0.55 N: 1.7 GB less at 1080p and
+    // the same time on the bench input, but a stage that then wants more makes the pool grow by the
+    // dearer formula below -- 8 GB instead of 3.2 -- and at 3840x2160 the large components no longer
+    // fit the 2^27 edges the stamps address: kept at 1.15 N)
+    const double want = 1.15 * (double)wh_ * (double)capacity_frames_;
     const int by_graph = (int)std::min<double>(std::max<double>(want, 1 << 20), 120 << 20);
     S.spine_max_edges = getenv("VSG_SPINE_MAX_EDGES") ? atoi(getenv("VSG_SPINE_MAX_EDGES"))
                                                       : std::max(by_graph, spine_max_edges_grown_);
@@ -817,7 +823,12 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
         // few, large components already: the rest of the bucket in one stage -- in as few as the
         // tree replay can take (its rank stamps address 2^27 edges; the giant components of a
         // low-contrast 4K bucket have 260 M, and left to the wave worker they cost seconds)
-        const int64_t rest_cap = getenv("VSG_REST_CAP") ? atoll(getenv("VSG_REST_CAP")) : (119ll << 20);
+        // (and in pieces of at most 1.4 N edges -- 61 M at 1080p --: the active edges of a stage size the
+        // 106-byte-per-edge scratch, and the rest of a first, unconstrained chunk's bucket in ONE stage
+        // was 61 M active edges = 6.5 GB for nothing: two pieces take the same time)
+        const int64_t rest_default = std::min<int64_t>(
+            119ll << 20, std::max<int64_t>(16ll << 20, (int64_t)(1.4 * (double)wh_ * (double)capacity_frames_)));
+        const int64_t rest_cap = getenv("VSG_REST_CAP") ? atoll(getenv("VSG_REST_CAP")) : rest_default;
         const int64_t rest_n = (int64_t)n_b - pos;
         const int pieces = (int)std::max<int64_t>(1, (rest_n + rest_cap - 1) / rest_cap);
         const int64_t piece = (rest_n + pieces - 1) / pieces;

@@ -252,6 +252,7 @@ struct MergeScratch {
   int small_seg;         // components of up to this many replayed edges: one lane each (k_merge_small)
   int wide_min;          // components of at least this many replayed edges: wide worker (merge_wide.hip), 0: off
   int wide_waves;        // wavefronts per component of the wide worker (2 or 4)
+  int chain_relax;       // StageThr::relax (VSG_CHAIN_RELAX, default 1)
   int wave_debug;        // use the instrumented build of the wave worker (counters, self checks)
   int wave_dbg;          // debug hook (bit mask): 1 no chain, 4 no hot region, 8 one generic lane per round,
                          // 16 chain self check, 32 no jumping over pending lanes, 64 one chain lane per round

@@ -167,6 +167,7 @@ struct StageThr {
                    // invalidates the run's followers and has to be reported as a violation
   int side;        // the segments are side clusters of a spine (merge_spine.hip): a kept edge means
                    // the cluster does not end up as one region and is reported as a violation
+  int relax = 1;   // a certainly kept lane may join the chain whatever marks its partner carries
 };
 
 __device__ __forceinline__ int DecideEdge(RState& s1, RState& s2, const StageThr& T, int& stat) {

@@ -979,6 +979,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   T.min_size = P.min_region_size;
   T.rle = rle ? 1 : 0;
   T.side = 0;
+  T.relax = S.chain_relax;
   // Replayed edges in component order; the scratch arrays of the earlier steps are free by now.
   int32_t* s_ra = reinterpret_cast<int32_t*>(S.a_comp);
   int32_t* s_rb = reinterpret_cast<int32_t*>(S.a_idx);

@@ -307,12 +307,18 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
       const bool noop_b = any_kept_kind &&
                           ((B.cons >= 0 && Hs.cons >= 0) ? (B.cons != Hs.cons)
                                                          : (fin_b && B.sz >= T.min_size && Hs.sz >= T.min_size));
-      const bool plain_a = base && PlainPartner(A.flags) &&
-                           (noop_a || ((A.cons < 0 || A.cons == Hs.cons) && A.sz < Hs.sz &&
-                                       (!fin_a || A.cons >= 0 || Hs.sz >= T.min_size)));
-      const bool plain_b = base && PlainPartner(B.flags) &&
-                           (noop_b || ((B.cons < 0 || B.cons == Hs.cons) && B.sz < Hs.sz &&
-                                       (!fin_b || B.cons >= 0 || Hs.sz >= T.min_size)));
+      // (a certainly kept edge changes nothing, whatever marks its partner carries: only a partner
+      // that MERGES has to be plain -- no mark to hand on, no missing descriptor)
+      const bool plain_a =
+          base && ((noop_a && T.relax) ||
+                   (PlainPartner(A.flags) &&
+                    (noop_a || ((A.cons < 0 || A.cons == Hs.cons) && A.sz < Hs.sz &&
+                                (!fin_a || A.cons >= 0 || Hs.sz >= T.min_size)))));
+      const bool plain_b =
+          base && ((noop_b && T.relax) ||
+                   (PlainPartner(B.flags) &&
+                    (noop_b || ((B.cons < 0 || B.cons == Hs.cons) && B.sz < Hs.sz &&
+                                (!fin_b || B.cons >= 0 || Hs.sz >= T.min_size)))));
       // (a lane that took part in the reservations as a kept lane may only be one: on the hot
       // region as a chain lane, away from it through the generic code below -- or it waits)
       const bool part_a = plain_a && (noop_l ? (noop_a && free_p && b_hot) : own_a);

@@ -281,12 +281,18 @@ __device__ __forceinline__ bool ReplayRoundsWide(WideTable<W>& tab, WideShared<W
         const bool noop_b = any_kept_kind &&
                             ((B.cons >= 0 && Hs.cons >= 0) ? (B.cons != Hs.cons)
                                                            : (fin_b && B.sz >= T.min_size && Hs.sz >= T.min_size));
-        const bool plain_a = base && PlainPartner(A.flags) &&
-                             (noop_a || ((A.cons < 0 || A.cons == Hs.cons) && A.sz < Hs.sz &&
-                                         (!fin_a || A.cons >= 0 || Hs.sz >= T.min_size)));
-        const bool plain_b = base && PlainPartner(B.flags) &&
-                             (noop_b || ((B.cons < 0 || B.cons == Hs.cons) && B.sz < Hs.sz &&
-                                         (!fin_b || B.cons >= 0 || Hs.sz >= T.min_size)));
+        // (a certainly kept edge changes nothing, whatever marks its partner carries: only a partner
+        // that MERGES has to be plain -- no mark to hand on, no missing descriptor)
+        const bool plain_a =
+            base && ((noop_a && T.relax) ||
+                     (PlainPartner(A.flags) &&
+                      (noop_a || ((A.cons < 0 || A.cons == Hs.cons) && A.sz < Hs.sz &&
+                                  (!fin_a || A.cons >= 0 || Hs.sz >= T.min_size)))));
+        const bool plain_b =
+            base && ((noop_b && T.relax) ||
+                     (PlainPartner(B.flags) &&
+                      (noop_b || ((B.cons < 0 || B.cons == Hs.cons) && B.sz < Hs.sz &&
+                                  (!fin_b || B.cons >= 0 || Hs.sz >= T.min_size)))));
         const bool part_a = plain_a && (noop_l ? (noop_a && free_p && b_hot) : own_a);
         const bool part_b = plain_b && (noop_l ? (noop_b && free_p && a_hot) : own_b);
         const bool merge_a = part_a && !noop_a && (A.cons >= 0 || !fin_a || A.sz < T.min_size);
