@@ -20,8 +20,9 @@ for k in range(N):
     if n:
         t = s.last_timings()
         now = time.time()
-        print("k=%d out=%d wall=%.3fs | pre %.1f edges %.1f merge %.1f readout %.1f host %.1f ms | edges %d merges %d stats %s"
-              % (k, n, now - tl, t.preprocess_ms, t.edges_ms, t.merge_ms, t.readout_ms, t.host_post_ms,
-                 t.edges_total, t.merges, s.last_merge_stats()), flush=True)
+        print("k=%d out=%d wall=%.3fs | pre %.1f edges %.1f merge %.1f (filter %.1f wave %.1f spine %.1f) readout %.1f host %.1f ms | edges %d merges %d stats %s"
+              % (k, n, now - tl, t.preprocess_ms, t.edges_ms, t.merge_ms, t.filter_kernel_ms, t.wave_kernel_ms,
+                 t.spine_kernel_ms, t.readout_ms, t.host_post_ms, t.edges_total, t.merges, s.last_merge_stats()),
+              flush=True)
         tl = now
 print("total %.3fs -> %.2f fps" % (time.time() - t0, N / (time.time() - t0)))

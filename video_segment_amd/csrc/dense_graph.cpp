@@ -53,6 +53,7 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   desc_sz_.alloc(N);
   cons_.alloc(N);
   flags_.alloc(N);
+  hub8_.alloc(N);
   cc_.alloc(N);
   label_uf_.alloc(N);
   label_img_.alloc(N);
@@ -68,6 +69,8 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   hist_sums_.alloc(EdgeSortSumInts(wh_) + 1);
   scalars_.alloc(32);
   stats_.alloc(96);
+  hub_excl_.alloc(kHubExclCap + 4);
+  VSG_HIP(hipMemsetAsync(hub_excl_.get(), 0, sizeof(int32_t), stream_));   // (the count; blocks of the cache are not zeroed)
   {
     // mailbox: 256 slots of four words + a list of 2 * 4095 ints, mapped and coherent (the device
     // writes it while kernels run, the host polls it)
@@ -355,7 +358,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   const ThreadAllocCounters alloc0 = ThreadAllocSnapshot();
   MailWaitResetLongest();
   const MailWaitCounters mail0 = MailWaitSnapshot();
-  int64_t diag_stages = 0, diag_slab_growths = 0, diag_spine_growths = 0;
+  int64_t diag_stages = 0, diag_slab_growths = 0, diag_spine_growths = 0, diag_hub_stages = 0, diag_hub_absorbed = 0;
   double diag_slab_ms = 0, diag_spine_ms = 0;
 
   // List table.
@@ -519,6 +522,10 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.wide_min = getenv("VSG_WIDE_MIN") ? atoi(getenv("VSG_WIDE_MIN")) : 0;
   S.wide_waves = getenv("VSG_WIDE_WAVES") ? atoi(getenv("VSG_WIDE_WAVES")) : 4;
   S.chain_relax = getenv("VSG_CHAIN_RELAX") ? atoi(getenv("VSG_CHAIN_RELAX")) : 1;
+  S.hubs = getenv("VSG_HUBS") ? atoi(getenv("VSG_HUBS")) : 1;
+  S.hub_excl = hub_excl_.get();
+  // (a stage takes its marks off again; an exception in the middle of one must not leave any behind)
+  VSG_HIP(hipMemsetAsync(hub8_.get(), 0, N, stream_));
   // Sizes that follow the graph rather than the 1080p bench: the tree replay's scratch pool holds
   // the large components of one stage, which together are at most about one bucket of the chunk
   // graph (1.15 N edges: 48 M at 1080p x 21 slices; the stamped ranks of the spanning forest allow
@@ -758,6 +765,8 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
       info.want_components = debug_stages ? 2 : measure;
       ++diag_stages;
       RunStageDebug(b, w, windows, j0, n, P, inert_mode, S, debug_stages, &info);
+      diag_hub_stages += info.hub_stages;
+      diag_hub_absorbed += info.hub_absorbed;
       group_active += info.replayed;
       if (debug_stages && info.want_components && wave_target_active_ != kNoWindowTarget) {
         std::fprintf(stderr, "[vsg]   window: max wave segment %d, target %lld active (density %.4f), limited %d\n",
@@ -860,6 +869,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   timings_.optimistic_stages = optimistic_stages_;
   timings_.rollbacks = rollbacks_;
   LaunchKeepVirtualBucket(list_desc_dev_.get(), L, stream_);
+  ResetHubExclusions(S, nodes(), stream_);
   VSG_HIP(hipStreamSynchronize(stream_));
   const double t_buckets = NowMs();
   if (getenv("VSG_DEBUG_HASH")) DebugHash("after buckets");
@@ -883,6 +893,10 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
                  "cuts %llu; optimistic stages %lld rollbacks %lld\n",
                  st[3], st[7], st[5], st[4], st[6], st[20], st[21], (long long)optimistic_stages_,
                  (long long)rollbacks_);
+    std::fprintf(stderr, "[vsg] hubs: %lld stages used hub regions, %lld regions absorbed through them, %lld stages redone "
+                 "(broken %lld, inherit %lld, shape %lld, marked %lld, pair %lld, split %lld)\n",
+                 (long long)diag_hub_stages, (long long)diag_hub_absorbed, S.hub_retries, S.hub_reasons[0],
+                 S.hub_reasons[1], S.hub_reasons[2], S.hub_reasons[3], S.hub_reasons[4], S.hub_reasons[5]);
     std::fprintf(stderr, "[vsg] wide: edges %llu batches %llu (%.1f lanes each) rounds %llu (%.1f per batch), chain lanes %llu, "
                  "kept-lane iterations %llu; kcyc per batch: staging %.1f rounds %.1f (%.2f per round)\n",
                  st[31], st[45], (double)st[72] / std::max(1.0, (double)st[45]), st[44],

@@ -112,7 +112,7 @@ class DenseGraphHip {
   void SortList(ListBuf& lb, int per_px);
   void MergeConstrainedHostAssisted();
   NodeArrays nodes() {
-    return NodeArrays{parent_.get(), desc_sz_.get(), cons_.get(), flags_.get()};
+    return NodeArrays{parent_.get(), desc_sz_.get(), cons_.get(), flags_.get(), hub8_.get()};
   }
 
   QuiesceGuard quiesce_;   // first member: spans the release of every buffer below (device_cache.h)
@@ -134,6 +134,7 @@ class DenseGraphHip {
   DevBuf<float4> desc_sz_;
   DevBuf<int32_t> cons_;
   DevBuf<uint8_t> flags_;
+  DevBuf<uint8_t> hub8_;    // NodeArrays::hub8
   // N-sized scratch / result arrays
   DevBuf<int32_t> cc_, label_uf_, label_img_, adjust_;
   // lists
@@ -176,6 +177,7 @@ class DenseGraphHip {
   int64_t optimistic_stages_ = 0, rollbacks_ = 0;
   DevBuf<int32_t> scalars_;   // num_active, num_segs, misc
   DevBuf<int32_t> seg_table_dev_;   // k_filter: the segments of the current stage
+  DevBuf<int32_t> hub_excl_;        // exclusion list of the hub regions (device_graph.h: kFlagHubExcluded)
   PinnedBuf<int32_t> iv_host_;      // read-out: the scan intervals on the host (label, frame|y, lx, rx)
   std::vector<int32_t> seg_table_host_, list_off_host_;
   Mailbox mail_;              // host-visible scalars (device_graph.h); mapped host memory

@@ -25,12 +25,29 @@ namespace vsg {
 constexpr uint8_t kFlagFinalized = 1;
 constexpr uint8_t kFlagNoDesc = 2;
 constexpr uint8_t kFlagTentative = 4;   // region has tentatively settled edges in this stage
+// Hub regions of a stage (merge_stage.hip, "hubs"): a finalized region of at least the minimum size
+// absorbs a small unconstrained neighbour whatever its own mean and size are, so its edges to such
+// neighbours do not tie the neighbours' components together; the absorbed regions are logged and the
+// hub's size and mean are brought up to date, in sequence order, after the workers (k_hub_apply).
+// The hub mark itself lives in NodeArrays::hub8 (one byte per region, plain idempotent stores by
+// the filter: thousands of edges mark the same region, and the flags byte is written with plain
+// read-modify-write stores by the same kernel); the workers fold it into RState::flags as kFlagHub.
+constexpr uint8_t kFlagHub = 8;         // (RState::flags only) the stage uses the region as a hub
+constexpr uint8_t kFlagHubBroken = 16;  // the region is on the exclusion list (keeps the list free of duplicates:
+                                        // set with atomics, possibly lost to a plain store -- a hint)
+// A region that broke a hub rule is put on the stage's exclusion list (MergeScratch::hub_excl: count,
+// then the regions) and carries kFlagHubExcluded through the retries of that stage: their filter
+// does not make it a hub again (a hint only -- a stage is exact with any set of hubs).
+constexpr uint8_t kFlagHubExcluded = 32;
+constexpr int kHubExclCap = 16384;      // entries of the exclusion list
+constexpr int kHubMaxAttempts = 4;      // retries of a stage with a longer list before it runs without hubs
 
 struct NodeArrays {
   int32_t* parent;
   float4* desc_sz;
   int32_t* cons;
   uint8_t* flags;
+  uint8_t* hub8;    // 1: hub of the current stage (kFlagHub above); zero between stages
 };
 
 // One bucket list as seen by the merge / neighbour kernels.
@@ -253,6 +270,12 @@ struct MergeScratch {
   int wide_min;          // components of at least this many replayed edges: wide worker (merge_wide.hip), 0: off
   int wide_waves;        // wavefronts per component of the wide worker (2 or 4)
   int chain_relax;       // StageThr::relax (VSG_CHAIN_RELAX, default 1)
+  int hubs;              // hub regions (VSG_HUBS, default 1): see kFlagHub
+  int hubs_off;          // (> 0 while a stage that violated a hub rule is replayed without hubs)
+  int hub_attempt;       // retries of the current stage with hubs (kHubMaxAttempts)
+  int32_t* hub_excl;     // exclusion list of the stage: [0] count, [1 ..] regions (kHubExclCap)
+  long long hub_retries; // such replays in this Segment call
+  long long hub_reasons[6];   // ... by reason (kHubVioBroken .. kHubVioSplit)
   int wave_debug;        // use the instrumented build of the wave worker (counters, self checks)
   int wave_dbg;          // debug hook (bit mask): 1 no chain, 4 no hot region, 8 one generic lane per round,
                          // 16 chain self check, 32 no jumping over pending lanes, 64 one chain lane per round
@@ -295,7 +318,11 @@ struct StageInfo {
   int components = 0;   // independent components they fell into
   int max_wave_segment = 0;   // (with want_components) edges of the largest component that one
                               // wavefront replayed -- those of the tree replay do not count
+  int hub_stages = 0;         // the stage used hub regions (kFlagHub)
+  long long hub_absorbed = 0; // regions its hubs absorbed
 };
+// Takes the marks of the hub exclusion list off the regions and empties the list.
+void ResetHubExclusions(MergeScratch& S, NodeArrays nodes, hipStream_t s);
 void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const int32_t* bucket_base,
                     const uint32_t* list_slot_base, uint8_t* kept_all, NodeArrays nodes,
                     const MergeParams& P, int inert_mode, MergeScratch& S, hipStream_t s,

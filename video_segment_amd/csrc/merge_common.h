@@ -168,6 +168,7 @@ struct StageThr {
   int side;        // the segments are side clusters of a spine (merge_spine.hip): a kept edge means
                    // the cluster does not end up as one region and is reported as a violation
   int relax = 1;   // a certainly kept lane may join the chain whatever marks its partner carries
+  int hubs = 0;    // regions with kFlagHub are hubs of this stage (HubEdge below)
 };
 
 __device__ __forceinline__ int DecideEdge(RState& s1, RState& s2, const StageThr& T, int& stat) {
@@ -212,13 +213,83 @@ __device__ __forceinline__ int DecideEdge(RState& s1, RState& s2, const StageThr
 // the small one of the two is absorbed, two large ones are kept and nothing changes.  That is the
 // rule on noisy and on low-contrast inputs: a giant region whose neighbours have all failed a
 // test before.
-__device__ __forceinline__ bool PlainPartner(int flags) { return (flags & ~(int)kFlagFinalized) == 0; }
+// (A hub of the stage is no partner: its edges are decided by their other end.  The other hub marks
+// -- broken, excluded -- say nothing about the region's state.)
+__device__ __forceinline__ bool PlainPartner(int flags) {
+  return (flags & (kFlagNoDesc | kFlagTentative | kFlagHub)) == 0;
+}
 
 // DecideEdge keeps the edge and changes neither state: different constraints, or (unconstrained
 // rule) one of the two finalized -- no test -- and both at least of minimum size.
 __device__ __forceinline__ bool NoopPair(const RState& s1, const RState& s2, const StageThr& T) {
   if (s1.cons >= 0 && s2.cons >= 0) return s1.cons != s2.cons;
   return ((s1.flags | s2.flags) & kFlagFinalized) && s1.sz >= T.min_size && s2.sz >= T.min_size;
+}
+
+// ------------------------------------------------------------------------------------------
+// Hub edges (device_graph.h: kFlagHub).  x: the region at the other end of an edge to the hub h.
+// What DecideEdge would do follows from x alone while h is a finalized region of at least the
+// minimum size whose constraint does not change during the stage:
+//   different constraints (both >= 0)             -> kept, nothing changes (kHubKeep)
+//   x unconstrained, x.sz >= min size              -> kept, nothing changes (no test: h is finalized)
+//   x unconstrained, x.sz < min size, x has a mean -> h absorbs x ("small" merge; kHubAbsorb): the
+//        hub's constraint stays (max(h.cons, -1)), the absorbed state is logged, the hub's own
+//        state is not touched here
+//   equal constraints >= 0, x smaller than h       -> h absorbs x ("forced" merge) provided the split
+//        test passes when the log is applied (kHubAbsorbTest)
+//   anything else (x constrained and h not: the hub would inherit the constraint; x without a mean;
+//        a broken hub; a marked x whose constraint would change) -> the stage cannot use hubs
+//        (kHubViolation: bit 2 of the stage's violation word)
+// ------------------------------------------------------------------------------------------
+enum : int { kHubKeep = 0, kHubAbsorb = 1, kHubAbsorbTest = 3, kHubViolation = 4 };
+// (a violation is kHubViolation or one of the bits above it: the reason, all of them in
+// kHubViolationMask of the stage's violation word -- bit 0: optimistic stage, bit 1: tree replay)
+constexpr int kHubViolationMask = 0xfc;
+constexpr int kHubVioBroken = 4, kHubVioInherit = 8, kHubVioShape = 16, kHubVioMarked = 32, kHubVioPair = 64,
+              kHubVioSplit = 128;
+constexpr int kHubTestBit = 1 << 30;   // in a hub mark: the absorption is subject to the split test (k_hub_apply)
+// h_sz: the hub's size when the stage started (it only grows).  Returns kHubKeep / kHubAbsorb /
+// kHubAbsorbTest or a violation bit.
+__device__ __forceinline__ int HubEdge(const RState& x, int h_cons, int h_flags, int h_sz, const StageThr& T) {
+  if (h_flags & kFlagHubBroken) return kHubVioBroken;
+  if (x.cons >= 0) {
+    if (h_cons < 0) return kHubVioInherit;       // the hub would inherit the constraint
+    if (h_cons != x.cons) return kHubKeep;       // different constraints: never merged
+    // Equal constraints: merged unless the means are further apart than the split threshold -- which
+    // only the hub's mean at that moment can tell.  Nearly every such edge merges (two million
+    // forced merges per constrained 1080p chunk, a handful of splits), so the absorption is logged
+    // as one to be VERIFIED when the log is applied in order; a failed test undoes the stage.
+    if ((x.flags & kFlagNoDesc) || x.sz >= h_sz) return kHubVioShape;
+    return kHubAbsorbTest;
+  }
+  if (x.sz >= T.min_size) return kHubKeep;
+  if (x.flags & kFlagNoDesc) return kHubVioShape;
+  if ((x.flags & kFlagTentative) && h_cons != x.cons) return kHubVioMarked;   // TentativeViolated
+  return kHubAbsorb;
+}
+// Two hubs: both finalized and large -- kept unless their (equal) constraints ask for the split test.
+__device__ __forceinline__ int HubHubEdge(int c1, int f1, int c2, int f2) {
+  if ((f1 | f2) & kFlagHubBroken) return kHubVioBroken;
+  return (c1 >= 0 && c1 == c2) ? kHubVioPair : kHubKeep;
+}
+// Sets flag bits of a region with an atomic on the word that holds its flags byte (several kinds of
+// marks are set concurrently: a byte read-modify-write would lose one).
+// Returns the region's flags before.
+__device__ __forceinline__ int AtomicOrFlags(uint8_t* flags, int r, int bits) {
+  unsigned* w = reinterpret_cast<unsigned*>(flags + ((size_t)r & ~(size_t)3));
+  return (int)((atomicOr(w, (unsigned)bits << (8 * (r & 3))) >> (8 * (r & 3))) & 0xffu);
+}
+// A region that cannot be a hub of its stage (the filter found an edge that needs its exact state, a
+// worker an edge that breaks a hub rule): marked broken -- the stage is redone -- and, once, put on
+// the exclusion list that the retry turns into kFlagHubExcluded marks.
+__device__ __forceinline__ void HubExclude(int32_t* excl, uint8_t* flags, int r) {
+  if (AtomicOrFlags(flags, r, kFlagHubBroken) & kFlagHubBroken) return;
+  const int q = atomicAdd(&excl[0], 1);
+  if (q < kHubExclCap) excl[1 + q] = r;
+}
+__device__ __forceinline__ void AtomicAndFlags(uint8_t* flags, int r, int keep_bits) {
+  unsigned* w = reinterpret_cast<unsigned*>(flags + ((size_t)r & ~(size_t)3));
+  atomicAnd(w, ~((unsigned)(~keep_bits & 0xff) << (8 * (r & 3))));
 }
 
 // A tentatively settled edge stays settled only while the constraints of its two regions do not
@@ -245,7 +316,13 @@ __device__ __forceinline__ RState LoadState(const NodeArrays& nodes, int r) {
 __device__ __forceinline__ void StoreState(const NodeArrays& nodes, int r, const RState& s) {
   nodes.desc_sz[r] = make_float4(s.d0, s.d1, s.d2, __int_as_float(s.sz));
   nodes.cons[r] = s.cons;
-  nodes.flags[r] = (uint8_t)s.flags;
+  nodes.flags[r] = (uint8_t)(s.flags & ~(int)kFlagHub);
+}
+// ... in a stage with hubs: with the hub mark (device_graph.h: NodeArrays::hub8) as kFlagHub.
+__device__ __forceinline__ RState LoadStateHub(const NodeArrays& nodes, int r, int hubs) {
+  RState s = LoadState(nodes, r);
+  if (hubs && nodes.hub8[r]) s.flags |= kFlagHub;
+  return s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -353,6 +430,11 @@ struct WorkerArgs {
   // replayed by the wide worker (merge_wide.hip: wide_waves wavefronts per component); 0: none.
   int wide_min = 0;
   int wide_waves = 4;
+  // Hubs (T.hubs): hub_mark[seq] receives the absorbed region of the work edge with sequence number seq
+  // (-1 otherwise; cleared by the stage driver), seq = s_seq[position in the component-sorted arrays].
+  int32_t* hub_mark = nullptr;
+  const uint32_t* s_seq = nullptr;
+  int32_t* hub_excl = nullptr;   // MergeScratch::hub_excl
 };
 constexpr int kWaveClasses = 3;
 constexpr int kWaveClassMin1 = 192;    // class 1: at least this many edges

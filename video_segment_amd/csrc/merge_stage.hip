@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
                                                  int32_t* __restrict__ e_rb,
                                                  uint32_t* __restrict__ e_gpos,
                                                  FilterMasks M,
-                                                 int32_t* __restrict__ num_ti, FilterSegs segs) {
+                                                 int32_t* __restrict__ num_ti, FilterSegs segs, int hubs,
+                                                 int32_t* __restrict__ num_hub, int32_t* __restrict__ hub_excl) {
   __shared__ int wave_cnt[kFilterPer][4], wave_kept[kFilterPer][4];
   __shared__ int s_start[kFilterEdges], s_pos0[kFilterEdges];
   // ... with what the edges of a segment need from its list (a 48-byte descriptor per thread
@@ -430,18 +431,19 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
     if (!valid[e] || ra == rb) continue;
     if (P.spatial_survivors && l_type[e] == 0 && !P.spatial_survivors[gpos[e]]) continue;   // the edge is gone
     bool inert = false;
+    int f1 = 0, f2 = 0, s1 = 0, s2 = 0, c1 = -1, c2 = -1;
     if (inert_mode != 0) {
-      const int f1 = nodes.flags[ra], f2 = nodes.flags[rb];
-      bool both_final_large = false;
-      if ((f1 & kFlagFinalized) && (f2 & kFlagFinalized)) {
-        const int s1 = __float_as_int(nodes.desc_sz[ra].w);
-        const int s2 = __float_as_int(nodes.desc_sz[rb].w);
-        both_final_large = (s1 >= P.min_region_size) && (s2 >= P.min_region_size);
-      }
+      f1 = nodes.flags[ra];
+      f2 = nodes.flags[rb];
+      if (f1 & kFlagFinalized) s1 = __float_as_int(nodes.desc_sz[ra].w);
+      if (f2 & kFlagFinalized) s2 = __float_as_int(nodes.desc_sz[rb].w);
+      const bool both_final_large = (f1 & kFlagFinalized) && (f2 & kFlagFinalized) &&
+                                    (s1 >= P.min_region_size) && (s2 >= P.min_region_size);
       if (inert_mode == 1) {
         inert = both_final_large;
       } else {
-        const int c1 = nodes.cons[ra], c2 = nodes.cons[rb];
+        c1 = nodes.cons[ra];
+        c2 = nodes.cons[rb];
         if (c1 >= 0 && c2 >= 0) {
           inert = (c1 != c2);            // different constraints: never merged
         } else {
@@ -449,6 +451,8 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
         }
         if (inert) {
           ti[e] = 1;
+          // (plain stores: every writer of the kernel that matters writes this bit into what it read;
+          // the one other writer -- kFlagHubBroken, with atomics -- only keeps a list free of duplicates)
           if (!(f1 & kFlagTentative)) nodes.flags[ra] = (uint8_t)(f1 | kFlagTentative);
           if (!(f2 & kFlagTentative)) nodes.flags[rb] = (uint8_t)(f2 | kFlagTentative);
         }
@@ -459,7 +463,37 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
       settled[e] = 1;
     } else {
       active[e] = 1;
-      CcUnion(cc, ra, rb);
+      // Hubs (device_graph.h: kFlagHub): an edge between a finalized region of at least the minimum
+      // size and a region that has a mean and is unconstrained (or shares the hub's constraint: merged
+      // subject to a test that is verified later) is decided by the latter alone -- it does not
+      // tie the two into one component.  The record lists the other region first (the component key is
+      // taken from the first root), the hub second.  An active edge that needs a hub's exact state
+      // marks it broken and puts it on the exclusion list: a stage that uses such a region as a hub
+      // elsewhere is redone with the region as an ordinary one.
+      bool hub_edge = false;
+      if (hubs) {
+        constexpr int kNoHub = kFlagNoDesc | kFlagHubExcluded;
+        const bool h1 = (f1 & kFlagFinalized) && !(f1 & kNoHub) && s1 >= P.min_region_size;
+        const bool h2 = (f2 & kFlagFinalized) && !(f2 & kNoHub) && s2 >= P.min_region_size;
+        if (h1 != h2) {
+          const int h = h1 ? ra : rb, x = h1 ? rb : ra;
+          const int fx = h1 ? f2 : f1, cx = h1 ? c2 : c1, fh = h1 ? f1 : f2;
+          const int ch = h1 ? c1 : c2;
+          if ((cx < 0 || cx == ch) && !(fx & kFlagNoDesc)) {
+            hub_edge = true;
+            root[2 * e] = x;
+            root[2 * e + 1] = h;
+            if (!nodes.hub8[h]) nodes.hub8[h] = 1;
+            if (*num_hub == 0) *num_hub = 1;
+          } else if (!(fh & kFlagHubBroken)) {
+            HubExclude(hub_excl, nodes.flags, h);
+          }
+        } else if (h1 && h2) {   // (not inert: equal constraints -- the split test reads both means)
+          if (!(f1 & kFlagHubBroken)) HubExclude(hub_excl, nodes.flags, ra);
+          if (!(f2 & kFlagHubBroken)) HubExclude(hub_excl, nodes.flags, rb);
+        }
+      }
+      if (!hub_edge) CcUnion(cc, ra, rb);
     }
   }
   // What the edge turned out to be is three bits per edge, one 64-bit word per wavefront and
@@ -604,7 +638,7 @@ __global__ __launch_bounds__(256) void k_compact_active(int n_b, FilterMasks M,
                                                          int32_t* __restrict__ num_active,
                                                          const int32_t* __restrict__ num_ti,
                                                          unsigned long long* __restrict__ mail, unsigned mail_seq,
-                                                         int a_cap) {
+                                                         int a_cap, const int32_t* __restrict__ num_hub) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t gw0 = (size_t)blockIdx.x * 4;
@@ -626,6 +660,7 @@ __global__ __launch_bounds__(256) void k_compact_active(int n_b, FilterMasks M,
     *num_active = total;
     MailPost(mail, mail_seq, 0, total);
     MailPost(mail, mail_seq, 1, *num_ti);   // (k_filter's sum: complete, it is the kernel before)
+    MailPost(mail, mail_seq, 2, *num_hub);
   }
 }
 
@@ -686,7 +721,9 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
                                                       int small_seg, int wave_max,
                                                       uint32_t* __restrict__ work_list,
                                                       int work_cap, int32_t* __restrict__ work_ctl,
-                                                      int cls_min0) {
+                                                      int cls_min0, int32_t* __restrict__ hub_mark,
+                                                      const uint32_t* __restrict__ s_seq,
+                                                      int32_t* __restrict__ hub_excl) {
   const int seg = blockIdx.x * 256 + threadIdx.x;
   unsigned n_forced = 0, n_regular = 0, n_small = 0;
   const int cnt = seg < *num_segs ? seg_cnt[seg] : 0;
@@ -718,6 +755,32 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
         if (r1 == r2) continue;
         RState s1 = LoadState(nodes, r1);
         RState s2 = LoadState(nodes, r2);
+        if (T.hubs) {
+          if (nodes.hub8[r1]) s1.flags |= kFlagHub;
+          if (nodes.hub8[r2]) s2.flags |= kFlagHub;
+        }
+        if (T.hubs && ((s1.flags | s2.flags) & kFlagHub)) {
+          // an edge on a hub of the stage (merge_common.h: HubEdge): decided by the other region alone
+          const bool hub1 = (s1.flags & kFlagHub) != 0, hub2 = (s2.flags & kFlagHub) != 0;
+          const RState& x = hub1 ? s2 : s1;
+          const RState& h = hub1 ? s1 : s2;
+          const int act = (hub1 && hub2) ? HubHubEdge(s1.cons, s1.flags, s2.cons, s2.flags)
+                                         : HubEdge(x, h.cons, h.flags, h.sz, T);
+          if (act >= kHubViolation) {
+            atomicOr(violation, act);
+            if (hub1) HubExclude(hub_excl, nodes.flags, r1);
+            if (hub2) HubExclude(hub_excl, nodes.flags, r2);
+          } else if (act == kHubKeep) {
+            kept_all[s_gpos[p]] = 1;
+          } else {
+            const int xr = hub1 ? r2 : r1, hr = hub1 ? r1 : r2;
+            nodes.parent[xr] = hr;
+            if (x.flags & kFlagTentative) AtomicOrFlags(nodes.flags, hr, kFlagTentative);
+            hub_mark[s_seq[p]] = xr | (act == kHubAbsorbTest ? kHubTestBit : 0);
+            if (act == kHubAbsorbTest) ++n_forced; else ++n_small;
+          }
+          continue;
+        }
         const RState o1 = s1, o2 = s2;
         int stat;
         const int out = DecideEdge(s1, s2, T, stat);
@@ -827,6 +890,150 @@ __global__ __launch_bounds__(256) void k_resolve_followers(int n, const int32_t*
 }
 
 // ------------------------------------------------------------------------------------------
+// Hubs: what the workers logged is applied in sequence order (device_graph.h: kFlagHub).
+// ------------------------------------------------------------------------------------------
+// hub_mark[seq] = region absorbed by a hub at the work edge with sequence number seq (or -1): the
+// absorbed regions in sequence order (one fused scan), with the hub of each -- its parent.
+struct HubMarkValue {
+  const int32_t* mark;
+  __device__ int operator()(int i) const { return mark[i] >= 0; }
+};
+struct HubMarkEmit {
+  const int32_t* mark;
+  const int32_t* parent;
+  uint32_t* x_list;
+  uint32_t* key_list;
+  __device__ void operator()(int i, int is_set, int q) const {
+    if (is_set) {
+      const int x = mark[i];
+      x_list[q] = (uint32_t)x;                          // (with kHubTestBit)
+      key_list[q] = (uint32_t)parent[x & ~kHubTestBit];
+    }
+  }
+};
+struct HubMarkFinish {
+  int32_t* count;
+  unsigned long long* mail;
+  unsigned mail_seq;
+  __device__ void operator()(int total) const {
+    *count = total;
+    MailPost(mail, mail_seq, 0, total);
+  }
+};
+
+// One thread per hub: MergeStates (merge_common.h) with the hub as the survivor, once per absorbed
+// region, in sequence order (the list is sorted by hub, stably).  The loads do not depend on the
+// recurrence: four regions are fetched ahead of the arithmetic.
+__global__ __launch_bounds__(64) void k_hub_apply(const int32_t* __restrict__ num_runs,
+                                                   const int32_t* __restrict__ run_off,
+                                                   const int32_t* __restrict__ run_cnt,
+                                                   const uint32_t* __restrict__ hub_sorted,
+                                                   const uint32_t* __restrict__ x_sorted,
+                                                   NodeArrays nodes, float split_s,
+                                                   int32_t* __restrict__ violation,
+                                                   int32_t* __restrict__ hub_excl) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= *num_runs) return;
+  const int off = run_off[r], cnt = run_cnt[r];
+  const int hub = (int)hub_sorted[off];
+  const float4 hs = nodes.desc_sz[hub];
+  float h0 = hs.x, h1 = hs.y, h2 = hs.z;
+  int S = __float_as_int(hs.w);
+  bool bad = false;
+  auto absorb = [&](const float4& o, bool test) {
+    if (test) {   // equal constraints: DecideEdge keeps the edge (and drops constraints) beyond the split threshold
+      const float x = h0 - o.x, y = h1 - o.y, z = h2 - o.z;
+      if ((x * x + y * y + z * z) * (1.0f / 3.0f) > split_s) bad = true;
+    }
+    const int osz = __float_as_int(o.w);
+    const float denom = 1.0f / (float)(osz + S);
+    const float ca = (float)osz * denom;
+    const float cb = (float)S * denom;
+    h0 = ca * o.x + cb * h0;
+    h1 = ca * o.y + cb * h1;
+    h2 = ca * o.z + cb * h2;
+    S += osz;
+  };
+  int k = 0;
+  for (; k + 4 <= cnt; k += 4) {
+    float4 o[4];
+    uint32_t xv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      xv[q] = x_sorted[off + k + q];
+      o[q] = nodes.desc_sz[xv[q] & ~(uint32_t)kHubTestBit];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) absorb(o[q], (xv[q] & (uint32_t)kHubTestBit) != 0);
+  }
+  for (; k < cnt; ++k) {
+    const uint32_t xv = x_sorted[off + k];
+    absorb(nodes.desc_sz[xv & ~(uint32_t)kHubTestBit], (xv & (uint32_t)kHubTestBit) != 0);
+  }
+  if (bad) {
+    atomicOr(violation, kHubVioSplit);
+    HubExclude(hub_excl, nodes.flags, hub);
+  }
+  nodes.desc_sz[hub] = make_float4(h0, h1, h2, __int_as_float(S));
+}
+
+// The hub marks of a stage go with the stage: off both roots of every active edge.
+__global__ __launch_bounds__(256) void k_hub_clear(int n, const int32_t* __restrict__ a_ra,
+                                                    const int32_t* __restrict__ a_rb, NodeArrays nodes) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ra = a_ra[i], rb = a_rb[i];
+  if (nodes.hub8[ra]) nodes.hub8[ra] = 0;
+  if (nodes.hub8[rb]) nodes.hub8[rb] = 0;
+  // (several edges clear the same region: each writes what the others write)
+  const int fa = nodes.flags[ra], fb = nodes.flags[rb];
+  if (fa & kFlagHubBroken) nodes.flags[ra] = (uint8_t)(fa & ~(int)kFlagHubBroken);
+  if (fb & kFlagHubBroken) nodes.flags[rb] = (uint8_t)(fb & ~(int)kFlagHubBroken);
+}
+
+// The regions on the exclusion list are no hubs for the rest of the chunk (device_graph.h:
+// kFlagHubExcluded); launched again after every undone stage -- the restored flags are older.
+__global__ __launch_bounds__(256) void k_hub_exclude(const int32_t* __restrict__ excl, NodeArrays nodes) {
+  const int n = min(excl[0], kHubExclCap);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int r = excl[1 + i];
+    if (!(nodes.flags[r] & kFlagHubExcluded)) AtomicOrFlags(nodes.flags, r, kFlagHubExcluded);
+  }
+}
+
+// A region that the filter put on the exclusion list (an edge needs its exact state) while other
+// edges made it a hub: known before any worker runs -- bit 1 of the word the host waits for; bit 2: the
+// list overflowed, which regions are broken is not known; bit 3: the list is not empty (regions carry
+// kFlagHubBroken, to be cleared with the stage's other marks).
+__global__ __launch_bounds__(256) void k_hub_check(const int32_t* __restrict__ excl, NodeArrays nodes,
+                                                    int32_t* __restrict__ num_hub) {
+  const int cnt = excl[0];
+  if (cnt > 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(num_hub, cnt > kHubExclCap ? 12 : 8);
+  const int n = min(cnt, kHubExclCap);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    if (nodes.hub8[excl[1 + i]]) {
+      atomicOr(num_hub, 2);
+      break;
+    }
+  }
+}
+
+// ... and the marks are taken off again when the stage is through (the list starts empty).
+__global__ __launch_bounds__(256) void k_hub_unexclude(int32_t* __restrict__ excl, NodeArrays nodes) {
+  const int n = min(excl[0], kHubExclCap);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    AtomicAndFlags(nodes.flags, excl[1 + i], 0xff & ~(kFlagHubExcluded | kFlagHubBroken));
+  }
+}
+__global__ void k_hub_excl_reset(int32_t* __restrict__ excl) { excl[0] = 0; }
+void ResetHubExclusions(MergeScratch& S, NodeArrays nodes, hipStream_t s) {
+  if (!S.hub_excl) return;
+  hipLaunchKernelGGL(k_hub_unexclude, dim3(16), dim3(256), 0, s, S.hub_excl, nodes);
+  hipLaunchKernelGGL(k_hub_excl_reset, dim3(1), dim3(1), 0, s, S.hub_excl);
+  VSG_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------
 // Host driver of one stage.
 // ------------------------------------------------------------------------------------------
 static inline unsigned Blocks(int n) { return (unsigned)((n + 255) / 256); }
@@ -844,8 +1051,19 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   }
   if (n_b <= 0) return;
   const int bucket_hi = S.group_hi > bucket ? S.group_hi : bucket + 1;
-  int32_t* d_num_ti = TakeStageScalars(S, 2);   // fresh counters per stage: nothing to clear
+  int32_t* d_num_ti = TakeStageScalars(S, 5);   // fresh counters per stage: nothing to clear
   int32_t* d_violation = d_num_ti + 1;
+  int32_t* d_num_hub = d_num_ti + 2;
+  int32_t* d_hub_count = d_num_ti + 3;
+  int32_t* d_hub_runs = d_num_ti + 4;
+  // Hubs (device_graph.h: kFlagHub) only in stages that the tree replay cannot take (it works on the
+  // region states directly) and never in the conservative replay of a violated stage.
+  const bool spine_possible = S.spine_min > 0 && !S.spine_off && bucket < *S.spine_limit_bucket &&
+                              !(bucket < 2 && S.spine_low_skip[bucket]);
+  const bool try_hubs = S.hubs && !S.hubs_off && inert_mode != 0 && !spine_possible && S.wide_min <= 0;
+  // (the list of a stage starts empty: what the filter of an earlier stage put there without
+  // consequences -- a broken region that no edge used as a hub -- is not excluded from this one)
+  if (try_hubs && S.hub_attempt == 0) VSG_HIP(hipMemsetAsync(S.hub_excl, 0, sizeof(int32_t), s));
   int32_t* d_num_leaders = S.num_active + 5;
   // The stage's non-empty (bucket, list) segments, from the host copy of the bucket table.
   FilterSegs segs = {nullptr, nullptr, nullptr, 0};
@@ -888,21 +1106,22 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   if (ef0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ef0], s));
   hipLaunchKernelGGL(k_filter, dim3((unsigned)((n_b + kFilterEdges - 1) / kFilterEdges)), dim3(256), 0, s, bucket, bucket_hi, j0, n_b, lists,
                      bucket_base, S.bucket_prefix, list_slot_base, kept_all, nodes, P, inert_mode, S.cc, S.e_ra, S.e_rb, S.e_gpos,
-                     S.masks, d_num_ti, segs);
+                     S.masks, d_num_ti, segs, try_hubs ? 1 : 0, d_num_hub, S.hub_excl);
   const int ef1 = NextEvent(S);
   if (ef1 >= 0) {
     VSG_HIP(hipEventRecord((*S.ev_pool)[ef1], s));
     S.ev_filter->emplace_back(ef0, ef1);
   }
+  if (try_hubs) hipLaunchKernelGGL(k_hub_check, dim3(16), dim3(256), 0, s, S.hub_excl, nodes, d_num_hub);
   ExclusiveSum(S.scan, S.masks.block_cnt, S.block_off, (int)Blocks(n_b), s);
-  int h[2] = {0, 0};   // num_active, num_ti
+  int h[3] = {0, 0, 0};   // num_active, num_ti, hubs (k_hub_check)
   for (int attempt = 0;; ++attempt) {
     const MailSlot m_active = NextMail(*S.mail);
     hipLaunchKernelGGL(k_compact_active, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks, S.block_off,
                        S.e_ra, S.e_rb, S.e_gpos, S.a_ra, S.a_rb, S.a_gpos, S.num_active, d_num_ti, m_active.dev,
-                       m_active.seq, S.active_cap);
+                       m_active.seq, S.active_cap, d_num_hub);
     VSG_HIP(hipGetLastError());
-    MailWait(m_active, 2, h, s);
+    MailWait(m_active, 3, h, s);
     if (h[0] <= S.active_cap) break;
     // the arrays that hold active edges are too small for this stage: enlarge them, compact again
     VSG_REQUIRE(attempt == 0 && S.grow_active && S.grow_active(h[0]) && h[0] <= S.active_cap, -4,
@@ -910,6 +1129,12 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   }
   const int n_active = h[0];
   const int n_ti = h[1];
+  const bool hubs_used = try_hubs && (h[2] & 1) != 0;
+  auto clear_hub_marks = [&]() {
+    if (try_hubs && (h[2] & 9) != 0 && n_active > 0) {
+      hipLaunchKernelGGL(k_hub_clear, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra, S.a_rb, nodes);
+    }
+  };
   auto clear_marks = [&]() {
     if (n_ti > 0) {
       hipLaunchKernelGGL(k_clear_tentative, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks, S.e_ra,
@@ -920,6 +1145,42 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     clear_marks();
     return;
   }
+  // A stage whose hubs broke a rule is run again with the regions that did as ordinary regions (they
+  // are on the exclusion list); after kHubMaxAttempts of those -- or when the list has overflowed --
+  // without hubs.  (Called with the stage undone.)
+  auto retry_without_broken_hubs = [&](int violated, int work, bool list_complete) {
+    for (int q = 0; q < 6; ++q) S.hub_reasons[q] += (violated >> (2 + q)) & 1;
+    ++S.hub_retries;
+    if (getenv("VSG_DEBUG_STAGES")) {
+      int cnt = 0;
+      VSG_HIP(hipMemcpyAsync(&cnt, S.hub_excl, sizeof(int), hipMemcpyDeviceToHost, s));
+      VSG_HIP(hipStreamSynchronize(s));
+      std::fprintf(stderr, "[vsg]   hub rule violated (mask %x) in b=%d n=%d work %d, attempt %d, %d regions excluded so far\n",
+                   violated, bucket, n_b, work, S.hub_attempt, cnt);
+    }
+    int& depth = (list_complete && S.hub_attempt + 1 < kHubMaxAttempts) ? S.hub_attempt : S.hubs_off;
+    if (&depth == &S.hub_attempt) {
+      hipLaunchKernelGGL(k_hub_exclude, dim3(16), dim3(256), 0, s, S.hub_excl, nodes);
+    }
+    ++depth;
+    RunBucketStage(bucket, j0, n_b, lists, bucket_base, list_slot_base, kept_all, nodes, P, inert_mode, S, s, info);
+    --depth;
+    // (the exclusions go with the stage: a hub that was about to inherit a constraint, or to meet
+    // its like, is an ordinary hub again once that edge is behind it)
+    if (S.hub_attempt == 0 && S.hubs_off == 0) ResetHubExclusions(S, nodes, s);
+  };
+  if (hubs_used && (h[2] & 6) != 0) {
+    // The filter itself found a hub whose exact state an edge needs: nothing has been replayed yet.
+    hipLaunchKernelGGL(k_reset_cc, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra, S.a_rb, S.cc,
+                       d_violation, nullptr, 0u);
+    hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks, S.e_gpos, kept_all);
+    clear_marks();
+    clear_hub_marks();
+    VSG_HIP(hipGetLastError());
+    retry_without_broken_hubs(kHubVioBroken, n_active, (h[2] & 4) == 0);
+    return;
+  }
+  if (hubs_used && info) ++info->hub_stages;
 
   // Run leaders (inert_mode 0 is the conservative replay of a violated stage: every edge).
   // In a graph with constraints a run-compressed stage has to stay undoable (constrained split).
@@ -965,7 +1226,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   const bool spine = !spine_in.segs.empty();
   // A stage that settles edges tentatively, replays run leaders only or relies on the spine
   // structure has to stay undoable.
-  const bool optimistic = ((inert_mode == 2) && (n_ti > 0 || rle)) || spine;
+  const bool optimistic = ((inert_mode == 2) && (n_ti > 0 || rle)) || spine || hubs_used;
   if (optimistic) {
     hipLaunchKernelGGL(k_backup_roots, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, w_rb,
                        nodes, S.bk_ds, S.bk_cons, S.bk_flags, S.stats);
@@ -980,6 +1241,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   T.rle = rle ? 1 : 0;
   T.side = 0;
   T.relax = S.chain_relax;
+  T.hubs = hubs_used ? 1 : 0;
   // Replayed edges in component order; the scratch arrays of the earlier steps are free by now.
   int32_t* s_ra = reinterpret_cast<int32_t*>(S.a_comp);
   int32_t* s_rb = reinterpret_cast<int32_t*>(S.a_idx);
@@ -1015,6 +1277,13 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   wa.work_ctl = wa.work_list ? TakeZeroed(S, 2 * kWaveClasses) : nullptr;
   wa.wide_min = S.wide_min;
   wa.wide_waves = S.wide_waves;
+  if (hubs_used) {
+    // (the sorted component keys are free once the runs are known: one mark per work edge)
+    wa.hub_mark = reinterpret_cast<int32_t*>(S.s_comp);
+    wa.s_seq = S.s_idx;
+    wa.hub_excl = S.hub_excl;
+    VSG_HIP(hipMemsetAsync(wa.hub_mark, 0xFF, (size_t)n_work * sizeof(int32_t), s));
+  }
   auto general_workers = [&](const WorkerArgs& w, int small_threads, int grid, hipStream_t s) {
     if (w.wave_min == w.small_seg) {
       hipLaunchKernelGGL(k_merge_small, dim3(Blocks(small_threads)), dim3(256), 0, s, w.num_segs,
@@ -1023,7 +1292,8 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
                          w.work_ctl,
                          // (the largest size class starts where the wide worker does, if that is lower)
                          (w.wide_min > 0 && w.wide_min < kWaveClassMin0) ? std::max(w.wide_min, w.small_seg + 1)
-                                                                        : kWaveClassMin0);
+                                                                        : kWaveClassMin0,
+                         w.hub_mark, w.s_seq, w.hub_excl);
     }
     // the wave worker is timed on the stream it runs on
     const int ew0 = NextEvent(S);
@@ -1068,6 +1338,28 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     }
     VSG_HIP(hipStreamWaitEvent(s, S.aux_join, 0));
   }
+  if (hubs_used) {
+    // What the hubs absorbed, in sequence order, grouped by hub (stable sort), one thread per hub --
+    // before the violation word is read: an absorption that was subject to the split test may fail it.
+    uint32_t* x_list = S.a_comp;                                   // (the workers' inputs are free now)
+    uint32_t* key_list = S.a_idx;
+    uint32_t* key_sorted = reinterpret_cast<uint32_t*>(S.e_apos);
+    uint32_t* x_sorted = S.s_idx;
+    int32_t* run_off = reinterpret_cast<int32_t*>(S.seg_key);      // (the work list)
+    int32_t* run_cnt = reinterpret_cast<int32_t*>(S.s_comp);       // (the marks, once they are compacted)
+    const MailSlot m_hub = NextMail(*S.mail);
+    FusedScan(S.scan, HubMarkValue{wa.hub_mark}, HubMarkEmit{wa.hub_mark, nodes.parent, x_list, key_list},
+              HubMarkFinish{d_hub_count, m_hub.dev, m_hub.seq}, n_work, s);
+    int n_abs = 0;
+    MailWait(m_hub, 1, &n_abs, s);
+    if (n_abs > 0) {
+      SortPairsU32(S.cub_temp, S.cub_temp_bytes, key_list, key_sorted, x_list, x_sorted, n_abs, S.node_key_bits, s);
+      RunsOfSortedKeys(S.scan, key_sorted, n_abs, run_off, run_cnt, d_hub_runs, s);
+      hipLaunchKernelGGL(k_hub_apply, dim3((unsigned)((n_abs + 63) / 64)), dim3(64), 0, s, d_hub_runs, run_off,
+                         run_cnt, key_sorted, x_sorted, nodes, T.split_s, d_violation, S.hub_excl);
+    }
+    if (info) info->hub_absorbed += n_abs;
+  }
   MailSlot m_vio = {nullptr, nullptr, 0};
   if (optimistic) m_vio = NextMail(*S.mail);
   hipLaunchKernelGGL(k_reset_cc, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, w_rb, S.cc, d_violation,
@@ -1084,6 +1376,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
                          nodes, S.bk_ds, S.bk_cons, S.bk_flags, S.stats);
       hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks, S.e_gpos, kept_all);
       clear_marks();
+      clear_hub_marks();   // (the restored flags carry the marks the filter had set)
       VSG_HIP(hipGetLastError());
       if (spine && violated == 2 && !S.force_rollback) {
         // Only the tree replay's assumption failed (an edge of a large component was kept): the
@@ -1096,6 +1389,13 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
         RunBucketStage(bucket, j0, n_b, lists, bucket_base, list_slot_base, kept_all, nodes, P, inert_mode, S,
                        s, info);
         S.spine_off = off;
+        return;
+      }
+      if (hubs_used && (violated & kHubViolationMask) != 0 && (violated & ~kHubViolationMask) == 0 &&
+          !S.force_rollback) {
+        // Only a hub rule failed (an edge met a hub that it would have changed, a split test on a hub
+        // did not pass).
+        retry_without_broken_hubs(violated, n_work, true);
         return;
       }
       if (bucket_hi > bucket + 1) {
@@ -1147,6 +1447,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
                        S.lead_pos, S.a_gpos, S.l_gpos, kept_all);
   }
   clear_marks();
+  clear_hub_marks();
   VSG_HIP(hipGetLastError());
 }
 

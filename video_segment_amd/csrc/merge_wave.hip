@@ -86,6 +86,7 @@ struct WaveQueue {
   int32_t ra[kQueue];
   int32_t rb[kQueue];
   uint32_t gpos[kQueue];
+  uint32_t seq[kQueue];   // sequence number of the edge among the stage's work edges (hubs: WorkerArgs::s_seq)
   int produced;   // entries pushed by the producer wave (monotonic)
   int consumed;   // entries taken by the consumer wave (monotonic)
   int done;       // the producer has read the whole component
@@ -96,6 +97,7 @@ struct WaveStage {
   int32_t ra[128];
   int32_t rb[128];
   uint32_t gpos[128];
+  uint32_t seq[128];
 };
 
 // Orders the LDS accesses of the lanes of ONE wavefront (they execute in order in hardware; this
@@ -133,7 +135,8 @@ template <bool kDbg>
 __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, const NodeArrays& nodes,
                                              const StageThr& T, int optimistic, int32_t* violation,
                                              unsigned long long* stats, int dbg_flags, int lane,
-                                             bool valid, int sa, int sb, WaveCounters& C) {
+                                             bool valid, int sa, int sb, WaveCounters& C, uint32_t seq,
+                                             int32_t* hub_mark, int32_t* hub_excl) {
   auto Clock = []() -> unsigned long long { return kDbg ? __builtin_readcyclecounter() : 0ull; };
   bool pending = valid;
   int hot = -1;   // wave-uniform slot of the round's hot region
@@ -162,6 +165,8 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
       const int sza = __float_as_int(tab.ds[fa].w), szb = __float_as_int(tab.ds[fb].w);
       hot = (sza >= szb) ? fa : fb;
       if (kDbg && (dbg_flags & 4)) hot = -1;
+      // (an edge on a hub of the stage is decided by its other region alone: no hot region then)
+      if (T.hubs && ((tab.flags[fa] | tab.flags[fb]) & kFlagHub)) hot = -1;
     }
     if (round > 140u) {   // cannot happen (the earliest pending lane commits, after at most one failed chain test): report
       if (lane == 0) atomicAdd(&stats[22], 1ull);
@@ -183,6 +188,11 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
       A = TabLoad(tab, sa);
       B = TabLoad(tab, sb);
     }
+    // Hub ends (kFlagHub): never reserved for real -- every edge on a hub is decided by its other
+    // region alone (HubEdge), so edges on the same hub do not wait for each other.
+    const bool a_hub = T.hubs && pending && (A.flags & kFlagHub);
+    const bool b_hub = T.hubs && pending && (B.flags & kFlagHub);
+    if ((a_hub && (A.flags & kFlagHubBroken)) || (b_hub && (B.flags & kFlagHubBroken))) atomicOr(violation, kHubVioBroken);
     // An edge that is certainly *kept without changing anything* (NoopPair: different constraints,
     // or one region finalized and both large) does not have to wait for earlier edges of the same
     // kind *that are committed in the same round*, only for earlier edges whose outcome is open.
@@ -225,11 +235,11 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
       }
       if (__ballot(noop_l)) {
         if (pending && !noop_l) {
-          if (!a_hot) {
+          if (!a_hot && !a_hub) {
             atomicMin(&tab.res2[sa], key);
             atomicMin(&tab.res3[sa], key);
           }
-          if (!b_hot) {
+          if (!b_hot && !b_hub) {
             atomicMin(&tab.res2[sb], key);
             atomicMin(&tab.res3[sb], key);
           }
@@ -239,15 +249,19 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
         WaveSync();
         bool cand = noop_l && !lit;
         for (;;) {
-          const bool ok = cand && tab.res2[sa] > key && tab.res2[sb] > key;
+          const bool ok = cand && (a_hub || tab.res2[sa] > key) && (b_hub || tab.res2[sb] > key);
           const bool drop = cand && !ok;
           cand = ok;
           if (!__ballot(drop)) break;
           if (drop) {
-            atomicMin(&tab.res2[sa], key);
-            atomicMin(&tab.res2[sb], key);
-            atomicMin(&tab.res3[sa], key);
-            atomicMin(&tab.res3[sb], key);
+            if (!a_hub) {
+              atomicMin(&tab.res2[sa], key);
+              atomicMin(&tab.res3[sa], key);
+            }
+            if (!b_hub) {
+              atomicMin(&tab.res2[sb], key);
+              atomicMin(&tab.res3[sb], key);
+            }
           }
           WaveSync();
         }
@@ -259,8 +273,8 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
     }
     // own_x: this lane is the earliest pending edge on region x (the hot region is not reserved)
     const unsigned long long ph1 = Clock();
-    const bool own_a = pending && !a_hot && res_a == key;
-    const bool own_b = pending && !b_hot && res_b == key;
+    const bool own_a = pending && !a_hot && (res_a == key || a_hub);
+    const bool own_b = pending && !b_hot && (res_b == key || b_hub);
     const int oa = (int)(res_a & 63u), ob = (int)(res_b & 63u);   // owners (earlier lanes)
     RState Hs = {}, P = {};
     int ps = 0;            // partner slot of a chain lane
@@ -325,7 +339,7 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
       const bool part_b = plain_b && (noop_l ? (noop_b && free_p && a_hot) : own_b);
       const bool merge_a = part_a && !noop_a && (A.cons >= 0 || !fin_a || A.sz < T.min_size);
       const bool merge_b = part_b && !noop_b && (B.cons >= 0 || !fin_b || B.sz < T.min_size);
-      const bool abs_a = pending && !own_a, abs_b = pending && !own_b;   // may be absorbed
+      const bool abs_a = pending && !own_a && !a_hub, abs_b = pending && !own_b && !b_hub;   // may be absorbed
       // A lane merges into the chain when one end is effectively hot and the other end is a
       // partner it owns (merge_x implies own_x, so that end can only be hot literally).  Hence a
       // lane depends on at most ONE earlier lane -- the owner of its not-owned end -- and the
@@ -408,6 +422,30 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
     }
 
     const unsigned long long ph3 = Clock();
+    // ---- lanes on a hub of the stage: decided by the other region alone (merge_common.h: HubEdge) --
+    if (n_win && (a_hub || b_hub)) {
+      const RState& x = a_hub ? B : A;
+      const RState& h = a_hub ? A : B;
+      const int act = (a_hub && b_hub) ? HubHubEdge(A.cons, A.flags, B.cons, B.flags)
+                                       : HubEdge(x, h.cons, h.flags, h.sz, T);
+      if (act >= kHubViolation) {
+        atomicOr(violation, act);
+        if (a_hub) HubExclude(hub_excl, nodes.flags, tab.key[sa]);
+        if (b_hub) HubExclude(hub_excl, nodes.flags, tab.key[sb]);
+      } else if (act == kHubKeep) {
+        my_kept = true;
+      } else {
+        const int xs = a_hub ? sb : sa, hs = a_hub ? sa : sb;
+        // (the state the hub absorbs is read from memory after the workers: k_hub_apply)
+        if (tab.flags[xs] & kTabDirty) StoreState(nodes, tab.key[xs], x);
+        CommitLoser(tab, nodes, xs, hs);
+        if (x.flags & kFlagTentative) AtomicOrFlags(nodes.flags, tab.key[hs], kFlagTentative);
+        hub_mark[seq] = tab.key[xs] | (act == kHubAbsorbTest ? kHubTestBit : 0);
+        if (act == kHubAbsorbTest) ++C.n_forced; else ++C.n_small;
+      }
+      pending = false;
+      n_win = false;
+    }
     // ---- lanes that own both regions: generic edge ------------------------------------------
     if (n_win) {
       const RState& s1 = A;
@@ -645,7 +683,10 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
                                                     unsigned long long* __restrict__ stats,
                                                     int dbg_flags, int wave_min, int wave_max,
                                                     const uint32_t* __restrict__ work_list, int work_cap,
-                                                    int32_t* __restrict__ work_ctl) {
+                                                    int32_t* __restrict__ work_ctl,
+                                                    const uint32_t* __restrict__ s_seq,
+                                                    int32_t* __restrict__ hub_mark,
+                                                    int32_t* __restrict__ hub_excl) {
   __shared__ WaveTable tab;
   auto Clock = []() -> unsigned long long { return kDbg ? __builtin_readcyclecounter() : 0ull; };
   __shared__ WaveQueue queue;
@@ -722,7 +763,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
         const unsigned long long pt1 = Clock();
         cyc_wait += pt1 - pt0;
         int xa[kFill], xb[kFill], ca[kFill], cb[kFill];
-        uint32_t gp[kFill];
+        uint32_t gp[kFill], sq[kFill];
         bool vd[kFill];
 #pragma unroll
         for (int k = 0; k < kFill; ++k) {
@@ -731,6 +772,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           xa[k] = vd[k] ? s_ra[p] : 0;
           xb[k] = vd[k] ? s_rb[p] : 0;
           gp[k] = vd[k] ? s_gpos[p] : 0u;
+          sq[k] = (vd[k] && s_seq) ? s_seq[p] : 0u;
           ca[k] = xa[k];
           cb[k] = xb[k];
         }
@@ -764,6 +806,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
             queue.ra[slot] = ca[k];
             queue.rb[slot] = cb[k];
             queue.gpos[slot] = gp[k];
+            queue.seq[slot] = sq[k];
           }
           produced += (int)__popcll(m);
         }
@@ -815,17 +858,19 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
         const int t = avail < want ? avail : want;
         if (n_raw + t == 0) break;
         int ca = 0, cb = 0;
-        uint32_t cg = 0;
+        uint32_t cg = 0, cq = 0;
         const bool cand = lane < n_raw + t;
         if (lane < n_raw) {
           ca = stage.ra[lane];
           cb = stage.rb[lane];
           cg = stage.gpos[lane];
+          cq = stage.seq[lane];
         } else if (cand) {
           const int slot = (consumed + lane - n_raw) & (kQueue - 1);
           ca = queue.ra[slot];
           cb = queue.rb[slot];
           cg = queue.gpos[slot];
+          cq = queue.seq[slot];
         }
         for (bool more = cand; more;) {
           const int pa = nodes.parent[ca], pb = nodes.parent[cb];
@@ -845,6 +890,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
           stage.ra[pos] = ca;
           stage.rb[pos] = cb;
           stage.gpos[pos] = cg;
+          stage.seq[pos] = cq;
         }
         if (kDbg && lane == 0) {
           dbg_taken += (unsigned)(n_raw + t);
@@ -864,26 +910,29 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
       const int take = n_valid < 64 ? n_valid : 64;
       const bool valid = lane < take;
       int ra = -1, rb = -1;
-      uint32_t gpos = 0;
+      uint32_t gpos = 0, seq = 0;
       if (valid) {
         ra = stage.ra[lane];
         rb = stage.rb[lane];
         gpos = stage.gpos[lane];
+        seq = stage.seq[lane];
       }
       n_raw = n_valid - take;
       if (n_raw > 0) {   // move the rest to the front; it is re-validated by the next pass
         int xa = 0, xb = 0;
-        uint32_t xg = 0;
+        uint32_t xg = 0, xq = 0;
         if (lane < n_raw) {
           xa = stage.ra[64 + lane];
           xb = stage.rb[64 + lane];
           xg = stage.gpos[64 + lane];
+          xq = stage.seq[64 + lane];
         }
         WaveSync();
         if (lane < n_raw) {
           stage.ra[lane] = xa;
           stage.rb[lane] = xb;
           stage.gpos[lane] = xg;
+          stage.seq[lane] = xq;
         }
       }
       WaveSync();
@@ -891,7 +940,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
       int sa = 0, sb = 0;     // table slots of the current roots of the two end regions
       int mine_a = -1, mine_b = -1;   // slots this lane inserted (it writes them back and frees them)
       if (pending) {
-        const RState A = LoadState(nodes, ra), B = LoadState(nodes, rb);   // both in flight
+        const RState A = LoadStateHub(nodes, ra, T.hubs), B = LoadStateHub(nodes, rb, T.hubs);   // both in flight
         bool ins_a, ins_b;
         sa = TabInsert(tab, ra, ins_a);
         sb = TabInsert(tab, rb, ins_b);
@@ -912,7 +961,7 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
       cyc_load += bt1 - bt0b;
 
       const bool my_kept = ReplayRounds<kDbg>(tab, chain_buf, nodes, T, optimistic, violation, stats,
-                                              dbg_flags, lane, valid, sa, sb, C);
+                                              dbg_flags, lane, valid, sa, sb, C, seq, hub_mark, hub_excl);
       WaveSync();
 
       if (valid && my_kept) kept_all[gpos] = 1;
@@ -992,12 +1041,12 @@ void LaunchMergeWave(int grid, const WorkerArgs& a, bool instrumented, int dbg_f
     hipLaunchKernelGGL(k_merge_wave<true>, dim3(grid), dim3(128), 0, s, a.num_segs, a.seg_off,
                        a.seg_cnt, a.s_ra, a.s_rb, a.s_gpos, a.nodes, a.kept_all, a.T, a.optimistic,
                        a.violation, a.stats, dbg_flags, a.wave_min, a.wave_max, a.work_list, a.work_cap,
-                       a.work_ctl);
+                       a.work_ctl, a.s_seq, a.hub_mark, a.hub_excl);
   } else {
     hipLaunchKernelGGL(k_merge_wave<false>, dim3(grid), dim3(128), 0, s, a.num_segs, a.seg_off,
                        a.seg_cnt, a.s_ra, a.s_rb, a.s_gpos, a.nodes, a.kept_all, a.T, a.optimistic,
                        a.violation, a.stats, 0, a.wave_min, a.wave_max, a.work_list, a.work_cap,
-                       a.work_ctl);
+                       a.work_ctl, a.s_seq, a.hub_mark, a.hub_excl);
   }
   VSG_HIP(hipGetLastError());
 }
