@@ -341,6 +341,18 @@ int vsg_graph_merge_stats(const vsg_graph* g, int64_t* forced_regular_small);
 int vsg_graph_timings(const vsg_graph* g, vsg_timings* t);
 int vsg_graph_diagnostics(const vsg_graph* g, vsg_diagnostics* d);
 
+/* Test hook: the merge path's stable radix sort of (key, value) pairs by the low `end_bit` bits of
+ * the keys (csrc/radix_sort.hip), on host arrays of n elements, run on `device`.  The reference sorts
+ * nothing here -- its per-bucket vectors are in order by construction (segmentation_graph.h:336);
+ * the sort is how the device path orders a stage's edges by component. */
+int vsg_debug_sort_pairs(const uint32_t* keys, const uint32_t* values, int n, int end_bit,
+                         uint32_t* keys_out, uint32_t* values_out, int device);
+/* ... with the implementation chosen (0: what the merge would use for n, 1: hand-written, 2: rocPRIM),
+ * repeated `reps` times; *avg_us = device time per sort (HIP events around the repetitions). */
+int vsg_debug_sort_pairs_timed(const uint32_t* keys, const uint32_t* values, int n, int end_bit,
+                               uint32_t* keys_out, uint32_t* values_out, int device, int impl, int reps,
+                               double* avg_us);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,9 @@ def test_chain_self_check_is_silent(vsg, monkeypatch, capfd):
                                  {"VSG_ACTIVE_CAP": "64", "VSG_SPINE_MIN": "32", "VSG_FORCE_ROLLBACK": "1"},
                                  # the wide worker (merge_wide.hip: several wavefronts per component in
                                  # lock-step rounds; off by default) on every component it can take
+                                 # the hand-written radix sort for every size / for none (csrc/radix_sort.hip)
+                                 {"VSG_SORT_HAND": "0:2000000000", "VSG_SPINE_MIN": "32", "VSG_SPINE_CHECK": "1"},
+                                 {"VSG_SORT_HAND": "1:0"},
                                  {"VSG_WIDE_MIN": "25"},
                                  {"VSG_WIDE_MIN": "40", "VSG_WIDE_WAVES": "2", "VSG_SPINE_MIN": "0"},
                                  {"VSG_WIDE_MIN": "25", "VSG_FORCE_ROLLBACK": "1", "VSG_SPINE_MIN": "64"}])

@@ -120,6 +120,7 @@ EXPORTED_SYMBOLS = [
     "vsg_graph_get_intervals", "vsg_graph_smoothed",
     "vsg_graph_spatial_buckets", "vsg_graph_temporal_buckets", "vsg_graph_node_roots",
     "vsg_graph_merge_stats", "vsg_graph_timings", "vsg_graph_diagnostics",
+    "vsg_debug_sort_pairs", "vsg_debug_sort_pairs_timed",
 ]
 
 
@@ -188,6 +189,9 @@ def lib():
     L.vsg_regionseg_process_frame.argtypes = [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t, vp, C.POINTER(C.c_int)]
     L.vsg_regionseg_result_bytes.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.vsg_bgr_to_lab.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp]
+    L.vsg_debug_sort_pairs.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int]
+    L.vsg_debug_sort_pairs_timed.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(C.c_double)]
     L.vsg_graph_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.vsg_graph_destroy.argtypes = [vp]
     L.vsg_graph_add_frame_bgr.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_int]

@@ -635,6 +635,54 @@ int vsg_bgr_to_lab(const uint8_t* bgr, size_t stride, int width, int height, uin
   });
 }
 
+int vsg_debug_sort_pairs_timed(const uint32_t* keys, const uint32_t* values, int n, int end_bit,
+                               uint32_t* keys_out, uint32_t* values_out, int device, int impl, int reps,
+                               double* avg_us) {
+  return Guard([&] {
+    VSG_REQUIRE(keys && values && keys_out && values_out && n >= 0 && end_bit >= 1 && end_bit <= 32 && reps >= 1 &&
+                    impl >= 0 && impl <= 2,
+                VSG_ERR_INVALID, "bad argument");
+    RequireDevice(device);
+    DeviceGuard dg(ResolveDevice(device));
+    if (avg_us) *avg_us = 0;
+    if (n == 0) return;
+    vsg::DevBuf<uint32_t> k((size_t)n), v((size_t)n), ko((size_t)n), vo((size_t)n);
+    vsg::DevBuf<uint8_t> temp(vsg::SortPairsU32TempBytes(n));
+    hipStream_t s = nullptr;
+    VSG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct Owner {
+      hipStream_t& s;
+      hipEvent_t &e0, &e1;
+      ~Owner() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(s);
+      }
+    } owner{s, e0, e1};
+    VSG_HIP(hipEventCreate(&e0));
+    VSG_HIP(hipEventCreate(&e1));
+    VSG_HIP(hipMemcpyAsync(k.get(), keys, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    VSG_HIP(hipMemcpyAsync(v.get(), values, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    auto sort = impl == 1 ? vsg::SortPairsU32Hand : impl == 2 ? vsg::SortPairsU32Lib : vsg::SortPairsU32;
+    sort(temp.get(), temp.size(), k.get(), ko.get(), v.get(), vo.get(), n, end_bit, s);   // (warm-up)
+    VSG_HIP(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) sort(temp.get(), temp.size(), k.get(), ko.get(), v.get(), vo.get(), n, end_bit, s);
+    VSG_HIP(hipEventRecord(e1, s));
+    VSG_HIP(hipMemcpyAsync(keys_out, ko.get(), (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    VSG_HIP(hipMemcpyAsync(values_out, vo.get(), (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    VSG_HIP(hipStreamSynchronize(s));
+    float ms = 0;
+    VSG_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (avg_us) *avg_us = (double)ms * 1e3 / reps;
+  });
+}
+
+int vsg_debug_sort_pairs(const uint32_t* keys, const uint32_t* values, int n, int end_bit,
+                         uint32_t* keys_out, uint32_t* values_out, int device) {
+  return vsg_debug_sort_pairs_timed(keys, values, n, end_bit, keys_out, values_out, device, 0, 1, nullptr);
+}
+
 // ---- graph -------------------------------------------------------------------------------
 int vsg_graph_create(int width, int height, int max_frames, int l1, int device, vsg_graph** out) {
   return Guard([&] {

@@ -114,7 +114,15 @@ struct ScanScratch {
   int32_t* sums;   // [kScanMaxTiles]
 };
 
-// ---- sort_scan.hip (rocPRIM radix sort, and the 64-bit sort / unique of the read-out) -----------------
+// ---- radix_sort.hip: the stable (key, value) sort of the merge path, hand-written ----------------------
+// (sort_scan.hip: the rocPRIM 64-bit sort / unique of the read-out)
+// SortPairsU32 = the hand-written sort inside its window of sizes, the library outside (measured, radix_sort.hip).
+size_t SortPairsU32HandTempBytes(int n);
+void SortPairsU32Hand(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                      const uint32_t* vals_in, uint32_t* vals_out, int n, int end_bit, hipStream_t s);
+size_t SortPairsU32LibTempBytes(int n);
+void SortPairsU32Lib(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                     const uint32_t* vals_in, uint32_t* vals_out, int n, int end_bit, hipStream_t s);
 size_t SortPairsU32TempBytes(int n);
 void SortPairsU32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
                   const uint32_t* vals_in, uint32_t* vals_out, int n, int end_bit, hipStream_t s);
@@ -301,6 +309,7 @@ struct MergeScratch {
 // n zeroed ints (see ZeroPool) for kernels that are launched right away; when the current half of
 // the pool is used up all three streams are drained and the other half is cleared and taken over.
 int32_t* TakeZeroed(MergeScratch& S, size_t n);
+
 // n zeroed ints that stay intact until the stage that took them (at its entry) has ended.
 int32_t* TakeStageScalars(MergeScratch& S, size_t n);
 

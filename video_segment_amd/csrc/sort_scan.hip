@@ -1,18 +1,17 @@
-// sort_scan.hip -- thin wrappers around the rocPRIM/hipCUB device-wide radix sort (and the 64-bit
-// unique of the read-out).
+// sort_scan.hip -- thin wrappers around the rocPRIM/hipCUB 64-bit key sort and unique of the read-out
+// (the distinct neighbour pairs of a chunk, once per chunk boundary, when the pair hash table is not
+// used).
 //
-// The stable LSD radix sort is the one generic building block left from the library; scans, run
-// detection and compactions are hand-written and fused into the kernels around them
-// (scan_device.h), like every kernel that encodes the segmentation algorithm itself
-// (build_kernels.hip / merge_*.hip / readout_kernels.hip; the bucket sort of the edge slots:
-// edge_sort.hip).
+// Nothing on the merge path comes from the library any more: its stable (key, value) radix sort is
+// radix_sort.hip, scans, run detection and compactions are scan_device.h, the bucket sort of the edge
+// slots is edge_sort.hip.
 #include <hipcub/hipcub.hpp>
 
 #include "device_graph.h"
 
 namespace vsg {
 
-size_t SortPairsU32TempBytes(int n) {
+size_t SortPairsU32LibTempBytes(int n) {
   size_t bytes = 0;
   VSG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr,
                                              (uint32_t*)nullptr, (const uint32_t*)nullptr,
@@ -20,8 +19,8 @@ size_t SortPairsU32TempBytes(int n) {
   return bytes;
 }
 
-void SortPairsU32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                  const uint32_t* vals_in, uint32_t* vals_out, int n, int end_bit, hipStream_t s) {
+void SortPairsU32Lib(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                     const uint32_t* vals_in, uint32_t* vals_out, int n, int end_bit, hipStream_t s) {
   VSG_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in,
                                              vals_out, n, 0, end_bit, s));
 }
