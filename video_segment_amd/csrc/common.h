@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "device_cache.h"
@@ -40,6 +42,18 @@ struct Error : std::runtime_error {
   do {                                                                                   \
     if (!(cond)) ::vsg::Throw((code), std::string(msg) + " [" #cond "]");                \
   } while (0)
+
+// Upper bound on the host threads of one parallel section of the chunk boundary (region tables, tube
+// analysis, rasters): VSG_HOST_THREADS, or a share of the machine that leaves room for one process per
+// GPU of an 8-GPU node -- 16 at least, 48 at most.
+inline int HostThreadCap() {
+  static const int cap = [] {
+    if (const char* e = getenv("VSG_HOST_THREADS")) return std::max(1, atoi(e));
+    const int hw = (int)std::thread::hardware_concurrency();
+    return std::max(16, std::min(hw / 8, 48));
+  }();
+  return cap;
+}
 
 // Simple owning device buffer.  The block comes from / goes back to the process-wide cache
 // (device_cache.h): a closed handle's memory is adopted by the next one instead of being unmapped.

@@ -69,8 +69,8 @@ DenseGraphHip::DenseGraphHip(int W, int H, int max_frames, bool l1, hipStream_t 
   hist_sums_.alloc(EdgeSortSumInts(wh_) + 1);
   scalars_.alloc(32);
   stats_.alloc(96);
-  hub_excl_.alloc(kHubExclCap + 4);
-  VSG_HIP(hipMemsetAsync(hub_excl_.get(), 0, sizeof(int32_t), stream_));   // (the count; blocks of the cache are not zeroed)
+  hub_excl_.alloc(kHubListInts);
+  VSG_HIP(hipMemsetAsync(hub_excl_.get(), 0, 4 * sizeof(int32_t), stream_));   // (the count; blocks of the cache are not zeroed)
   {
     // mailbox: 256 slots of four words + a list of 2 * 4095 ints, mapped and coherent (the device
     // writes it while kernels run, the host polls it)
@@ -710,15 +710,24 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     S.bucket_base_host = getenv("VSG_FILTER_SEGS") && atoi(getenv("VSG_FILTER_SEGS")) == 0 ? nullptr
                                                                                           : bucket_base_host_.data();
     S.list_off_host = list_off_host_.data();
+    S.list_slot_base_host = list_slot_base_.data();
     S.seg_dev = seg_table_dev_.get();
     S.seg_cap = seg_table_dev_.size();
     S.seg_host = &seg_table_host_;
   }
   if (++window_target_age_ > 8) {
     window_target_age_ = 0;
-    for (auto& t : window_target_) {
-      if (t != 0 && t != kNoWindowTarget) t = t * 2 > (1ll << 28) ? 0 : t * 2;
+    // A target grows again only on evidence of slack: the largest component of the bucket's stages over
+    // the chunks since the last look was a quarter of the limit or less.  (Unconditionally, as up to
+    // round 5, the targets of a stationary noisy input drifted upwards -- doubled here, halved twice
+    // without the largest component falling by 60 %, which is how a percolating bucket looks between
+    // one stage and the next, restored and frozen one doubling higher -- and a stream of 20 chunks was
+    // back at one-second merges: round 6, 400 frames of the +-40 noise input.)
+    for (size_t b = 0; b < window_target_.size(); ++b) {
+      int64_t& t = window_target_[b];
+      if (t != 0 && t != kNoWindowTarget && window_peak_[b] <= 4096) t = t * 2 > (1ll << 28) ? 0 : t * 2;
     }
+    std::fill(window_peak_.begin(), window_peak_.end(), 0);
     std::fill(window_last_seg_.begin(), window_last_seg_.end(), 0);
     std::fill(window_frozen_.begin(), window_frozen_.end(), 0);
     std::fill(window_unpaid_.begin(), window_unpaid_.end(), 0);
@@ -745,6 +754,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
       window_last_seg_.assign(kNumBuckets + 1, 0);
       window_frozen_.assign(kNumBuckets + 1, 0);
       window_unpaid_.assign(kNumBuckets + 1, 0);
+      window_peak_.assign(kNumBuckets + 1, 0);
     }
     if (window_target_[b] != 0) {
       wave_target_active_ = window_target_[b];
@@ -772,8 +782,11 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
         std::fprintf(stderr, "[vsg]   window: max wave segment %d, target %lld active (density %.4f), limited %d\n",
                      info.max_wave_segment, (long long)wave_target_active_, last_density_, (int)limited);
       }
-      if (measure && adapt_windows && (measure > 1 || info.replayed > 16384)) {
+      // (a stage that was run again with broken hubs as ordinary regions says nothing about the
+      // window: its large components are the neighbourhoods of those regions)
+      if (measure && adapt_windows && info.hub_retries == 0 && (measure > 1 || info.replayed > 16384)) {
         last_density_ = std::max((double)info.replayed / (double)std::max(n, 1), 1e-6);
+        window_peak_[b] = std::max(window_peak_[b], info.max_wave_segment);
         if (info.max_wave_segment > 16384 && !window_frozen_[b]) {
           // Halving has to pay: below the percolation threshold the largest component collapses
           // (184 K -> 57 K -> 10 K edges); the edges of ONE region against its neighbours just
@@ -850,6 +863,11 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
       }
     }
     window_target_[b] = wave_target_active_;
+    if (debug_stages && wave_target_active_ != kNoWindowTarget) {
+      std::fprintf(stderr, "[vsg]   bucket %d leaves target %lld (frozen %d, unpaid %d, last %d, peak %d)\n", b,
+                   (long long)wave_target_active_, (int)window_frozen_[b], (int)window_unpaid_[b], window_last_seg_[b],
+                   window_peak_[b]);
+    }
     if (b >= first_plain) {
       if (group_active < 2048) {
         group_width = std::min(group_width * 4, 512);
@@ -893,9 +911,9 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
                  "cuts %llu; optimistic stages %lld rollbacks %lld\n",
                  st[3], st[7], st[5], st[4], st[6], st[20], st[21], (long long)optimistic_stages_,
                  (long long)rollbacks_);
-    std::fprintf(stderr, "[vsg] hubs: %lld stages used hub regions, %lld regions absorbed through them, %lld stages redone "
+    std::fprintf(stderr, "[vsg] hubs: %lld stages used hub regions, %lld regions absorbed through them, %lld stages cut at an edge, %lld redone "
                  "(broken %lld, inherit %lld, shape %lld, marked %lld, pair %lld, split %lld)\n",
-                 (long long)diag_hub_stages, (long long)diag_hub_absorbed, S.hub_retries, S.hub_reasons[0],
+                 (long long)diag_hub_stages, (long long)diag_hub_absorbed, S.hub_splits, S.hub_retries, S.hub_reasons[0],
                  S.hub_reasons[1], S.hub_reasons[2], S.hub_reasons[3], S.hub_reasons[4], S.hub_reasons[5]);
     std::fprintf(stderr, "[vsg] wide: edges %llu batches %llu (%.1f lanes each) rounds %llu (%.1f per batch), chain lanes %llu, "
                  "kept-lane iterations %llu; kcyc per batch: staging %.1f rounds %.1f (%.2f per round)\n",
@@ -1458,7 +1476,7 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
         }
       };
       const int hw = (int)std::thread::hardware_concurrency();
-      const int nt = std::max(1, std::min({ns, hw > 0 ? hw : 1, 16}));
+      const int nt = std::max(1, std::min({ns, hw > 0 ? hw : 1, HostThreadCap()}));
       std::vector<std::thread> pool;
       for (int t = 1; t < nt; ++t) pool.emplace_back(work);
       work();
@@ -1549,7 +1567,7 @@ void DenseGraphHip::ObtainResults(const std::vector<const float*>* dev_flows, bo
           for (int i = next.fetch_add(1); i < num_regions; i = next.fetch_add(1)) fn(by_work[i]);
         };
         const int hw = (int)std::thread::hardware_concurrency();
-        const int nt = std::max(1, std::min({(int)(total_work / 16384), num_regions, hw > 0 ? hw : 1, 16}));
+        const int nt = std::max(1, std::min({(int)(total_work / 16384), num_regions, hw > 0 ? hw : 1, HostThreadCap()}));
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; ++t) pool.emplace_back(work);
         work();

@@ -197,6 +197,7 @@ class DenseGraphHip {
   std::vector<int> window_last_seg_;      // per bucket: largest wave segment when the target was last halved
   std::vector<uint8_t> window_frozen_;    // per bucket: halving stopped paying
   std::vector<uint8_t> window_unpaid_;    // per bucket: halvings in a row that did not pay
+  std::vector<int> window_peak_;          // per bucket: largest component of a stage since the targets were last reviewed
   double last_density_ = 1.0;                      // active / all edges of the last measured stage
   int spine_max_edges_grown_ = 0;   // what the pool was enlarged to for this video's largest stage
   DevBuf<unsigned long long> stats_;

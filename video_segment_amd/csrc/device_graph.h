@@ -41,6 +41,16 @@ constexpr uint8_t kFlagHubBroken = 16;  // the region is on the exclusion list (
 constexpr uint8_t kFlagHubExcluded = 32;
 constexpr int kHubExclCap = 16384;      // entries of the exclusion list
 constexpr int kHubMaxAttempts = 4;      // retries of a stage with a longer list before it runs without hubs
+// A stage is exact in front of the earliest edge that broke a hub rule, and that edge on its own is an
+// ordinary edge: the stage is cut there -- [start, edge) with hubs, the edge alone, (edge, end) with hubs
+// again -- up to kHubMaxSplits times per stage, before the exclusion list is used.
+constexpr int kHubMaxSplits = 64;
+// One buffer (MergeScratch::hub_excl) holds the exclusion list and the edges at which hub rules were
+// broken: [0] regions on the exclusion list, [1] / [2] edges recorded by the filter (position inside the
+// stage) / by the workers and k_hub_apply (number of the work edge), [4 ..) the regions, then the two
+// lists of edges (kHubCutCap each; more violations than that are found by the parts of the cut stage).
+constexpr int kHubCutCap = 64;
+constexpr int kHubListInts = 4 + kHubExclCap + 2 * kHubCutCap;
 
 struct NodeArrays {
   int32_t* parent;
@@ -281,7 +291,11 @@ struct MergeScratch {
   int hubs;              // hub regions (VSG_HUBS, default 1): see kFlagHub
   int hubs_off;          // (> 0 while a stage that violated a hub rule is replayed without hubs)
   int hub_attempt;       // retries of the current stage with hubs (kHubMaxAttempts)
-  int32_t* hub_excl;     // exclusion list of the stage: [0] count, [1 ..] regions (kHubExclCap)
+  int hub_splits_left;   // times the current top-level stage may still be cut at a violating edge (below)
+  int hub_split_depth;   // (> 0 inside the parts of a cut stage)
+  long long hub_splits;  // cuts in this Segment call
+  const uint32_t* list_slot_base_host;   // first kept position of every list (host copy), for StagePosition
+  int32_t* hub_excl;     // exclusion list of the stage and the edges that broke hub rules (kHubListInts)
   long long hub_retries; // such replays in this Segment call
   long long hub_reasons[6];   // ... by reason (kHubVioBroken .. kHubVioSplit)
   int wave_debug;        // use the instrumented build of the wave worker (counters, self checks)
@@ -329,6 +343,9 @@ struct StageInfo {
                               // wavefront replayed -- those of the tree replay do not count
   int hub_stages = 0;         // the stage used hub regions (kFlagHub)
   long long hub_absorbed = 0; // regions its hubs absorbed
+  int hub_retries = 0;        // times the stage was run again with broken hubs as ordinary regions: the
+                              // neighbourhood of such a region is one large component of the retry --
+                              // not the percolation the window target reacts to
 };
 // Takes the marks of the hub exclusion list off the regions and empties the list.
 void ResetHubExclusions(MergeScratch& S, NodeArrays nodes, hipStream_t s);

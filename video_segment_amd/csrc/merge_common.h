@@ -247,6 +247,11 @@ enum : int { kHubKeep = 0, kHubAbsorb = 1, kHubAbsorbTest = 3, kHubViolation = 4
 constexpr int kHubViolationMask = 0xfc;
 constexpr int kHubVioBroken = 4, kHubVioInherit = 8, kHubVioShape = 16, kHubVioMarked = 32, kHubVioPair = 64,
               kHubVioSplit = 128;
+// Bit 8 of the violation word: an edge changed what the filter had assumed for the edges BEHIND it -- the
+// constraint of a region with tentatively settled edges, the outcome of a run's leader (a constrained
+// split) -- so the stage is exact in front of that edge (recorded with HubViolationAt) and can be cut
+// there like a stage whose hub broke a rule, instead of being replayed edge by edge as a whole.
+constexpr int kVioCut = 256;
 constexpr int kHubTestBit = 1 << 30;   // in a hub mark: the absorption is subject to the split test (k_hub_apply)
 // h_sz: the hub's size when the stage started (it only grows).  Returns kHubKeep / kHubAbsorb /
 // kHubAbsorbTest or a violation bit.
@@ -282,10 +287,16 @@ __device__ __forceinline__ int AtomicOrFlags(uint8_t* flags, int r, int bits) {
 // A region that cannot be a hub of its stage (the filter found an edge that needs its exact state, a
 // worker an edge that breaks a hub rule): marked broken -- the stage is redone -- and, once, put on
 // the exclusion list that the retry turns into kFlagHubExcluded marks.
+// An edge of the stage that broke a hub rule (device_graph.h: kHubCutCap): the stage is exact in front of
+// the earliest one.  kind 0: position inside the stage (the filter), 1: number of the work edge.
+__device__ __forceinline__ void HubViolationAt(int32_t* list, int kind, int position) {
+  const int q = atomicAdd(&list[1 + kind], 1);
+  if (q < kHubCutCap) list[4 + kHubExclCap + kind * kHubCutCap + q] = position;
+}
 __device__ __forceinline__ void HubExclude(int32_t* excl, uint8_t* flags, int r) {
   if (AtomicOrFlags(flags, r, kFlagHubBroken) & kFlagHubBroken) return;
   const int q = atomicAdd(&excl[0], 1);
-  if (q < kHubExclCap) excl[1 + q] = r;
+  if (q < kHubExclCap) excl[4 + q] = r;
 }
 __device__ __forceinline__ void AtomicAndFlags(uint8_t* flags, int r, int keep_bits) {
   unsigned* w = reinterpret_cast<unsigned*>(flags + ((size_t)r & ~(size_t)3));

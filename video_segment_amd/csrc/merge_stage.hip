@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
                                                  uint32_t* __restrict__ e_gpos,
                                                  FilterMasks M,
                                                  int32_t* __restrict__ num_ti, FilterSegs segs, int hubs,
-                                                 int32_t* __restrict__ num_hub, int32_t* __restrict__ hub_excl) {
+                                                 int32_t* __restrict__ num_hub, int32_t* __restrict__ hub_excl,
+                                                 float split_s) {
   __shared__ int wave_cnt[kFilterPer][4], wave_kept[kFilterPer][4];
   __shared__ int s_start[kFilterEdges], s_pos0[kFilterEdges];
   // ... with what the edges of a segment need from its list (a 48-byte descriptor per thread
@@ -484,13 +485,31 @@ __global__ __launch_bounds__(256) void k_filter(int bucket, int bucket_hi, int j
             root[2 * e] = x;
             root[2 * e + 1] = h;
             if (!nodes.hub8[h]) nodes.hub8[h] = 1;
-            if (*num_hub == 0) *num_hub = 1;
-          } else if (!(fh & kFlagHubBroken)) {
-            HubExclude(hub_excl, nodes.flags, h);
+            if (!(*num_hub & 1)) atomicOr(num_hub, 1);
+            if (cx >= 0) {
+              // Equal constraints: absorbed unless the means are further apart than the split threshold
+              // (HubEdge, verified by k_hub_apply against the hub's mean of that moment).  With the
+              // hub's mean of NOW the answer is almost always the same, and a test that fails is an
+              // edge at which the stage is cut (bit 4 of the word the host waits for) before a worker
+              // has run.
+              const float4 dx = nodes.desc_sz[x], dh = nodes.desc_sz[h];
+              const float u = dh.x - dx.x, v = dh.y - dx.y, w = dh.z - dx.z;
+              if ((u * u + v * v + w * w) * (1.0f / 3.0f) > split_s) {
+                HubViolationAt(hub_excl, 0, jf + e * 256 + (int)threadIdx.x);
+                if (!(*num_hub & 16)) atomicOr(num_hub, 16);
+              }
+            }
+          } else {
+            HubViolationAt(hub_excl, 0, jf + e * 256 + (int)threadIdx.x);
+            if (!(fh & kFlagHubBroken)) HubExclude(hub_excl, nodes.flags, h);
           }
-        } else if (h1 && h2) {   // (not inert: equal constraints -- the split test reads both means)
-          if (!(f1 & kFlagHubBroken)) HubExclude(hub_excl, nodes.flags, ra);
-          if (!(f2 & kFlagHubBroken)) HubExclude(hub_excl, nodes.flags, rb);
+        } else if (h1 && h2) {
+          // (not inert: equal constraints -- the split test reads both means.)  With the smaller of
+          // the two an ordinary region the edge is a hub edge of the larger one -- absorbed subject to
+          // the test (HubEdge) -- and only the smaller one's neighbours are tied into a component.
+          HubViolationAt(hub_excl, 0, jf + e * 256 + (int)threadIdx.x);
+          if (s1 <= s2 && !(f1 & kFlagHubBroken)) HubExclude(hub_excl, nodes.flags, ra);
+          if (s2 <= s1 && !(f2 & kFlagHubBroken)) HubExclude(hub_excl, nodes.flags, rb);
         }
       }
       if (!hub_edge) CcUnion(cc, ra, rb);
@@ -768,6 +787,7 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
                                          : HubEdge(x, h.cons, h.flags, h.sz, T);
           if (act >= kHubViolation) {
             atomicOr(violation, act);
+            HubViolationAt(hub_excl, 1, (int)s_seq[p]);
             if (hub1) HubExclude(hub_excl, nodes.flags, r1);
             if (hub2) HubExclude(hub_excl, nodes.flags, r2);
           } else if (act == kHubKeep) {
@@ -788,9 +808,15 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
           const bool v = (out == kOutKeep)     ? TentativeViolated(o1, o2, s1, s2)
                          : (out == kOutMerge1) ? TentativeViolated(o1, o2, s1, s1)
                                                : TentativeViolated(o1, o2, s2, s2);
-          if (v) *violation = 1;
+          if (v) {
+            atomicOr(violation, kVioCut);
+            HubViolationAt(hub_excl, 1, (int)s_seq[p]);
+          }
         }
-        if (stat == 4 && T.rle) *violation = 1;
+        if (stat == 4 && T.rle) {
+          atomicOr(violation, kVioCut);
+          HubViolationAt(hub_excl, 1, (int)s_seq[p]);
+        }
         n_forced += (stat == 1);
         n_regular += (stat == 2);
         n_small += (stat == 3);
@@ -901,13 +927,12 @@ struct HubMarkValue {
 struct HubMarkEmit {
   const int32_t* mark;
   const int32_t* parent;
-  uint32_t* x_list;
+  uint32_t* seq_list;
   uint32_t* key_list;
   __device__ void operator()(int i, int is_set, int q) const {
     if (is_set) {
-      const int x = mark[i];
-      x_list[q] = (uint32_t)x;                          // (with kHubTestBit)
-      key_list[q] = (uint32_t)parent[x & ~kHubTestBit];
+      seq_list[q] = (uint32_t)i;   // (the absorbed region is mark[i], with kHubTestBit)
+      key_list[q] = (uint32_t)parent[mark[i] & ~kHubTestBit];
     }
   }
 };
@@ -928,7 +953,8 @@ __global__ __launch_bounds__(64) void k_hub_apply(const int32_t* __restrict__ nu
                                                    const int32_t* __restrict__ run_off,
                                                    const int32_t* __restrict__ run_cnt,
                                                    const uint32_t* __restrict__ hub_sorted,
-                                                   const uint32_t* __restrict__ x_sorted,
+                                                   const uint32_t* __restrict__ seq_sorted,
+                                                   const int32_t* __restrict__ mark,
                                                    NodeArrays nodes, float split_s,
                                                    int32_t* __restrict__ violation,
                                                    int32_t* __restrict__ hub_excl) {
@@ -939,11 +965,11 @@ __global__ __launch_bounds__(64) void k_hub_apply(const int32_t* __restrict__ nu
   const float4 hs = nodes.desc_sz[hub];
   float h0 = hs.x, h1 = hs.y, h2 = hs.z;
   int S = __float_as_int(hs.w);
-  bool bad = false;
-  auto absorb = [&](const float4& o, bool test) {
+  int bad_seq = -1;   // the first absorption (in sequence order) that fails its test
+  auto absorb = [&](const float4& o, bool test, uint32_t seq) {
     if (test) {   // equal constraints: DecideEdge keeps the edge (and drops constraints) beyond the split threshold
       const float x = h0 - o.x, y = h1 - o.y, z = h2 - o.z;
-      if ((x * x + y * y + z * z) * (1.0f / 3.0f) > split_s) bad = true;
+      if ((x * x + y * y + z * z) * (1.0f / 3.0f) > split_s && bad_seq < 0) bad_seq = (int)seq;
     }
     const int osz = __float_as_int(o.w);
     const float denom = 1.0f / (float)(osz + S);
@@ -957,21 +983,24 @@ __global__ __launch_bounds__(64) void k_hub_apply(const int32_t* __restrict__ nu
   int k = 0;
   for (; k + 4 <= cnt; k += 4) {
     float4 o[4];
-    uint32_t xv[4];
+    uint32_t xv[4], sq[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      xv[q] = x_sorted[off + k + q];
-      o[q] = nodes.desc_sz[xv[q] & ~(uint32_t)kHubTestBit];
-    }
+    for (int q = 0; q < 4; ++q) sq[q] = seq_sorted[off + k + q];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) absorb(o[q], (xv[q] & (uint32_t)kHubTestBit) != 0);
+    for (int q = 0; q < 4; ++q) xv[q] = (uint32_t)mark[sq[q]];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = nodes.desc_sz[xv[q] & ~(uint32_t)kHubTestBit];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) absorb(o[q], (xv[q] & (uint32_t)kHubTestBit) != 0, sq[q]);
   }
   for (; k < cnt; ++k) {
-    const uint32_t xv = x_sorted[off + k];
-    absorb(nodes.desc_sz[xv & ~(uint32_t)kHubTestBit], (xv & (uint32_t)kHubTestBit) != 0);
+    const uint32_t sq = seq_sorted[off + k];
+    const uint32_t xv = (uint32_t)mark[sq];
+    absorb(nodes.desc_sz[xv & ~(uint32_t)kHubTestBit], (xv & (uint32_t)kHubTestBit) != 0, sq);
   }
-  if (bad) {
+  if (bad_seq >= 0) {
     atomicOr(violation, kHubVioSplit);
+    HubViolationAt(hub_excl, 1, bad_seq);
     HubExclude(hub_excl, nodes.flags, hub);
   }
   nodes.desc_sz[hub] = make_float4(h0, h1, h2, __int_as_float(S));
@@ -996,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_hub_clear(int n, const int32_t* __restr
 __global__ __launch_bounds__(256) void k_hub_exclude(const int32_t* __restrict__ excl, NodeArrays nodes) {
   const int n = min(excl[0], kHubExclCap);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const int r = excl[1 + i];
+    const int r = excl[4 + i];
     if (!(nodes.flags[r] & kFlagHubExcluded)) AtomicOrFlags(nodes.flags, r, kFlagHubExcluded);
   }
 }
@@ -1011,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_hub_check(const int32_t* __restrict__ e
   if (cnt > 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(num_hub, cnt > kHubExclCap ? 12 : 8);
   const int n = min(cnt, kHubExclCap);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    if (nodes.hub8[excl[1 + i]]) {
+    if (nodes.hub8[excl[4 + i]]) {
       atomicOr(num_hub, 2);
       break;
     }
@@ -1022,15 +1051,70 @@ __global__ __launch_bounds__(256) void k_hub_check(const int32_t* __restrict__ e
 __global__ __launch_bounds__(256) void k_hub_unexclude(int32_t* __restrict__ excl, NodeArrays nodes) {
   const int n = min(excl[0], kHubExclCap);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    AtomicAndFlags(nodes.flags, excl[1 + i], 0xff & ~(kFlagHubExcluded | kFlagHubBroken));
+    AtomicAndFlags(nodes.flags, excl[4 + i], 0xff & ~(kFlagHubExcluded | kFlagHubBroken));
   }
 }
 __global__ void k_hub_excl_reset(int32_t* __restrict__ excl) { excl[0] = 0; }
+// The work edges that broke a rule, as kept positions (what the host can locate).
+__global__ void k_hub_cut_gpos(int32_t* __restrict__ list, const uint32_t* __restrict__ work_gpos) {
+  const int n = min(list[2], kHubCutCap);
+  int32_t* at = list + 4 + kHubExclCap + kHubCutCap;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) at[i] = (int32_t)work_gpos[at[i]];
+}
 void ResetHubExclusions(MergeScratch& S, NodeArrays nodes, hipStream_t s) {
   if (!S.hub_excl) return;
   hipLaunchKernelGGL(k_hub_unexclude, dim3(16), dim3(256), 0, s, S.hub_excl, nodes);
   hipLaunchKernelGGL(k_hub_excl_reset, dim3(1), dim3(1), 0, s, S.hub_excl);
   VSG_HIP(hipGetLastError());
+}
+
+// One edge of a bucket on its own -- the edge at which a stage is cut: both roots, DecideEdge, the states
+// and the kept mark, exactly what the lane worker does for an edge without any of the stage's assumptions.
+__global__ void k_plain_edge(int bucket, int jb, const ListDesc* __restrict__ lists,
+                             const int32_t* __restrict__ bucket_base, const uint32_t* __restrict__ list_slot_base,
+                             uint8_t* __restrict__ kept_all, NodeArrays nodes, MergeParams P, StageThr T,
+                             unsigned long long* __restrict__ stats) {
+  const int32_t* base_row = bucket_base + (size_t)bucket * (P.num_lists + 1);
+  const int l = LocateList(base_row, P.num_lists, jb);
+  const int pos = lists[l].offsets[bucket] + (jb - base_row[l]);
+  const ListDesc L = lists[l];
+  int a, b;
+  DecodeEdge(L, L.slots[pos], P.W, a, b);
+  const uint32_t gpos = list_slot_base[l] + (uint32_t)pos;
+  if (P.spatial_survivors && L.type == 0 && !P.spatial_survivors[gpos]) return;   // the edge is gone
+  int r1 = a, r2 = b;
+  for (int p; (p = nodes.parent[r1]) != r1;) r1 = p;
+  for (int p; (p = nodes.parent[r2]) != r2;) r2 = p;
+  if (r1 == r2) return;
+  RState s1 = LoadState(nodes, r1), s2 = LoadState(nodes, r2);
+  int stat;
+  const int out = DecideEdge(s1, s2, T, stat);
+  if (stat >= 1 && stat <= 3) atomicAdd(&stats[stat - 1], 1ull);
+  if (out == kOutKeep) {
+    kept_all[gpos] = 1;
+    StoreState(nodes, r1, s1);
+    StoreState(nodes, r2, s2);
+  } else if (out == kOutMerge1) {
+    StoreState(nodes, r1, s1);
+    nodes.parent[r2] = r1;
+  } else {
+    StoreState(nodes, r2, s2);
+    nodes.parent[r1] = r2;
+  }
+}
+
+// Position, inside its bucket, of the edge with kept position `gpos` (the order of the edge sequence: the
+// bucket's edges list by list), from the host copies of the bucket tables.
+static long long BucketPosition(const MergeScratch& S, const MergeParams& P, int bucket, uint32_t gpos) {
+  const int L = P.num_lists;
+  int lo = 0, hi = L;   // the last list that starts at or before gpos
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (S.list_slot_base_host[mid] <= gpos) lo = mid; else hi = mid;
+  }
+  const long long p = (long long)gpos - (long long)S.list_slot_base_host[lo];
+  const int32_t* row = S.bucket_base_host + (size_t)bucket * (L + 1);
+  return (long long)row[lo] + (p - (long long)S.list_off_host[(size_t)lo * (kNumBuckets + 2) + bucket]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1051,7 +1135,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   }
   if (n_b <= 0) return;
   const int bucket_hi = S.group_hi > bucket ? S.group_hi : bucket + 1;
-  int32_t* d_num_ti = TakeStageScalars(S, 5);   // fresh counters per stage: nothing to clear
+  int32_t* d_num_ti = TakeStageScalars(S, 8);   // fresh counters per stage: nothing to clear
   int32_t* d_violation = d_num_ti + 1;
   int32_t* d_num_hub = d_num_ti + 2;
   int32_t* d_hub_count = d_num_ti + 3;
@@ -1063,7 +1147,15 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   const bool try_hubs = S.hubs && !S.hubs_off && inert_mode != 0 && !spine_possible && S.wide_min <= 0;
   // (the list of a stage starts empty: what the filter of an earlier stage put there without
   // consequences -- a broken region that no edge used as a hub -- is not excluded from this one)
-  if (try_hubs && S.hub_attempt == 0) VSG_HIP(hipMemsetAsync(S.hub_excl, 0, sizeof(int32_t), s));
+  // (... and the edges that broke a rule are those of this run of the stage -- recorded with or without hubs)
+  if (S.hub_excl) {
+    if (S.hub_attempt == 0) {
+      VSG_HIP(hipMemsetAsync(S.hub_excl, 0, 4 * sizeof(int32_t), s));
+    } else {
+      VSG_HIP(hipMemsetAsync(S.hub_excl + 1, 0, 2 * sizeof(int32_t), s));
+    }
+  }
+  if (S.hub_attempt == 0 && S.hub_split_depth == 0) S.hub_splits_left = kHubMaxSplits;
   int32_t* d_num_leaders = S.num_active + 5;
   // The stage's non-empty (bucket, list) segments, from the host copy of the bucket table.
   FilterSegs segs = {nullptr, nullptr, nullptr, 0};
@@ -1102,11 +1194,12 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       segs.n = nseg;
     }
   }
+  const float split_s = ((float)bucket * P.inv_scale < P.force_merge_weight) ? P.s_lt_02 : P.s_le_015;   // (StageThr::split_s)
   const int ef0 = NextEvent(S);
   if (ef0 >= 0) VSG_HIP(hipEventRecord((*S.ev_pool)[ef0], s));
   hipLaunchKernelGGL(k_filter, dim3((unsigned)((n_b + kFilterEdges - 1) / kFilterEdges)), dim3(256), 0, s, bucket, bucket_hi, j0, n_b, lists,
                      bucket_base, S.bucket_prefix, list_slot_base, kept_all, nodes, P, inert_mode, S.cc, S.e_ra, S.e_rb, S.e_gpos,
-                     S.masks, d_num_ti, segs, try_hubs ? 1 : 0, d_num_hub, S.hub_excl);
+                     S.masks, d_num_ti, segs, try_hubs ? 1 : 0, d_num_hub, S.hub_excl, split_s);
   const int ef1 = NextEvent(S);
   if (ef1 >= 0) {
     VSG_HIP(hipEventRecord((*S.ev_pool)[ef1], s));
@@ -1145,19 +1238,101 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     clear_marks();
     return;
   }
-  // A stage whose hubs broke a rule is run again with the regions that did as ordinary regions (they
-  // are on the exclusion list); after kHubMaxAttempts of those -- or when the list has overflowed --
-  // without hubs.  (Called with the stage undone.)
-  auto retry_without_broken_hubs = [&](int violated, int work, bool list_complete) {
+  // A stage whose hubs broke a rule.  (Called with the stage undone.)  The stage is exact in front of
+  // the earliest edge at which that happened, and that edge on its own is an ordinary edge: the stage
+  // is cut there -- [start, edge) with hubs, the edge alone, (edge, end) with hubs again; whatever
+  // made the hub unusable (a constraint it was about to inherit, a region of its own constraint
+  // that fails the split test, its like) is behind it then.  After kHubMaxSplits cuts, in a stage over
+  // several buckets, or without the host tables that locate an edge, the stage is run again with
+  // the regions that broke a rule as ordinary regions (they are on the exclusion list), and after
+  // kHubMaxAttempts of those -- or when the list has overflowed -- without hubs.
+  // (a stage inside one bucket, whose edges the host tables can locate, with cuts left)
+  auto can_cut = [&]() {
+    return bucket_hi == bucket + 1 && S.hub_splits_left > 0 && S.bucket_base_host && S.list_off_host &&
+           S.list_slot_base_host;
+  };
+  auto retry_without_broken_hubs = [&](int violated, int work, bool list_complete, const uint32_t* work_gpos) -> bool {
     for (int q = 0; q < 6; ++q) S.hub_reasons[q] += (violated >> (2 + q)) & 1;
     ++S.hub_retries;
+    if (info) ++info->hub_retries;
+    // The edges at which rules were broken, as positions inside the stage, in order.
+    std::vector<int> cuts;
+    if (can_cut()) {
+      int head[4] = {0, 0, 0, 0};
+      int at[2 * kHubCutCap];
+      if (work_gpos) hipLaunchKernelGGL(k_hub_cut_gpos, dim3(1), dim3(64), 0, s, S.hub_excl, work_gpos);
+      VSG_HIP(hipMemcpyAsync(head, S.hub_excl, sizeof(head), hipMemcpyDeviceToHost, s));
+      VSG_HIP(hipMemcpyAsync(at, S.hub_excl + 4 + kHubExclCap, sizeof(at), hipMemcpyDeviceToHost, s));
+      VSG_HIP(hipStreamSynchronize(s));
+      for (int i = 0; i < std::min(head[1], kHubCutCap); ++i) cuts.push_back(at[i]);
+      if (work_gpos) {
+        for (int i = 0; i < std::min(head[2], kHubCutCap); ++i) {
+          cuts.push_back((int)(BucketPosition(S, P, bucket, (uint32_t)at[kHubCutCap + i]) - j0));
+        }
+      }
+      std::sort(cuts.begin(), cuts.end());
+      cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+      while (!cuts.empty() && cuts.back() >= n_b) cuts.pop_back();
+      while (!cuts.empty() && cuts.front() < 0) cuts.erase(cuts.begin());
+      // (What the filter found: only the earliest.  A hub about to inherit a constraint has as many such
+      // edges as constrained neighbours, and all but the first are ordinary hub edges once it has; the
+      // rest of the stage finds what is left at the cost of a filter pass.)
+      if (!work_gpos && cuts.size() > 1) cuts.resize(1);
+      if ((int)cuts.size() > S.hub_splits_left) cuts.resize((size_t)S.hub_splits_left);
+    }
     if (getenv("VSG_DEBUG_STAGES")) {
       int cnt = 0;
       VSG_HIP(hipMemcpyAsync(&cnt, S.hub_excl, sizeof(int), hipMemcpyDeviceToHost, s));
       VSG_HIP(hipStreamSynchronize(s));
-      std::fprintf(stderr, "[vsg]   hub rule violated (mask %x) in b=%d n=%d work %d, attempt %d, %d regions excluded so far\n",
-                   violated, bucket, n_b, work, S.hub_attempt, cnt);
+      std::fprintf(stderr, "[vsg]   hub rule violated (mask %x) in b=%d j0=%d n=%d work %d, attempt %d, %d regions on the "
+                   "list, %zu cuts (first at %d, %d left)\n", violated, bucket, j0, n_b, work, S.hub_attempt, cnt,
+                   cuts.size(), cuts.empty() ? -1 : cuts[0], S.hub_splits_left);
     }
+    if (!cuts.empty()) {
+      // (the positions after the first are hints: what the stage does behind a cut may differ from this
+      // run -- every part checks itself and is cut again if need be)
+      S.hub_splits_left -= (int)cuts.size();
+      S.hub_splits += (long long)cuts.size();
+      int replayed = 0;
+      auto part = [&](int off, int n, bool plain) {
+        if (n <= 0) return;
+        StageInfo sub;
+        if (info) sub.want_components = info->want_components;
+        ++S.hub_split_depth;
+        if (plain) ++S.hubs_off;
+        RunBucketStage(bucket, j0 + off, n, lists, bucket_base, list_slot_base, kept_all, nodes, P, inert_mode, S, s,
+                       info ? &sub : nullptr);
+        if (plain) --S.hubs_off;
+        --S.hub_split_depth;
+        replayed += sub.replayed;
+        if (info) {
+          info->hub_stages += sub.hub_stages;
+          info->hub_absorbed += sub.hub_absorbed;
+          info->hub_retries += sub.hub_retries;
+          info->components += sub.components;
+          info->max_wave_segment = std::max(info->max_wave_segment, sub.max_wave_segment);
+        }
+      };
+      StageThr plain;   // (the thresholds of the bucket, none of a stage's assumptions)
+      plain.pass_s = ((float)bucket * P.inv_scale < P.force_merge_weight) ? P.s_lt_02 : P.s_lt_005;
+      plain.split_s = split_s;
+      plain.min_size = P.min_region_size;
+      plain.rle = 0;
+      plain.side = 0;
+      plain.hubs = 0;
+      int prev = 0;
+      for (const int c : cuts) {
+        part(prev, c - prev, false);
+        hipLaunchKernelGGL(k_plain_edge, dim3(1), dim3(1), 0, s, bucket, j0 + c, lists, bucket_base, list_slot_base,
+                           kept_all, nodes, P, plain, S.stats);
+        ++replayed;
+        prev = c + 1;
+      }
+      part(prev, n_b - prev, false);
+      if (info) info->replayed = replayed;
+      return true;
+    }
+    if (violated & kVioCut) return false;   // (not a matter of hubs: the caller replays the stage edge by edge)
     int& depth = (list_complete && S.hub_attempt + 1 < kHubMaxAttempts) ? S.hub_attempt : S.hubs_off;
     if (&depth == &S.hub_attempt) {
       hipLaunchKernelGGL(k_hub_exclude, dim3(16), dim3(256), 0, s, S.hub_excl, nodes);
@@ -1168,8 +1343,9 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     // (the exclusions go with the stage: a hub that was about to inherit a constraint, or to meet
     // its like, is an ordinary hub again once that edge is behind it)
     if (S.hub_attempt == 0 && S.hubs_off == 0) ResetHubExclusions(S, nodes, s);
+    return true;
   };
-  if (hubs_used && (h[2] & 6) != 0) {
+  if (hubs_used && ((h[2] & 6) != 0 || ((h[2] & 16) != 0 && can_cut()))) {
     // The filter itself found a hub whose exact state an edge needs: nothing has been replayed yet.
     hipLaunchKernelGGL(k_reset_cc, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra, S.a_rb, S.cc,
                        d_violation, nullptr, 0u);
@@ -1177,8 +1353,8 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     clear_marks();
     clear_hub_marks();
     VSG_HIP(hipGetLastError());
-    retry_without_broken_hubs(kHubVioBroken, n_active, (h[2] & 4) == 0);
-    return;
+    if (retry_without_broken_hubs(kHubVioBroken, n_active, (h[2] & 4) == 0, nullptr)) return;
+    VSG_REQUIRE(false, -4, "hub stage: no way to rerun it");
   }
   if (hubs_used && info) ++info->hub_stages;
 
@@ -1277,11 +1453,11 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   wa.work_ctl = wa.work_list ? TakeZeroed(S, 2 * kWaveClasses) : nullptr;
   wa.wide_min = S.wide_min;
   wa.wide_waves = S.wide_waves;
+  wa.s_seq = S.s_idx;          // (number of a work edge in the stage's sequence: where a rule was broken)
+  wa.hub_excl = S.hub_excl;
   if (hubs_used) {
     // (the sorted component keys are free once the runs are known: one mark per work edge)
     wa.hub_mark = reinterpret_cast<int32_t*>(S.s_comp);
-    wa.s_seq = S.s_idx;
-    wa.hub_excl = S.hub_excl;
     VSG_HIP(hipMemsetAsync(wa.hub_mark, 0xFF, (size_t)n_work * sizeof(int32_t), s));
   }
   auto general_workers = [&](const WorkerArgs& w, int small_threads, int grid, hipStream_t s) {
@@ -1341,22 +1517,22 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   if (hubs_used) {
     // What the hubs absorbed, in sequence order, grouped by hub (stable sort), one thread per hub --
     // before the violation word is read: an absorption that was subject to the split test may fail it.
-    uint32_t* x_list = S.a_comp;                                   // (the workers' inputs are free now)
+    uint32_t* seq_list = S.a_comp;                                 // (the workers' inputs are free now)
     uint32_t* key_list = S.a_idx;
     uint32_t* key_sorted = reinterpret_cast<uint32_t*>(S.e_apos);
-    uint32_t* x_sorted = S.s_idx;
+    uint32_t* seq_sorted = S.s_idx;                                // (the marks themselves stay where they are: s_comp)
     int32_t* run_off = reinterpret_cast<int32_t*>(S.seg_key);      // (the work list)
-    int32_t* run_cnt = reinterpret_cast<int32_t*>(S.s_comp);       // (the marks, once they are compacted)
+    int32_t* run_cnt = S.seg_off;                                  // (the segments are through)
     const MailSlot m_hub = NextMail(*S.mail);
-    FusedScan(S.scan, HubMarkValue{wa.hub_mark}, HubMarkEmit{wa.hub_mark, nodes.parent, x_list, key_list},
+    FusedScan(S.scan, HubMarkValue{wa.hub_mark}, HubMarkEmit{wa.hub_mark, nodes.parent, seq_list, key_list},
               HubMarkFinish{d_hub_count, m_hub.dev, m_hub.seq}, n_work, s);
     int n_abs = 0;
     MailWait(m_hub, 1, &n_abs, s);
     if (n_abs > 0) {
-      SortPairsU32(S.cub_temp, S.cub_temp_bytes, key_list, key_sorted, x_list, x_sorted, n_abs, S.node_key_bits, s);
+      SortPairsU32(S.cub_temp, S.cub_temp_bytes, key_list, key_sorted, seq_list, seq_sorted, n_abs, S.node_key_bits, s);
       RunsOfSortedKeys(S.scan, key_sorted, n_abs, run_off, run_cnt, d_hub_runs, s);
       hipLaunchKernelGGL(k_hub_apply, dim3((unsigned)((n_abs + 63) / 64)), dim3(64), 0, s, d_hub_runs, run_off,
-                         run_cnt, key_sorted, x_sorted, nodes, T.split_s, d_violation, S.hub_excl);
+                         run_cnt, key_sorted, seq_sorted, wa.hub_mark, nodes, T.split_s, d_violation, S.hub_excl);
     }
     if (info) info->hub_absorbed += n_abs;
   }
@@ -1391,12 +1567,11 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
         S.spine_off = off;
         return;
       }
-      if (hubs_used && (violated & kHubViolationMask) != 0 && (violated & ~kHubViolationMask) == 0 &&
-          !S.force_rollback) {
+      if ((violated & (kHubViolationMask | kVioCut)) != 0 && (violated & ~(kHubViolationMask | kVioCut)) == 0 &&
+          !spine && !S.force_rollback) {
         // Only a hub rule failed (an edge met a hub that it would have changed, a split test on a hub
-        // did not pass).
-        retry_without_broken_hubs(violated, n_work, true);
-        return;
+        // did not pass), or edges changed what the filter had assumed for the edges behind them.
+        if (retry_without_broken_hubs(violated, n_work, true, w_gpos)) return;
       }
       if (bucket_hi > bucket + 1) {
         // A group of buckets: its two halves (each optimistic again, split further if it fails

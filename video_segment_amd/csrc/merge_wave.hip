@@ -430,6 +430,7 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
                                        : HubEdge(x, h.cons, h.flags, h.sz, T);
       if (act >= kHubViolation) {
         atomicOr(violation, act);
+        HubViolationAt(hub_excl, 1, (int)seq);
         if (a_hub) HubExclude(hub_excl, nodes.flags, tab.key[sa]);
         if (b_hub) HubExclude(hub_excl, nodes.flags, tab.key[sb]);
       } else if (act == kHubKeep) {
@@ -491,9 +492,15 @@ __device__ __forceinline__ bool ReplayRounds(WaveTable& tab, float4* chain_buf, 
         const bool v = (out == kOutKeep)     ? TentativeViolated(o1, o2, s1, s2)
                        : (out == kOutMerge1) ? TentativeViolated(o1, o2, s1, s1)
                                              : TentativeViolated(o1, o2, s2, s2);
-        if (v) *violation = 1;
+        if (v) {
+          atomicOr(violation, kVioCut);
+          HubViolationAt(hub_excl, 1, (int)seq);
+        }
       }
-      if (stat == 4 && T.rle) *violation = 1;
+      if (stat == 4 && T.rle) {
+        atomicOr(violation, kVioCut);
+        HubViolationAt(hub_excl, 1, (int)seq);
+      }
       C.n_forced += (stat == 1);
       C.n_regular += (stat == 2);
       C.n_small += (stat == 3);
