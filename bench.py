@@ -305,7 +305,7 @@ def kernel_table(W, H, chunk):
     return None
 
 
-PROFILE_TAGS = ("r5", "r4", "r3", "r2")
+PROFILE_TAGS = ("r6", "r5", "r4", "r3", "r2")
 
 
 def kernel_source_hash():

@@ -83,8 +83,8 @@ def test_committed_round_line_carries_every_key():
     single-GPU configs, the other inputs (each with its own oracle check), the streams sweep, the
     memory a stream holds -- and counters that belong to the kernel sources of the same commit."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r5_*_bench_1080p.json")))
-    assert paths, "no round-5 bench line under profiles/"
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r6_*_bench_1080p.json")))
+    assert paths, "no round-6 bench line under profiles/"
     out = last_json_line(open(paths[-1]).read())
     check(out, 1, out["steps"], out["warmup"])
     assert out["vs_baseline"] is None and out["parity_checked"] is True
@@ -111,5 +111,5 @@ def test_committed_round_line_carries_every_key():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from source_hash import source_hash
     assert r["kernels"]["source_hash"] == source_hash(ROOT)
-    for name in ("r5_pmc_wave.json", "r5_pmc_spine.json", "r5_kernel_table.json"):
+    for name in ("r6_pmc_wave.json", "r6_pmc_spine.json", "r6_kernel_table.json"):
         assert json.load(open(os.path.join(ROOT, "profiles", name)))["source_hash"] == source_hash(ROOT), name

@@ -8,7 +8,7 @@
 # with the average launch durations of step 1, 3. the compact kernel table, 4. the default bench.py
 # line (what the driver records) last, reading the summaries of this session.
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"

@@ -478,7 +478,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     S.bk_flags = act_.bk_flags;
     S.cub_temp = cub_temp_.get();
     S.cub_temp_bytes = cub_temp_.size();
-    S.scan = ScanScratch{scan_sums_.get()};
+    S.scan = ScanScratch{scan_sums_.get(), stream_};
     S.active_cap = (int)std::min<size_t>(scratch_active_, 0x7fffffff);
   };
   bind_scratch();

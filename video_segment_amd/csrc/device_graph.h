@@ -122,6 +122,7 @@ void LaunchInitVirtualNodes(const int32_t* labels, size_t n, int base, int num_l
 constexpr int kScanMaxTiles = 4096;
 struct ScanScratch {
   int32_t* sums;   // [kScanMaxTiles]
+  hipStream_t owner = nullptr;   // the one stream whose scans may use `sums` (null: not checked)
 };
 
 // ---- radix_sort.hip: the stable (key, value) sort of the merge path, hand-written ----------------------

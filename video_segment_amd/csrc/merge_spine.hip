@@ -1458,6 +1458,7 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
     int n_waiting = 0;
     const int32_t* gate = nullptr;
     int32_t* len_words = scalars + 8;   // [2]: the length of the current list / of the one the next compaction builds
+    int32_t* gate_words = scalars + 12;  // [2]: live edges of the last two rounds
     int len_cur = 0;
     for (int round = 0;; ++round) {
       dbg_rounds = round;
@@ -1471,8 +1472,11 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
       const MailSlot m_alive = NextMail(*S.mail);
       hipLaunchKernelGGL(k_bor_hook, dim3(Blocks(n_list)), dim3(256), 0, s, n_list, list, list_len, round, eu, ev,
                          estate, cc, best, side_key, spine_flag, d_ctr, m_alive.dev, m_alive.seq, gate,
-                         d_ctr + 16 * kAliveSlots + 1);
-      gate = d_ctr + 16 * kAliveSlots + 1;
+                         gate_words + (round & 1));
+      // (the round's total = the next round's gate: one of two words of the pool's scalars, written
+      // unconditionally by k_bor_hook -- not a word of the rotating zero pool, which the kernels of
+      // round r + 1 would read after the next TakeZeroed)
+      gate = gate_words + (round & 1);
       waiting[n_waiting++] = m_alive;
       const int depth = n_list <= ahead_max ? 1 : 0;   // rounds that may stay unanswered
       const double tr0 = dbg_big ? NowMs() : 0;

@@ -133,6 +133,8 @@ inline void FusedScan(const ScanScratch& sc, Value value, Emit emit, Finish fini
   while ((tiles + chunks - 1) / chunks > 2048) chunks *= 2;   // at most 2048 tiles (one million elements per tile at 2^31)
   const int grid = (int)((tiles + chunks - 1) / chunks);
   VSG_REQUIRE(grid <= kScanMaxTiles, -4, "scan: too many tiles");
+  // (two scans in flight on different streams would share the tile sums)
+  VSG_REQUIRE(sc.owner == nullptr || sc.owner == s, -4, "scan: issued on a stream that does not own the scratch");
   hipLaunchKernelGGL((k_scan_sums<Value>), dim3(grid), dim3(256), 0, s, value, n, chunks, sc.sums);
   hipLaunchKernelGGL((k_scan_emit<Value, Emit, Finish>), dim3(grid), dim3(256), 0, s, value, emit, finish, n, chunks,
                      sc.sums);
