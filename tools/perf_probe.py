@@ -9,14 +9,19 @@ import video_segment_amd as vsg
 
 W, H, N, chunk = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 kind = sys.argv[5] if len(sys.argv) > 5 else "bench"
+# "varflow": the headline frames with the spatially varying backward flow of synth.var_flow (a field per frame)
+var = kind == "varflow"
+if var:
+    kind = "bench"
 s = vsg.DenseSegmentation(W, H, vsg.default_options(chunk_size=chunk), has_flow=True)
 fl = torch.from_numpy(synth.const_flow(W, H)).cuda()
+flows = [synth.flow_torch("var", W, H, k, torch.device("cuda")) for k in range(N)] if var else None
 frames = [synth.frame_torch(kind, W, H, k, torch.device("cuda")) if kind in synth.FRAME_FNS
           else torch.from_numpy(synth.probe_frame(W, H, k)).cuda() for k in range(N)]
 torch.cuda.synchronize()
 t0 = time.time(); tl = t0
 for k in range(N):
-    n = s.process_frame(frames[k], fl if k > 0 else None, flush=(k == N - 1))
+    n = s.process_frame(frames[k], (flows[k] if var else fl) if k > 0 else None, flush=(k == N - 1))
     if n:
         t = s.last_timings()
         now = time.time()
