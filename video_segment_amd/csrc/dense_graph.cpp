@@ -143,6 +143,7 @@ void DenseGraphHip::ForgetLearned() {
   for (int b = 0; b < 2; ++b) spine_low_fails_[b] = spine_low_cooldown_[b] = 0;
   wave_target_active_ = kNoWindowTarget;
   window_target_.clear();
+  hub_bucket_pause_.clear();
   window_target_age_ = 0;
   last_density_ = 1.0;
 }
@@ -522,8 +523,10 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   S.wide_min = getenv("VSG_WIDE_MIN") ? atoi(getenv("VSG_WIDE_MIN")) : 0;
   S.wide_waves = getenv("VSG_WIDE_WAVES") ? atoi(getenv("VSG_WIDE_WAVES")) : 4;
   S.chain_relax = getenv("VSG_CHAIN_RELAX") ? atoi(getenv("VSG_CHAIN_RELAX")) : 1;
-  S.hubs = getenv("VSG_HUBS") ? atoi(getenv("VSG_HUBS")) : 1;
+  const int hubs_default = getenv("VSG_HUBS") ? atoi(getenv("VSG_HUBS")) : 1;
+  S.hubs = hubs_default;
   S.hub_excl = hub_excl_.get();
+  S.hub_cut_min_work = getenv("VSG_CUT_MIN_WORK") ? atoi(getenv("VSG_CUT_MIN_WORK")) : 0;
   // (a stage takes its marks off again; an exception in the middle of one must not leave any behind)
   VSG_HIP(hipMemsetAsync(hub8_.get(), 0, N, stream_));
   // Sizes that follow the graph rather than the 1080p bench: the tree replay's scratch pool holds
@@ -756,6 +759,16 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
       window_unpaid_.assign(kNumBuckets + 1, 0);
       window_peak_.assign(kNumBuckets + 1, 0);
     }
+    if (hub_bucket_pause_.empty()) {
+      hub_bucket_pause_.assign(kNumBuckets + 1, 0);
+      hub_bucket_stages_.assign(kNumBuckets + 1, 0);
+      hub_bucket_absorbed_.assign(kNumBuckets + 1, 0);
+    }
+    // (hubs are a choice per stage: a stage is exact with or without them)
+    S.hubs = hubs_default && hub_bucket_pause_[b] == 0 ? 1 : 0;
+    if (hub_bucket_pause_[b] > 0) --hub_bucket_pause_[b];
+    hub_bucket_stages_[b] = 0;
+    hub_bucket_absorbed_[b] = 0;
     if (window_target_[b] != 0) {
       wave_target_active_ = window_target_[b];
     } else if (b <= first_plain) {
@@ -777,6 +790,8 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
       RunStageDebug(b, w, windows, j0, n, P, inert_mode, S, debug_stages, &info);
       diag_hub_stages += info.hub_stages;
       diag_hub_absorbed += info.hub_absorbed;
+      hub_bucket_stages_[b] += info.hub_stages;
+      hub_bucket_absorbed_[b] += info.hub_absorbed;
       group_active += info.replayed;
       if (debug_stages && info.want_components && wave_target_active_ != kNoWindowTarget) {
         std::fprintf(stderr, "[vsg]   window: max wave segment %d, target %lld active (density %.4f), limited %d\n",
@@ -863,6 +878,8 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
       }
     }
     window_target_[b] = wave_target_active_;
+    // Hubs that absorbed less than a region per stage: the bucket does without them for eight chunks.
+    if (hub_bucket_stages_[b] > 0 && hub_bucket_absorbed_[b] < hub_bucket_stages_[b]) hub_bucket_pause_[b] = 8;
     if (debug_stages && wave_target_active_ != kNoWindowTarget) {
       std::fprintf(stderr, "[vsg]   bucket %d leaves target %lld (frozen %d, unpaid %d, last %d, peak %d)\n", b,
                    (long long)wave_target_active_, (int)window_frozen_[b], (int)window_unpaid_[b], window_last_seg_[b],

@@ -198,6 +198,11 @@ class DenseGraphHip {
   std::vector<uint8_t> window_frozen_;    // per bucket: halving stopped paying
   std::vector<uint8_t> window_unpaid_;    // per bucket: halvings in a row that did not pay
   std::vector<int> window_peak_;          // per bucket: largest component of a stage since the targets were last reviewed
+  // Hub regions per bucket (group): stages that used them and regions they absorbed in the chunk at
+  // hand, and for how many more chunks the bucket goes without (its hubs absorbed next to nothing:
+  // the pipeline around them -- marks, log, sort, one more host wait per stage -- is all cost there).
+  std::vector<int> hub_bucket_stages_, hub_bucket_pause_;
+  std::vector<long long> hub_bucket_absorbed_;
   double last_density_ = 1.0;                      // active / all edges of the last measured stage
   int spine_max_edges_grown_ = 0;   // what the pool was enlarged to for this video's largest stage
   DevBuf<unsigned long long> stats_;

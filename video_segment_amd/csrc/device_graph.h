@@ -294,6 +294,8 @@ struct MergeScratch {
   int hub_attempt;       // retries of the current stage with hubs (kHubMaxAttempts)
   int hub_splits_left;   // times the current top-level stage may still be cut at a violating edge (below)
   int hub_split_depth;   // (> 0 inside the parts of a cut stage)
+  int hub_list_dirty;    // the head of the list has to be cleared before the next stage uses it
+  int hub_cut_min_work;  // stages of fewer replayed edges are not cut (VSG_CUT_MIN_WORK, 0: measured, 32768 is worse)
   long long hub_splits;  // cuts in this Segment call
   const uint32_t* list_slot_base_host;   // first kept position of every list (host copy), for StagePosition
   int32_t* hub_excl;     // exclusion list of the stage and the edges that broke hub rules (kHubListInts)

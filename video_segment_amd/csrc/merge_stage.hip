@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_hub_unexclude(int32_t* __restrict__ exc
     AtomicAndFlags(nodes.flags, excl[4 + i], 0xff & ~(kFlagHubExcluded | kFlagHubBroken));
   }
 }
-__global__ void k_hub_excl_reset(int32_t* __restrict__ excl) { excl[0] = 0; }
+__global__ void k_hub_excl_reset(int32_t* __restrict__ excl) { excl[0] = excl[1] = excl[2] = excl[3] = 0; }
 // The work edges that broke a rule, as kept positions (what the host can locate).
 __global__ void k_hub_cut_gpos(int32_t* __restrict__ list, const uint32_t* __restrict__ work_gpos) {
   const int n = min(list[2], kHubCutCap);
@@ -1147,12 +1147,15 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   const bool try_hubs = S.hubs && !S.hubs_off && inert_mode != 0 && !spine_possible && S.wide_min <= 0;
   // (the list of a stage starts empty: what the filter of an earlier stage put there without
   // consequences -- a broken region that no edge used as a hub -- is not excluded from this one)
-  // (... and the edges that broke a rule are those of this run of the stage -- recorded with or without hubs)
-  if (S.hub_excl) {
+  // (... and the edges that broke a rule are those of this run of the stage -- recorded with or without
+  // hubs.  Cleared only when a stage has left something there: the host knows -- the filter's entries
+  // show in the word it waits for, a worker's come with a violation.)
+  if (S.hub_excl && S.hub_list_dirty) {
     if (S.hub_attempt == 0) {
       VSG_HIP(hipMemsetAsync(S.hub_excl, 0, 4 * sizeof(int32_t), s));
+      S.hub_list_dirty = 0;
     } else {
-      VSG_HIP(hipMemsetAsync(S.hub_excl + 1, 0, 2 * sizeof(int32_t), s));
+      VSG_HIP(hipMemsetAsync(S.hub_excl + 1, 0, 2 * sizeof(int32_t), s));   // (the exclusion list stays)
     }
   }
   if (S.hub_attempt == 0 && S.hub_split_depth == 0) S.hub_splits_left = kHubMaxSplits;
@@ -1223,6 +1226,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   const int n_active = h[0];
   const int n_ti = h[1];
   const bool hubs_used = try_hubs && (h[2] & 1) != 0;
+  if (h[2] & (8 | 16)) S.hub_list_dirty = 1;   // (the filter put regions / edges on the list)
   auto clear_hub_marks = [&]() {
     if (try_hubs && (h[2] & 9) != 0 && n_active > 0) {
       hipLaunchKernelGGL(k_hub_clear, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra, S.a_rb, nodes);
@@ -1247,9 +1251,13 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   // the regions that broke a rule as ordinary regions (they are on the exclusion list), and after
   // kHubMaxAttempts of those -- or when the list has overflowed -- without hubs.
   // (a stage inside one bucket, whose edges the host tables can locate, with cuts left)
-  auto can_cut = [&]() {
-    return bucket_hi == bucket + 1 && S.hub_splits_left > 0 && S.bucket_base_host && S.list_off_host &&
-           S.list_slot_base_host;
+  // (VSG_CUT_MIN_WORK: stages of fewer replayed edges are replayed edge by edge instead -- measured at
+  // 32 768: nothing gained on the value-noise input, whose 66 cuts per chunk sit in small stages, and a
+  // long +-40-noise stream back at one second per chunk: a small stage's edge-by-edge replay is still
+  // one percolating component.  0.)
+  auto can_cut = [&](int work) {
+    return work >= S.hub_cut_min_work && bucket_hi == bucket + 1 && S.hub_splits_left > 0 && S.bucket_base_host &&
+           S.list_off_host && S.list_slot_base_host;
   };
   auto retry_without_broken_hubs = [&](int violated, int work, bool list_complete, const uint32_t* work_gpos) -> bool {
     for (int q = 0; q < 6; ++q) S.hub_reasons[q] += (violated >> (2 + q)) & 1;
@@ -1257,7 +1265,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     if (info) ++info->hub_retries;
     // The edges at which rules were broken, as positions inside the stage, in order.
     std::vector<int> cuts;
-    if (can_cut()) {
+    if (can_cut(work)) {
       int head[4] = {0, 0, 0, 0};
       int at[2 * kHubCutCap];
       if (work_gpos) hipLaunchKernelGGL(k_hub_cut_gpos, dim3(1), dim3(64), 0, s, S.hub_excl, work_gpos);
@@ -1345,7 +1353,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     if (S.hub_attempt == 0 && S.hubs_off == 0) ResetHubExclusions(S, nodes, s);
     return true;
   };
-  if (hubs_used && ((h[2] & 6) != 0 || ((h[2] & 16) != 0 && can_cut()))) {
+  if (hubs_used && ((h[2] & 6) != 0 || ((h[2] & 16) != 0 && can_cut(n_active)))) {
     // The filter itself found a hub whose exact state an edge needs: nothing has been replayed yet.
     hipLaunchKernelGGL(k_reset_cc, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra, S.a_rb, S.cc,
                        d_violation, nullptr, 0u);
@@ -1548,6 +1556,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     if (violated || S.force_rollback) {
       // Undo the stage and replay it without any tentatively settled edge, every edge on its own.
       ++*S.rollbacks;
+      S.hub_list_dirty = 1;   // (whatever the workers recorded)
       hipLaunchKernelGGL(k_restore_roots, dim3(Blocks(n_work)), dim3(256), 0, s, n_work, w_ra, w_rb,
                          nodes, S.bk_ds, S.bk_cons, S.bk_flags, S.stats);
       hipLaunchKernelGGL(k_clear_kept, dim3(Blocks(n_b)), dim3(256), 0, s, n_b, S.masks, S.e_gpos, kept_all);
