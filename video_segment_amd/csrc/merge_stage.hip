@@ -946,6 +946,94 @@ struct HubMarkFinish {
   }
 };
 
+// A hub that absorbed hundreds of regions is a chain of dependent f32 operations -- one thread walks it at
+// ~19 ns per region, every load behind the one before; on a noisy input a few such hubs per stage were
+// 80 ms per chunk (and a thread that prefetches four regions at a time still waits three dependent loads
+// per four).  From kHubWaveMin regions on a hub gets a wavefront: 64 regions at a time, all lanes
+// load (sequence number -> region -> state) and compute what does not depend on the mean -- the hub's
+// size before every absorption is a prefix sum, so are the weights ca, cb and the products ca * x --,
+// then lane ch replays channel ch through the 64 steps  h = ca * x + cb * h  (coefficients from LDS,
+// the mean before every step left behind there), and all lanes check the split tests of their
+// regions against those means.  Same operations, same order, same roundings as the thread form.
+constexpr int kHubWaveMin = 32;
+__global__ __launch_bounds__(64) void k_hub_apply_wave(const int32_t* __restrict__ num_runs,
+                                                        const int32_t* __restrict__ run_off,
+                                                        const int32_t* __restrict__ run_cnt,
+                                                        const uint32_t* __restrict__ hub_sorted,
+                                                        const uint32_t* __restrict__ seq_sorted,
+                                                        const int32_t* __restrict__ mark, NodeArrays nodes,
+                                                        float split_s, int32_t* __restrict__ violation,
+                                                        int32_t* __restrict__ hub_excl) {
+  __shared__ float coef[64][4];     // ca * x (three channels), cb
+  __shared__ float before[64][4];   // the hub's mean before step l
+  const int lane = threadIdx.x;
+  const int n_runs = *num_runs;
+  for (int r = blockIdx.x; r < n_runs; r += gridDim.x) {
+    const int cnt = run_cnt[r];
+    if (cnt < kHubWaveMin) continue;
+    const int off = run_off[r];
+    const int hub = (int)hub_sorted[off];
+    const float4 hs = nodes.desc_sz[hub];
+    float h = lane == 0 ? hs.x : lane == 1 ? hs.y : hs.z;   // (lanes 0..2: one channel each)
+    int S = __float_as_int(hs.w);
+    int bad_seq = -1;
+    for (int base = 0; base < cnt; base += 64) {
+      const int i = base + lane;
+      const bool valid = i < cnt;
+      uint32_t sq = 0, xv = 0;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) {
+        sq = seq_sorted[off + i];
+        xv = (uint32_t)mark[sq];
+        o = nodes.desc_sz[xv & ~(uint32_t)kHubTestBit];
+      }
+      const int osz = valid ? __float_as_int(o.w) : 0;
+      const int incl = WaveInclusiveSum(osz);
+      const int Sb = S + incl - osz;   // the hub's size before this absorption
+      float4 q = make_float4(0.f, 0.f, 0.f, 1.f);   // (no region: the mean stays)
+      if (valid) {
+        const float denom = 1.0f / (float)(osz + Sb);
+        const float ca = (float)osz * denom;
+        const float cb = (float)Sb * denom;
+        q = make_float4(ca * o.x, ca * o.y, ca * o.z, cb);
+      }
+      coef[lane][0] = q.x;
+      coef[lane][1] = q.y;
+      coef[lane][2] = q.z;
+      coef[lane][3] = q.w;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 3) {
+#pragma unroll 8
+        for (int l = 0; l < 64; ++l) {
+          before[l][lane] = h;
+          h = coef[l][lane] + coef[l][3] * h;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      bool fails = false;
+      if (valid && (xv & (uint32_t)kHubTestBit)) {
+        const float x = before[lane][0] - o.x, y = before[lane][1] - o.y, z = before[lane][2] - o.z;
+        fails = (x * x + y * y + z * z) * (1.0f / 3.0f) > split_s;
+      }
+      const unsigned long long fm = __ballot(fails);
+      if (fm && bad_seq < 0) bad_seq = __builtin_amdgcn_readlane((int)sq, (int)__builtin_ctzll(fm));
+      S += __builtin_amdgcn_readlane(incl, 63);
+      __builtin_amdgcn_wave_barrier();
+    }
+    const float r0 = ReadLaneF(h, 0), r1 = ReadLaneF(h, 1), r2 = ReadLaneF(h, 2);
+    if (lane == 0) {
+      if (bad_seq >= 0) {
+        atomicOr(violation, kHubVioSplit);
+        HubViolationAt(hub_excl, 1, bad_seq);
+        HubExclude(hub_excl, nodes.flags, hub);
+      }
+      nodes.desc_sz[hub] = make_float4(r0, r1, r2, __int_as_float(S));
+    }
+  }
+}
+
 // One thread per hub: MergeStates (merge_common.h) with the hub as the survivor, once per absorbed
 // region, in sequence order (the list is sorted by hub, stably).  The loads do not depend on the
 // recurrence: four regions are fetched ahead of the arithmetic.
@@ -961,6 +1049,7 @@ __global__ __launch_bounds__(64) void k_hub_apply(const int32_t* __restrict__ nu
   const int r = blockIdx.x * 64 + threadIdx.x;
   if (r >= *num_runs) return;
   const int off = run_off[r], cnt = run_cnt[r];
+  if (cnt >= kHubWaveMin) return;   // (k_hub_apply_wave)
   const int hub = (int)hub_sorted[off];
   const float4 hs = nodes.desc_sz[hub];
   float h0 = hs.x, h1 = hs.y, h2 = hs.z;
@@ -1541,6 +1630,11 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       RunsOfSortedKeys(S.scan, key_sorted, n_abs, run_off, run_cnt, d_hub_runs, s);
       hipLaunchKernelGGL(k_hub_apply, dim3((unsigned)((n_abs + 63) / 64)), dim3(64), 0, s, d_hub_runs, run_off,
                          run_cnt, key_sorted, seq_sorted, wa.hub_mark, nodes, T.split_s, d_violation, S.hub_excl);
+      if (n_abs >= kHubWaveMin) {   // (the hubs that absorbed many: a wavefront each)
+        hipLaunchKernelGGL(k_hub_apply_wave, dim3((unsigned)std::min(n_abs / kHubWaveMin, 2048)), dim3(64), 0, s,
+                           d_hub_runs, run_off, run_cnt, key_sorted, seq_sorted, wa.hub_mark, nodes, T.split_s,
+                           d_violation, S.hub_excl);
+      }
     }
     if (info) info->hub_absorbed += n_abs;
   }
