@@ -90,7 +90,7 @@ def test_stage_decomposition_variants(vsg, monkeypatch, env):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import stress_parity as sp
-    for idx in range(12):
+    for idx in range(8):   # (27 variants x 8 random cases; the GPU suite's budget: tests/conftest.py)
         sp.one_case(np.random.default_rng([77, idx]), idx)
 
 
