@@ -1126,7 +1126,11 @@ __global__ __launch_bounds__(256) void k_hub_exclude(const int32_t* __restrict__
 __global__ __launch_bounds__(256) void k_hub_check(const int32_t* __restrict__ excl, NodeArrays nodes,
                                                     int32_t* __restrict__ num_hub) {
   const int cnt = excl[0];
-  if (cnt > 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(num_hub, cnt > kHubExclCap ? 12 : 8);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // (bits 8 ..: how many edges the filter recorded -- what a cut of the stage would cost)
+    const int bits = (cnt > 0 ? (cnt > kHubExclCap ? 12 : 8) : 0) | (min(excl[1], 0xfffff) << 8);
+    if (bits) atomicOr(num_hub, bits);
+  }
   const int n = min(cnt, kHubExclCap);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     if (nodes.hub8[excl[4 + i]]) {
@@ -1340,13 +1344,16 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   // the regions that broke a rule as ordinary regions (they are on the exclusion list), and after
   // kHubMaxAttempts of those -- or when the list has overflowed -- without hubs.
   // (a stage inside one bucket, whose edges the host tables can locate, with cuts left)
-  // (VSG_CUT_MIN_WORK: stages of fewer replayed edges are replayed edge by edge instead -- measured at
-  // 32 768: nothing gained on the value-noise input, whose 66 cuts per chunk sit in small stages, and a
-  // long +-40-noise stream back at one second per chunk: a small stage's edge-by-edge replay is still
-  // one percolating component.  0.)
-  auto can_cut = [&](int work) {
-    return work >= S.hub_cut_min_work && bucket_hi == bucket + 1 && S.hub_splits_left > 0 && S.bucket_base_host &&
-           S.list_off_host && S.list_slot_base_host;
+  // ... and a stage for which the cuts cost less than its edge-by-edge replay could: a cut is two more
+  // stages (0.2-0.3 ms of launches and waits each), the replay of a stage is one -- whose largest component,
+  // on one wavefront at ~0.2 us per edge, is at worst all of its n_b edges (a replay settles nothing in
+  // advance).  At 1920x1080 a stage has 0.3-8 M edges and tens of violations: cut.  A 320x240 stream of
+  // uniformly random frames has stages of a few thousand edges with as many violations each: cutting
+  // them made its merge 1.5 s per chunk instead of 0.4.  (VSG_CUT_MIN_WORK: a floor on the replayed edges
+  // as well -- measured at 2 K / 8 K / 32 K on the long 1080p noise stream: all worse than 0.)
+  auto can_cut = [&](int work, long long violations) {
+    return work >= S.hub_cut_min_work && (long long)n_b > 1500ll * (violations + 1) && bucket_hi == bucket + 1 &&
+           S.hub_splits_left > 0 && S.bucket_base_host && S.list_off_host && S.list_slot_base_host;
   };
   auto retry_without_broken_hubs = [&](int violated, int work, bool list_complete, const uint32_t* work_gpos) -> bool {
     for (int q = 0; q < 6; ++q) S.hub_reasons[q] += (violated >> (2 + q)) & 1;
@@ -1354,11 +1361,14 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     if (info) ++info->hub_retries;
     // The edges at which rules were broken, as positions inside the stage, in order.
     std::vector<int> cuts;
-    if (can_cut(work)) {
-      int head[4] = {0, 0, 0, 0};
+    int head[4] = {0, 0, 0, 0};
+    if (can_cut(work, 0)) {
+      VSG_HIP(hipMemcpyAsync(head, S.hub_excl, sizeof(head), hipMemcpyDeviceToHost, s));
+      VSG_HIP(hipStreamSynchronize(s));
+    }
+    if (can_cut(work, (long long)head[1] + (work_gpos ? head[2] : 0))) {
       int at[2 * kHubCutCap];
       if (work_gpos) hipLaunchKernelGGL(k_hub_cut_gpos, dim3(1), dim3(64), 0, s, S.hub_excl, work_gpos);
-      VSG_HIP(hipMemcpyAsync(head, S.hub_excl, sizeof(head), hipMemcpyDeviceToHost, s));
       VSG_HIP(hipMemcpyAsync(at, S.hub_excl + 4 + kHubExclCap, sizeof(at), hipMemcpyDeviceToHost, s));
       VSG_HIP(hipStreamSynchronize(s));
       for (int i = 0; i < std::min(head[1], kHubCutCap); ++i) cuts.push_back(at[i]);
@@ -1442,7 +1452,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     if (S.hub_attempt == 0 && S.hubs_off == 0) ResetHubExclusions(S, nodes, s);
     return true;
   };
-  if (hubs_used && ((h[2] & 6) != 0 || ((h[2] & 16) != 0 && can_cut(n_active)))) {
+  if (hubs_used && ((h[2] & 6) != 0 || ((h[2] & 16) != 0 && can_cut(n_active, (long long)(h[2] >> 8))))) {
     // The filter itself found a hub whose exact state an edge needs: nothing has been replayed yet.
     hipLaunchKernelGGL(k_reset_cc, dim3(Blocks(n_active)), dim3(256), 0, s, n_active, S.a_ra, S.a_rb, S.cc,
                        d_violation, nullptr, 0u);
