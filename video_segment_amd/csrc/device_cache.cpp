@@ -62,7 +62,10 @@ size_t RoundUp(size_t bytes) {
   return (bytes + g - 1) / g * g;
 }
 
-constexpr long long kPinnedLimit = 1ll << 30;
+// (Cached pinned host bytes per device.  At 1 GiB the streams of a bench run left just under the limit
+// behind, and the close of a small seam-3 window a few legs later paid for evicting them: 80 ms of
+// hipHostFree in one window of BASELINE configs[1], `slowest_window.phases.close` in r6_c.)
+constexpr long long kPinnedLimit = 4ll << 30;
 
 long long DefaultLimit() {
   if (const char* e = getenv("VSG_DEVICE_CACHE_MB")) return std::max(0ll, atoll(e)) << 20;
