@@ -1196,18 +1196,34 @@ __global__ void k_plain_edge(int bucket, int jb, const ListDesc* __restrict__ li
   }
 }
 
-// Position, inside its bucket, of the edge with kept position `gpos` (the order of the edge sequence: the
-// bucket's edges list by list), from the host copies of the bucket tables.
-static long long BucketPosition(const MergeScratch& S, const MergeParams& P, int bucket, uint32_t gpos) {
+// Position, in the edge sequence (bucket by bucket, inside a bucket list by list), of the edge with kept
+// position `gpos`, which lies in one of the buckets [b_lo, b_hi): from the host copies of the bucket tables.
+static long long SequencePosition(const MergeScratch& S, const MergeParams& P, int b_lo, int b_hi, uint32_t gpos) {
   const int L = P.num_lists;
   int lo = 0, hi = L;   // the last list that starts at or before gpos
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (S.list_slot_base_host[mid] <= gpos) lo = mid; else hi = mid;
   }
-  const long long p = (long long)gpos - (long long)S.list_slot_base_host[lo];
-  const int32_t* row = S.bucket_base_host + (size_t)bucket * (L + 1);
-  return (long long)row[lo] + (p - (long long)S.list_off_host[(size_t)lo * (kNumBuckets + 2) + bucket]);
+  const int l = lo;
+  const long long p = (long long)gpos - (long long)S.list_slot_base_host[l];
+  const int32_t* off = S.list_off_host + (size_t)l * (kNumBuckets + 2);   // where the list's edges of bucket b start
+  int b0 = b_lo, b1 = b_hi;   // the last bucket of the range whose part of the list starts at or before p
+  while (b1 - b0 > 1) {
+    const int mid = (b0 + b1) >> 1;
+    if (off[mid] <= p) b0 = mid; else b1 = mid;
+  }
+  const int32_t* row = S.bucket_base_host + (size_t)b0 * (L + 1);
+  return (long long)S.bucket_prefix_host[b0] + row[l] + (p - (long long)off[b0]);
+}
+// The bucket of [b_lo, b_hi) that holds sequence position g (the last one that starts at or before it).
+static int BucketOfPosition(const MergeScratch& S, int b_lo, int b_hi, long long g) {
+  int b0 = b_lo, b1 = b_hi;
+  while (b1 - b0 > 1) {
+    const int mid = (b0 + b1) >> 1;
+    if ((long long)S.bucket_prefix_host[mid] <= g) b0 = mid; else b1 = mid;
+  }
+  return b0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1343,7 +1359,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   // several buckets, or without the host tables that locate an edge, the stage is run again with
   // the regions that broke a rule as ordinary regions (they are on the exclusion list), and after
   // kHubMaxAttempts of those -- or when the list has overflowed -- without hubs.
-  // (a stage inside one bucket, whose edges the host tables can locate, with cuts left)
+  // (a stage whose edges the host tables can locate -- one bucket or a group of buckets --, with cuts left)
   // ... and a stage for which the cuts cost less than its edge-by-edge replay could: a cut is two more
   // stages (0.2-0.3 ms of launches and waits each), the replay of a stage is one -- whose largest component,
   // on one wavefront at ~0.2 us per edge, is at worst all of its n_b edges (a replay settles nothing in
@@ -1352,8 +1368,8 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
   // them made its merge 1.5 s per chunk instead of 0.4.  (VSG_CUT_MIN_WORK: a floor on the replayed edges
   // as well -- measured at 2 K / 8 K / 32 K on the long 1080p noise stream: all worse than 0.)
   auto can_cut = [&](int work, long long violations) {
-    return work >= S.hub_cut_min_work && (long long)n_b > 1500ll * (violations + 1) && bucket_hi == bucket + 1 &&
-           S.hub_splits_left > 0 && S.bucket_base_host && S.list_off_host && S.list_slot_base_host;
+    return work >= S.hub_cut_min_work && (long long)n_b > 1500ll * (violations + 1) && S.hub_splits_left > 0 &&
+           S.bucket_base_host && S.bucket_prefix_host && S.list_off_host && S.list_slot_base_host;
   };
   auto retry_without_broken_hubs = [&](int violated, int work, bool list_complete, const uint32_t* work_gpos) -> bool {
     for (int q = 0; q < 6; ++q) S.hub_reasons[q] += (violated >> (2 + q)) & 1;
@@ -1361,6 +1377,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
     if (info) ++info->hub_retries;
     // The edges at which rules were broken, as positions inside the stage, in order.
     std::vector<int> cuts;
+    const long long g_stage = (long long)S.bucket_prefix_host[bucket] + j0;   // the stage's first edge in the sequence
     int head[4] = {0, 0, 0, 0};
     if (can_cut(work, 0)) {
       VSG_HIP(hipMemcpyAsync(head, S.hub_excl, sizeof(head), hipMemcpyDeviceToHost, s));
@@ -1374,7 +1391,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       for (int i = 0; i < std::min(head[1], kHubCutCap); ++i) cuts.push_back(at[i]);
       if (work_gpos) {
         for (int i = 0; i < std::min(head[2], kHubCutCap); ++i) {
-          cuts.push_back((int)(BucketPosition(S, P, bucket, (uint32_t)at[kHubCutCap + i]) - j0));
+          cuts.push_back((int)(SequencePosition(S, P, bucket, bucket_hi, (uint32_t)at[kHubCutCap + i]) - g_stage));
         }
       }
       std::sort(cuts.begin(), cuts.end());
@@ -1407,8 +1424,9 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
         if (info) sub.want_components = info->want_components;
         ++S.hub_split_depth;
         if (plain) ++S.hubs_off;
-        RunBucketStage(bucket, j0 + off, n, lists, bucket_base, list_slot_base, kept_all, nodes, P, inert_mode, S, s,
-                       info ? &sub : nullptr);
+        const int b_at = BucketOfPosition(S, bucket, bucket_hi, g_stage + off);   // (a group: the part starts in a later bucket)
+        RunBucketStage(b_at, (int)(g_stage + off - S.bucket_prefix_host[b_at]), n, lists, bucket_base, list_slot_base,
+                       kept_all, nodes, P, inert_mode, S, s, info ? &sub : nullptr);
         if (plain) --S.hubs_off;
         --S.hub_split_depth;
         replayed += sub.replayed;
@@ -1430,8 +1448,9 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       int prev = 0;
       for (const int c : cuts) {
         part(prev, c - prev, false);
-        hipLaunchKernelGGL(k_plain_edge, dim3(1), dim3(1), 0, s, bucket, j0 + c, lists, bucket_base, list_slot_base,
-                           kept_all, nodes, P, plain, S.stats);
+        const int b_c = BucketOfPosition(S, bucket, bucket_hi, g_stage + c);
+        hipLaunchKernelGGL(k_plain_edge, dim3(1), dim3(1), 0, s, b_c, (int)(g_stage + c - S.bucket_prefix_host[b_c]), lists,
+                           bucket_base, list_slot_base, kept_all, nodes, P, plain, S.stats);
         ++replayed;
         prev = c + 1;
       }
