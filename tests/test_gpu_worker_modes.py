@@ -70,6 +70,12 @@ def test_chain_self_check_is_silent(vsg, monkeypatch, capfd):
                                  {"VSG_ACTIVE_CAP": "64", "VSG_SPINE_MIN": "32", "VSG_FORCE_ROLLBACK": "1"},
                                  # the wide worker (merge_wide.hip: several wavefronts per component in
                                  # lock-step rounds; off by default) on every component it can take
+                                 # hub regions off; violated stages never cut (rerun with the exclusion list / edge by
+                                 # edge) or cut once; every stage cut whatever it costs
+                                 {"VSG_HUBS": "0"},
+                                 {"VSG_HUB_SPLITS": "0"},
+                                 {"VSG_HUB_SPLITS": "1", "VSG_SPINE_MIN": "32"},
+                                 {"VSG_HUB_SPLITS": "0", "VSG_FORCE_ROLLBACK": "1"},
                                  # the hand-written radix sort for every size / for none (csrc/radix_sort.hip)
                                  {"VSG_SORT_HAND": "0:2000000000", "VSG_SPINE_MIN": "32", "VSG_SPINE_CHECK": "1"},
                                  {"VSG_SORT_HAND": "1:0"},

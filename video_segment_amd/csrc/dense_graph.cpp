@@ -526,6 +526,7 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
   const int hubs_default = getenv("VSG_HUBS") ? atoi(getenv("VSG_HUBS")) : 1;
   S.hubs = hubs_default;
   S.hub_excl = hub_excl_.get();
+  S.hub_max_splits = getenv("VSG_HUB_SPLITS") ? std::max(0, atoi(getenv("VSG_HUB_SPLITS"))) : kHubMaxSplits;
   S.hub_cut_min_work = getenv("VSG_CUT_MIN_WORK") ? atoi(getenv("VSG_CUT_MIN_WORK")) : 0;
   // (a stage takes its marks off again; an exception in the middle of one must not leave any behind)
   VSG_HIP(hipMemsetAsync(hub8_.get(), 0, N, stream_));

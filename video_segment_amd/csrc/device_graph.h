@@ -295,6 +295,7 @@ struct MergeScratch {
   int hub_splits_left;   // times the current top-level stage may still be cut at a violating edge (below)
   int hub_split_depth;   // (> 0 inside the parts of a cut stage)
   int hub_list_dirty;    // the head of the list has to be cleared before the next stage uses it
+  int hub_max_splits;    // cuts per top-level stage (VSG_HUB_SPLITS, kHubMaxSplits; 0: a violated stage is rerun as a whole)
   int hub_cut_min_work;  // stages of fewer replayed edges are not cut (VSG_CUT_MIN_WORK, 0: measured, 32768 is worse)
   long long hub_splits;  // cuts in this Segment call
   const uint32_t* list_slot_base_host;   // first kept position of every list (host copy), for StagePosition

@@ -1267,7 +1267,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       VSG_HIP(hipMemsetAsync(S.hub_excl + 1, 0, 2 * sizeof(int32_t), s));   // (the exclusion list stays)
     }
   }
-  if (S.hub_attempt == 0 && S.hub_split_depth == 0) S.hub_splits_left = kHubMaxSplits;
+  if (S.hub_attempt == 0 && S.hub_split_depth == 0) S.hub_splits_left = S.hub_max_splits;
   int32_t* d_num_leaders = S.num_active + 5;
   // The stage's non-empty (bucket, list) segments, from the host copy of the bucket table.
   FilterSegs segs = {nullptr, nullptr, nullptr, 0};
