@@ -140,7 +140,10 @@ void DenseGraphHip::Reset(int max_frames) {
 void DenseGraphHip::ForgetLearned() {
   spine_limit_bucket_ = 0x7fffffff;
   spine_limit_age_ = 0;
-  for (int b = 0; b < 2; ++b) spine_low_fails_[b] = spine_low_cooldown_[b] = 0;
+  for (int b = 0; b < 2; ++b) {
+    spine_low_fails_[b] = spine_low_cooldown_[b] = spine_low_cost_age_[b] = 0;
+    spine_low_cost_fail_[b] = spine_low_cost_skip_[b] = 0;
+  }
   wave_target_active_ = kNoWindowTarget;
   window_target_.clear();
   hub_bucket_pause_.clear();
@@ -737,7 +740,14 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
     std::fill(window_unpaid_.begin(), window_unpaid_.end(), 0);
   }
   int group_width = 1;
+  double low_bucket_ms[2] = {0, 0};
   for (int b = 0, hi = 0; b < kNumBuckets; b = hi) {
+    const double t_bucket0 = b < 2 ? NowMs() : 0;
+    struct LowBucketTimer {   // (what buckets 0 and 1 cost: see the cooldown of the tree replay below)
+      double* out;
+      double t0;
+      ~LowBucketTimer() { if (out) *out += NowMs() - t0; }
+    } low_timer{b < 2 ? &low_bucket_ms[b] : nullptr, t_bucket0};
     hi = b + 1;
     if (group_buckets && b >= first_plain) {   // as many buckets as fit the scratch arrays
       while (hi < kNumBuckets && hi - b < group_width &&
@@ -894,12 +904,33 @@ void DenseGraphHip::SegmentLists(int min_region_size, bool force_constraints, in
       }
     }
   }
+  // The tree replay in the first two buckets: where its assumption keeps failing (two chunks in a row)
+  // the bucket goes without it for a while -- but only while that is the cheaper of the two.  On the
+  // headline input, once constraints have accumulated for 35 chunks, an edge between regions of
+  // different constraints sits inside the giant component of bucket 1: a failed replay costs the chunk
+  // 30-40 ms (the stage again with the ordinary workers), a bucket without the replay 180 ms (the giant
+  // component on single wavefronts, 64 stages by the window target) -- eight chunks in a row, as up to
+  // round 5, was the wrong way round.  Both costs are measured (the bucket's wall time); a skip that is
+  // not known to be cheaper lasts one chunk, which measures it.
   for (int b = 0; b < 2; ++b) {
-    if (spine_low_skip[b]) continue;
+    if (++spine_low_cost_age_[b] > 64) {   // (what was measured ages)
+      spine_low_cost_age_[b] = 0;
+      spine_low_cost_fail_[b] = spine_low_cost_skip_[b] = 0;
+    }
+    if (spine_low_skip[b]) {
+      spine_low_cost_skip_[b] = low_bucket_ms[b];
+      if (spine_low_cost_fail_[b] > 0 && spine_low_cost_skip_[b] >= spine_low_cost_fail_[b]) spine_low_cooldown_[b] = 0;
+      continue;
+    }
+    if (spine_low_failed[b]) spine_low_cost_fail_[b] = low_bucket_ms[b];
     spine_low_fails_[b] = spine_low_failed[b] ? spine_low_fails_[b] + 1 : 0;
     if (spine_low_fails_[b] >= 2) {
       spine_low_fails_[b] = 0;
-      spine_low_cooldown_[b] = 8;
+      if (spine_low_cost_skip_[b] <= 0) {
+        spine_low_cooldown_[b] = 1;                                   // not known: one chunk measures it
+      } else if (spine_low_cost_skip_[b] < spine_low_cost_fail_[b]) {
+        spine_low_cooldown_[b] = 8;
+      }
     }
   }
   timings_.optimistic_stages = optimistic_stages_;

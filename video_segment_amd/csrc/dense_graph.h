@@ -189,6 +189,10 @@ class DenseGraphHip {
   int spine_limit_age_ = 0;               // chunks since it was learned (forgotten after 8: one atypical
                                           // chunk must not switch the tree replay off for good)
   int spine_low_fails_[2] = {0, 0}, spine_low_cooldown_[2] = {0, 0};   // the same for buckets 0 and 1
+  // ... and what the bucket cost (ms) the last time the replay failed in it / the last time it went
+  // without: a bucket is skipped only while that is known to be the cheaper of the two (0: not known)
+  double spine_low_cost_fail_[2] = {0, 0}, spine_low_cost_skip_[2] = {0, 0};
+  int spine_low_cost_age_[2] = {0, 0};
   DevBuf<int32_t> spine_pool_;   // scratch of the Kruskal-tree replay (merge_spine.hip)
   static constexpr int64_t kNoWindowTarget = 1ll << 40;
   int64_t wave_target_active_ = kNoWindowTarget;   // active edges per stage (SegmentLists), learned

@@ -50,7 +50,7 @@ constexpr int kHubMaxSplits = 64;
 // stage) / by the workers and k_hub_apply (number of the work edge), [4 ..) the regions, then the two
 // lists of edges (kHubCutCap each; more violations than that are found by the parts of the cut stage).
 constexpr int kHubCutCap = 64;
-constexpr int kHubListInts = 4 + kHubExclCap + 2 * kHubCutCap;
+constexpr int kHubListInts = 4 + kHubExclCap + 3 * kHubCutCap;   // ([3] / third list: kept positions of edges, kind 2)
 
 struct NodeArrays {
   int32_t* parent;

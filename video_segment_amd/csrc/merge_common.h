@@ -288,7 +288,8 @@ __device__ __forceinline__ int AtomicOrFlags(uint8_t* flags, int r, int bits) {
 // worker an edge that breaks a hub rule): marked broken -- the stage is redone -- and, once, put on
 // the exclusion list that the retry turns into kFlagHubExcluded marks.
 // An edge of the stage that broke a hub rule (device_graph.h: kHubCutCap): the stage is exact in front of
-// the earliest one.  kind 0: position inside the stage (the filter), 1: number of the work edge.
+// the earliest one.  kind 0: position inside the stage (the filter), 1: number of the work edge, 2: kept
+// position of the edge (the workers of a tree replay's side clusters, whose edge numbers are their own).
 __device__ __forceinline__ void HubViolationAt(int32_t* list, int kind, int position) {
   const int q = atomicAdd(&list[1 + kind], 1);
   if (q < kHubCutCap) list[4 + kHubExclCap + kind * kHubCutCap + q] = position;

@@ -821,7 +821,10 @@ __global__ __launch_bounds__(256) void k_merge_small(const int32_t* __restrict__
         n_regular += (stat == 2);
         n_small += (stat == 3);
         if (out == kOutKeep) {
-          if (T.side) atomicOr(violation, 2);
+          if (T.side) {   // (a side cluster of a tree replay does not end up as one region: the stage is cut here)
+            atomicOr(violation, 2);
+            HubViolationAt(hub_excl, 2, (int)s_gpos[p]);
+          }
           kept_all[s_gpos[p]] = 1;
           StoreState(nodes, r1, s1);
           StoreState(nodes, r2, s2);
@@ -1383,8 +1386,8 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       VSG_HIP(hipMemcpyAsync(head, S.hub_excl, sizeof(head), hipMemcpyDeviceToHost, s));
       VSG_HIP(hipStreamSynchronize(s));
     }
-    if (can_cut(work, (long long)head[1] + (work_gpos ? head[2] : 0))) {
-      int at[2 * kHubCutCap];
+    if (can_cut(work, (long long)head[1] + (work_gpos ? head[2] + head[3] : 0))) {
+      int at[3 * kHubCutCap];
       if (work_gpos) hipLaunchKernelGGL(k_hub_cut_gpos, dim3(1), dim3(64), 0, s, S.hub_excl, work_gpos);
       VSG_HIP(hipMemcpyAsync(at, S.hub_excl + 4 + kHubExclCap, sizeof(at), hipMemcpyDeviceToHost, s));
       VSG_HIP(hipStreamSynchronize(s));
@@ -1392,6 +1395,9 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       if (work_gpos) {
         for (int i = 0; i < std::min(head[2], kHubCutCap); ++i) {
           cuts.push_back((int)(SequencePosition(S, P, bucket, bucket_hi, (uint32_t)at[kHubCutCap + i]) - g_stage));
+        }
+        for (int i = 0; i < std::min(head[3], kHubCutCap); ++i) {   // (kept positions as they are)
+          cuts.push_back((int)(SequencePosition(S, P, bucket, bucket_hi, (uint32_t)at[2 * kHubCutCap + i]) - g_stage));
         }
       }
       std::sort(cuts.begin(), cuts.end());
@@ -1458,7 +1464,7 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       if (info) info->replayed = replayed;
       return true;
     }
-    if (violated & kVioCut) return false;   // (not a matter of hubs: the caller replays the stage edge by edge)
+    if (violated & (kVioCut | 2)) return false;   // (not a matter of hubs: the caller replays the stage its own way)
     int& depth = (list_complete && S.hub_attempt + 1 < kHubMaxAttempts) ? S.hub_attempt : S.hubs_off;
     if (&depth == &S.hub_attempt) {
       hipLaunchKernelGGL(k_hub_exclude, dim3(16), dim3(256), 0, s, S.hub_excl, nodes);
@@ -1686,6 +1692,9 @@ void RunBucketStage(int bucket, int j0, int n_b, const ListDesc* lists, const in
       clear_marks();
       clear_hub_marks();   // (the restored flags carry the marks the filter had set)
       VSG_HIP(hipGetLastError());
+      // (A kept edge in a side cluster of the tree replay, at a known position: the stage is cut there and
+      // the tree replay runs again on the parts -- not the whole stage on the ordinary workers.)
+      if (spine && violated == 2 && !S.force_rollback && retry_without_broken_hubs(2, n_work, true, w_gpos)) return;
       if (spine && violated == 2 && !S.force_rollback) {
         // Only the tree replay's assumption failed (an edge of a large component was kept): the
         // same stage again with the ordinary workers.  From the third bucket on that is the rule

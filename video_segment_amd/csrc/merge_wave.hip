@@ -972,7 +972,13 @@ __global__ __launch_bounds__(128) void k_merge_wave(const int32_t* __restrict__ 
       WaveSync();
 
       if (valid && my_kept) kept_all[gpos] = 1;
-      if (T.side && __ballot(my_kept) && lane == 0) atomicOr(violation, 2);
+      if (T.side) {   // (a side cluster with a kept edge: the earliest one of the batch is where the stage is cut)
+        const unsigned long long km = __ballot(valid && my_kept);
+        if (km && lane == (int)__builtin_ctzll(km)) {
+          atomicOr(violation, 2);
+          HubViolationAt(hub_excl, 2, (int)gpos);
+        }
+      }
       // ---- write the changed regions back, reset the table ---------------------------------------
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
