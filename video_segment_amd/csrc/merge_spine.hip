@@ -536,14 +536,20 @@ struct SpineEmit {
   const int32_t* te_e;
   int32_t* scan;
   int32_t* sp_child;
-  int32_t* sp_is_a;
+  int32_t* sp_is_a;   // bit 0: the child is the edge's first end; the bits above: where the edge is in the
+                      // level's sorted arrays (its kept position is s_gpos[...]: where a stage is cut when
+                      // the spine keeps the edge, k_spine)
+  const int32_t* comp_base;
+  const int32_t* comp_off;
+  int K;
   __device__ void operator()(int e, int f, int before) const {
     scan[e] = before;
     if (f) {
       const int ju = childidx[eu[e]];
       const bool child_is_u = ju != kNone && te_e[ju] == e;
       sp_child[before] = child_is_u ? eu[e] : ev[e];
-      sp_is_a[before] = child_is_u ? 1 : 0;
+      const int lo = CompOf(comp_base, K, e);
+      sp_is_a[before] = ((comp_off[lo] + (e - comp_base[lo])) << 1) | (child_is_u ? 1 : 0);
     }
   }
 };
@@ -588,7 +594,8 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
                                                const int32_t* __restrict__ sp_is_a, NodeArrays nodes, StageThr T,
                                                int optimistic, int32_t* __restrict__ violation,
                                                unsigned long long* __restrict__ stats,
-                                               int32_t* __restrict__ start_pos, int max_steps) {
+                                               int32_t* __restrict__ start_pos, int max_steps,
+                                               const uint32_t* __restrict__ s_gpos, int32_t* __restrict__ hub_excl) {
   __shared__ SpineRing ring;
   const int k = blockIdx.x;
   if (k >= K) return;
@@ -629,7 +636,7 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
         const int i = next + q * 64 + lane;
         vd[q] = i < n;
         c[q] = vd[q] ? sp_child[beg + i] : root_vertex[k];
-        isa[q] = vd[q] ? sp_is_a[beg + i] : 0;
+        isa[q] = vd[q] ? (sp_is_a[beg + i] & 1) : 0;
       }
       for (bool any = true; any;) {   // all root searches of the fill advance together
         int pa[kSpineFill];
@@ -791,6 +798,10 @@ __global__ __launch_bounds__(64 * (1 + kSpineReaders)) void k_spine(int K, const
       const int out = DecideEdge(s1, s2, T, stat);
       if (out == kOutKeep) {   // the structure assumed a merge
         violated = 2;
+        // (the edge, by its kept position: where the host cuts the stage -- merge_stage.hip)
+        if (lane == 0 && hub_excl && s_gpos) {
+          HubViolationAt(hub_excl, 2, (int)s_gpos[sp_is_a[beg + base + start] >> 1]);
+        }
         break;
       }
       if (optimistic) {
@@ -1653,7 +1664,7 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   if (!pool.ok) return false;
   hipLaunchKernelGGL(k_compact_side, dim3(Blocks(mE)), dim3(256), 0, s, mE, flag, scan, side_key, sk_in, si_in);
   // spine edges (the scan buffer is reused once the side positions are consumed)
-  FusedScan(S.scan, StateFlagValue{spine_flag, 1}, SpineEmit{eu, ev, childidx, te_e, scan, sp_child, sp_is_a},
+  FusedScan(S.scan, StateFlagValue{spine_flag, 1}, SpineEmit{eu, ev, childidx, te_e, scan, sp_child, sp_is_a, d_base, d_off, K},
             SpineFinish{comp_spine, K}, mE, s);
   hipLaunchKernelGGL(k_comp_spine, dim3(Blocks(K)), dim3(256), 0, s, K, d_base, scan, comp_spine);
   int dbg_spine_edges = 0;
@@ -1725,7 +1736,8 @@ bool RunSpineComponents(const SpineInput& in, const WorkerArgs& wa, MergeScratch
   int32_t* start_pos = nullptr;
   const auto LaunchSpine = [&](int max_steps) {
     hipLaunchKernelGGL(k_spine, dim3(K), dim3(64 * (1 + kSpineReaders)), 0, s, K, comp_spine, root_vertex, sp_child,
-                       sp_is_a, wa.nodes, wa.T, wa.optimistic, wa.violation, wa.stats, start_pos, max_steps);
+                       sp_is_a, wa.nodes, wa.T, wa.optimistic, wa.violation, wa.stats, start_pos, max_steps,
+                       wa.s_gpos, wa.hub_excl);
   };
   if (S.spine_fast > 0 && mt >= S.spine_fast_min) {
     SpineFastArrays F;
